@@ -1,0 +1,176 @@
+/*
+ * pysdr_hip.h -- C ABI of libpysdr_hip.so: the MI355X (gfx950) implementation of
+ * the pySDR receiver hot path (per-sub-receiver LO mix -> rational polyphase
+ * resample -> detect -> AF filter -> AGC, plus the PSD FFT).
+ *
+ * The reference (aa2il/pySDR) is pure Python and has no FFI of its own; its hot
+ * path is the Python surface of module `sig_proc` (absent from the tree,
+ * reconstructed from call sites in SURVEY.md 2.2).  Every entry point below names
+ * the reference call site it stands behind.  The Python facade
+ * `pysdr_amd/sig_proc.py` binds these with ctypes.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; all functions return 0 or a negative
+ *    pysdr_status (never throw, never abort) -- the reference convention is
+ *    "print + carry on" (receiver.py:603-605).
+ *  - caller owns every host buffer; the context owns all device memory.
+ *  - pysdr_process*() are called from ONE thread (the RX thread,
+ *    receiver.py:684-725).  Setters may be called concurrently from another thread
+ *    (the Qt thread, gui.py:1713,1938) and take effect at the next process call.
+ *  - complex data are interleaved float pairs (numpy complex64 layout).
+ */
+#ifndef PYSDR_HIP_H
+#define PYSDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYSDR_MAX_RX 8 /* reference MAX_RX = 6 (params.py:33) */
+
+typedef enum {
+  PYSDR_OK = 0,
+  PYSDR_ERR_ARG = -1,      /* bad argument                                   */
+  PYSDR_ERR_NO_DEVICE = -2,/* no HIP device / hipSetDevice failed            */
+  PYSDR_ERR_HIP = -3,      /* a HIP runtime call failed (see pysdr_last_error)*/
+  PYSDR_ERR_FFT = -4,      /* rocFFT failure                                  */
+  PYSDR_ERR_STATE = -5,    /* call order / capacity violation                */
+  PYSDR_ERR_RCCL = -6      /* RCCL failure                                    */
+} pysdr_status;
+
+/* Index into the reference's MODES list (Tables.py:34). */
+typedef enum {
+  PYSDR_AM = 0, PYSDR_AM_SYNCH = 1, PYSDR_SSB = 2, PYSDR_USB = 3, PYSDR_LSB = 4,
+  PYSDR_CW = 5, PYSDR_IQ = 6, PYSDR_WFM = 7, PYSDR_WFM2 = 8, PYSDR_NFM = 9,
+  PYSDR_RTTY = 10
+} pysdr_mode;
+
+/* Rates and sizes: the fields of the reference's P object that Receiver reads
+ * (params.py:405-406,440-444; receiver.py:818-820). */
+typedef struct {
+  double  srate;       /* P.SRATE, input complex sample rate (Hz)              */
+  int32_t up, down;    /* P.UP, P.DOWN = up_dn(SRATE, FS_OUT)                  */
+  int32_t in_chunk;    /* P.IN_CHUNK_SIZE, nominal samples per chunk           */
+  int32_t max_chunks;  /* capacity: chunks per pysdr_process_batch call        */
+  int32_t ntaps_dec;   /* P.FILT_LEN, prototype length at srate*up             */
+  int32_t ntaps_af;    /* AF filter length at FS_OUT                           */
+  int32_t device;      /* HIP device ordinal                                   */
+  int32_t reserved;
+} pysdr_cfg;
+
+typedef struct pysdr_ctx pysdr_ctx;
+typedef struct pysdr_spectrum pysdr_spectrum;
+
+/* rx.agc fields read by watchdog.py:298-302 */
+typedef struct { float agc, gain, maxbuf, ref, err; } pysdr_agc_state;
+
+/* Per-RX result of one pysdr_process() call.  `am`/`iq` are caller buffers with
+ * room for `cap` output samples (complex ones need 2*cap floats); either may be
+ * NULL to skip the copy.  On return n_out = samples produced (1023/1024 at
+ * 8 MS/s -> 48 kHz, SURVEY.md 5 "non-integer chunk ratio"). */
+typedef struct {
+  float*  am;            /* rx.am  : demodulated audio (receiver.py:235)       */
+  float*  iq;            /* rx.iq  : baseband IQ at FS_OUT (receiver.py:265)   */
+  int32_t cap;
+  int32_t n_out;
+  int32_t am_is_complex; /* 1 in IQ mode                                        */
+  float   peak_in;       /* max |x|^2 of the raw chunk (rx.auto_mute input)    */
+} pysdr_out;
+
+/* ---- library ------------------------------------------------------------- */
+const char* pysdr_strerror(int status);
+const char* pysdr_last_error(void);          /* text of the last HIP/rocFFT error (thread local) */
+int pysdr_device_count(int* n);
+int pysdr_version(void);
+
+/* ---- context = one wideband stream + its sub-receivers ------------------------
+ * stands behind SDR_EXECUTIVE.create_Receivers (receiver.py:826-835). */
+int  pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out);
+void pysdr_destroy(pysdr_ctx* ctx);
+
+/* dsp.Receiver(P, frq, irx, ...) (receiver.py:835).  lo_freq is the generator
+ * frequency (= -frq); h = rx.dec.h prototype (ntaps_dec doubles);
+ * af = complex AF taps (2*ntaps_af doubles, re/im interleaved). */
+int pysdr_rx_add(pysdr_ctx* ctx, int mode, double lo_freq, const double* h,
+                 const double* af, double bfo, int* irx);
+
+/* rx.lo.change_freq(f) -> actual f (receiver.py:112,352; gui.py:1938,2011) */
+int pysdr_set_lo(pysdr_ctx* ctx, int irx, double f_hz, double* f_actual);
+/* rx.dec.h = rx.dec.filter_bank[idx] (receiver.py:127,371; gui.py:1713,1762) */
+int pysdr_set_dec_taps(pysdr_ctx* ctx, int irx, const double* h, int n);
+/* P.MODE / P.AF_FILTER_NUM / P.BFO as read by Receiver each chunk
+ * (receiver.py:114-116,130-131; gui.py:1756-1757) */
+int pysdr_set_mode(pysdr_ctx* ctx, int irx, int mode, const double* af, int n, double bfo);
+/* rx.agc.reset() / rx.demod.am_pll.reset() (receiver.py:648-649): what = 1 AGC, 2 PLL, 3 both */
+int pysdr_reset(pysdr_ctx* ctx, int irx, unsigned what);
+int pysdr_agc_get(pysdr_ctx* ctx, int irx, pysdr_agc_state* st);
+/* AGC on/off and reference level */
+int pysdr_set_agc(pysdr_ctx* ctx, int irx, int enable, float ref);
+
+/* rx.demod_data(x) for every RX of the stream on ONE chunk of host samples
+ * (receiver.py:231-235,724-725).  n = complex samples; outs[num_rx]. */
+int pysdr_process(pysdr_ctx* ctx, const float* iq_interleaved, size_t n, pysdr_out* outs);
+
+/* Same arithmetic on `nchunks` consecutive chunks of `chunk_len` samples in one
+ * launch sequence; results are identical to nchunks pysdr_process() calls.
+ * on_device != 0: iq is a device pointer (pysdr_dev_alloc) -- the replay path
+ * (receiver.py:541-559) and the throughput benchmark. */
+int pysdr_process_batch(pysdr_ctx* ctx, const void* iq, int nchunks, size_t chunk_len, int on_device);
+/* Copy results of the last process call to the host.  am/iq may be NULL.
+ * chunk_nout[nchunks] (may be NULL) receives the per-chunk output counts,
+ * peaks[nchunks] the raw-chunk max |x|^2. */
+int pysdr_fetch(pysdr_ctx* ctx, int irx, float* am, float* iq, int cap, int* n_out,
+                int* am_is_complex, int* chunk_nout, float* peaks);
+int pysdr_sync(pysdr_ctx* ctx);
+
+/* Per-call timing with HIP events recorded on the context's stream (a ring of the last
+ * 64 calls; back = 0 is the most recent call): which = 0 mix+decimate kernel,
+ * 1 detector/AF/AGC kernels, 2 whole call.  Events are only recorded while enabled. */
+int pysdr_set_profile(pysdr_ctx* ctx, int enable);
+int pysdr_get_elapsed_ms(pysdr_ctx* ctx, int which, int back, float* ms);
+/* tuning knob: LDS bytes of input tile per workgroup in the mix+decimate kernel */
+int pysdr_set_tile(pysdr_ctx* ctx, int tile_bytes, int threads);
+
+/* ---- signal_generator.quad_mixer (receiver.py:552-553,822) --------------------
+ * y = x * exp(+j*phi_n), 32-bit phase accumulator, returns phase after n samples */
+int pysdr_quad_mixer(int device, const float* x, float* y, size_t n, uint32_t phase0,
+                     uint32_t fword, uint32_t* phase_out);
+uint32_t pysdr_freq_word(double f_hz, double fs_hz, double* f_actual);
+
+/* ---- spectrum (Plotting.py:376,462; gui.py:611-631) --------------------------- */
+int  pysdr_spectrum_create(int device, int chunk_size, int nfft, int max_frames,
+                           const float* window, pysdr_spectrum** out);
+void pysdr_spectrum_destroy(pysdr_spectrum* sp);
+/* spectrum.periodogram: one frame of chunk_size (complex or real) host samples ->
+ * psd_db[nfft] (complex, fftshifted) or psd_db[nfft/2] (real input) */
+int pysdr_spectrum_frame(pysdr_spectrum* sp, const float* x, int is_complex, int db,
+                         float* psd_out, int* n_out);
+/* nframes frames taken every `hop` samples from a device-resident complex stream;
+ * d_out = device [nframes][nfft] float (dB, fftshifted) */
+int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size_t hop,
+                         void* d_out);
+int pysdr_spectrum_sync(pysdr_spectrum* sp);
+int pysdr_spectrum_elapsed_ms(pysdr_spectrum* sp, float* ms);
+
+/* ---- device memory for resident streams --------------------------------------- */
+int pysdr_dev_alloc(int device, size_t bytes, void** out);
+int pysdr_dev_free(int device, void* p);
+int pysdr_dev_upload(int device, void* dst, const void* src_host, size_t bytes);
+int pysdr_dev_download(int device, void* dst_host, const void* src, size_t bytes);
+int pysdr_dev_copy(int device, void* dst, const void* src, size_t bytes);
+
+/* ---- multi-GPU: RCCL broadcast of the wideband chunk when ONE stream's
+ * sub-receivers are split across GPUs (the analogue of MP_SCHEME 3's
+ * que[irx].put(x), receiver.py:728-739).  id = 128-byte ncclUniqueId. */
+int pysdr_comm_unique_id(char id_out[128]);
+int pysdr_comm_init(pysdr_ctx* ctx, const char id[128], int rank, int nranks);
+int pysdr_comm_bcast(pysdr_ctx* ctx, void* d_buf, size_t bytes, int root);
+int pysdr_comm_destroy(pysdr_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYSDR_HIP_H */

@@ -1,0 +1,60 @@
+"""Build libpysdr_hip.so in-tree with hipcc for gfx950 (MI355X).
+
+    python -m pysdr_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting .so travels to the GPU box with the
+repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpysdr_hip.so")
+SOURCES = ["api.hip", "mixdec.hip", "stage2.hip", "misc.hip"]
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def _newest_source_mtime():
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    files.append(os.path.join(HERE, "..", "include", "pysdr_hip.h"))
+    return max(os.path.getmtime(f) for f in files)
+
+
+def needs_build():
+    return (not os.path.exists(LIB)) or os.path.getmtime(LIB) < _newest_source_mtime()
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.path.join(ROCM, "bin", "hipcc")
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
+               "-Wno-unused-function", "-ffp-contract=off",
+               "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + \
+          ["-L" + os.path.join(ROCM, "lib"), "-lrocfft", "-ldl",
+           "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print("built", LIB)

@@ -1,0 +1,901 @@
+// C ABI of libpysdr_hip.so (include/pysdr_hip.h): context management, the per-call
+// launch sequence of the receiver hot path, spectrum (rocFFT), device-memory helpers
+// and the RCCL broadcast.  Host-side only; kernels live in mixdec/stage2/misc.hip.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <rocfft/rocfft.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <map>
+
+#include "common.h"
+
+namespace pysdr {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace pysdr
+
+using namespace pysdr;
+
+namespace {
+
+constexpr double kTwo32 = 4294967296.0;
+constexpr float kNfmFullScaleDev = 5000.0f;
+constexpr double kPllBwHz = 50.0, kPllZeta = 0.7071;
+
+inline bool mode_has_agc(int m) {
+  return m == PYSDR_AM || m == PYSDR_AM_SYNCH || m == PYSDR_SSB || m == PYSDR_USB ||
+         m == PYSDR_LSB || m == PYSDR_CW || m == PYSDR_RTTY;
+}
+inline int mode_detector(int m) {
+  switch (m) {
+    case PYSDR_AM: return kDetAbs;
+    case PYSDR_AM_SYNCH: return kDetPll;
+    case PYSDR_NFM: return kDetFm;
+    case PYSDR_CW: return kDetBfo;
+    default: return kDetNone;
+  }
+}
+
+struct RxHost {
+  int mode = PYSDR_AM;
+  double lo_freq = 0;
+  uint32_t fword = 0, phase = 0;
+  std::vector<double> h;        // prototype, ntaps_dec
+  std::vector<double> af;       // complex AF taps, 2*ntaps_af
+  double bfo = 0;
+  uint32_t bfo_fword = 0;
+  bool taps_dirty = true, af_dirty = true, agc_dirty = true;
+  unsigned reset_pending = 3;
+  int agc_enable = 1;
+  float agc_ref = 0.5f;
+  float2* d_y = nullptr;        // [hy + mmax]
+  float2* d_ypll = nullptr;     // [hy + mmax], allocated on first AM-Synch use
+  float2* d_a = nullptr;        // [mmax]
+  float* d_am = nullptr;        // [2*mmax]
+  float2* d_aftaps = nullptr;   // [ntaps_af]
+};
+
+}  // namespace
+
+struct pysdr_ctx {
+  pysdr_cfg cfg;
+  int nrx = 0;
+  RxHost rx[PYSDR_MAX_RX];
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  int kdec = 0, kpad = 0, hist_len = 0, hy = 0, mmax = 0;
+  size_t cap_samples = 0;
+  float2* d_hist[2] = {nullptr, nullptr};
+  int hist_cur = 0;
+  float2* d_taps = nullptr;      // [MAX_RX][up][kpad]
+  float2* d_stage = nullptr;
+  size_t stage_cap = 0;
+  unsigned* d_peak = nullptr;    // [max_chunks]
+  unsigned* d_blkpeak = nullptr; // [MAX_RX][max_chunks]
+  float* d_gain = nullptr;       // [MAX_RX][max_chunks]
+  RxDevState* d_state = nullptr; // [MAX_RX]
+  unsigned long long s_abs = 0;  // absolute input sample index of the next call
+  // last call
+  long long last_m0 = 0;
+  int last_nout = 0, last_nchunks = 0;
+  size_t last_chunk_len = 0;
+  unsigned long long last_s0 = 0;
+  int last_complex[PYSDR_MAX_RX] = {0};
+  // tuning / profiling
+  int tile_bytes = 56 * 1024, threads = 256;
+  int profile = 0;
+  static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
+  hipEvent_t ev[kSlots][4] = {};
+  unsigned long long ncalls = 0;
+  std::vector<float2> h_taps;
+  // RCCL
+  void* rccl_lib = nullptr;
+  ncclComm_t comm = nullptr;
+};
+
+struct pysdr_spectrum {
+  int device = 0, chunk = 0, nfft = 0, max_frames = 0;
+  hipStream_t stream = nullptr;
+  float* d_win = nullptr;
+  float2* d_work = nullptr;   // [max_frames][nfft]
+  float2* d_in = nullptr;     // [chunk] staging for host frames
+  float* d_out = nullptr;     // [nfft] staging for host frames
+  void* d_fftwork = nullptr;
+  size_t fftwork_bytes = 0;
+  std::map<int, rocfft_plan> plans;
+  rocfft_execution_info info = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+namespace {
+
+std::mutex g_rocfft_mu;
+int g_rocfft_users = 0;
+
+int use_device(int dev) {
+  hipError_t e = hipSetDevice(dev);
+  if (e != hipSuccess) {
+    set_last_error("hipSetDevice(%d): %s", dev, hipGetErrorString(e));
+    return PYSDR_ERR_NO_DEVICE;
+  }
+  return PYSDR_OK;
+}
+
+// g[p][k] = h[p + up*k] * exp(-j*w*k), w = 2*pi*fword/2^32
+void build_taps(const pysdr_ctx* c, const RxHost& r, float2* out) {
+  const int up = c->cfg.up, kpad = c->kpad, nt = c->cfg.ntaps_dec;
+  for (int p = 0; p < up; ++p) {
+    for (int k = 0; k < kpad; ++k) {
+      const int j = p + up * k;
+      float2 g = make_float2(0.f, 0.f);
+      if (j < nt) {
+        const uint32_t ph = (uint32_t)((uint64_t)r.fword * (uint64_t)k);   // mod 2^32
+        const double ang = -2.0 * M_PI * ((double)(int32_t)ph / kTwo32);
+        g.x = (float)(r.h[j] * std::cos(ang));
+        g.y = (float)(r.h[j] * std::sin(ang));
+      }
+      out[(size_t)p * kpad + k] = g;
+    }
+  }
+}
+
+int apply_pending(pysdr_ctx* c) {
+  std::lock_guard<std::mutex> lk(c->mu);
+  const size_t per = (size_t)c->cfg.up * c->kpad;
+  for (int r = 0; r < c->nrx; ++r) {
+    RxHost& x = c->rx[r];
+    if (x.taps_dirty) {
+      build_taps(c, x, c->h_taps.data() + r * per);
+      PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_taps + r * per, c->h_taps.data() + r * per,
+                                     per * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+      x.taps_dirty = false;
+    }
+    if (x.af_dirty) {
+      std::vector<float2> t(c->cfg.ntaps_af);
+      for (int k = 0; k < c->cfg.ntaps_af; ++k)
+        t[k] = make_float2((float)x.af[2 * k], (float)x.af[2 * k + 1]);
+      PYSDR_HIP_CHECK(hipMemcpyAsync(x.d_aftaps, t.data(), t.size() * sizeof(float2),
+                                     hipMemcpyHostToDevice, c->stream));
+      PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));   // t goes out of scope
+      x.af_dirty = false;
+    }
+    if (x.reset_pending) {
+      RxDevState st;
+      PYSDR_HIP_CHECK(hipMemcpyAsync(&st, c->d_state + r, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+      PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (x.reset_pending & 1u) { st.env = 0.f; st.gain = 1.f; st.maxbuf = 0.f; st.err = 0.f; }
+      if (x.reset_pending & 2u) { st.pll_theta = 0.f; st.pll_w = 0.f; }
+      st.ref = x.agc_ref; st.agc_enable = x.agc_enable;
+      PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_state + r, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+      PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+      x.reset_pending = 0; x.agc_dirty = false;
+    }
+    if (x.agc_dirty) {
+      PYSDR_HIP_CHECK(hipMemcpyAsync(&(c->d_state + r)->ref, &x.agc_ref, sizeof(float), hipMemcpyHostToDevice, c->stream));
+      PYSDR_HIP_CHECK(hipMemcpyAsync(&(c->d_state + r)->agc_enable, &x.agc_enable, sizeof(int), hipMemcpyHostToDevice, c->stream));
+      PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+      x.agc_dirty = false;
+    }
+    if (x.mode == PYSDR_AM_SYNCH && x.d_ypll == nullptr) {
+      const size_t n = (size_t)c->hy + c->mmax;
+      PYSDR_HIP_CHECK(hipMalloc(&x.d_ypll, n * sizeof(float2)));
+      PYSDR_HIP_CHECK(hipMemsetAsync(x.d_ypll, 0, n * sizeof(float2), c->stream));
+    }
+  }
+  return PYSDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pysdr_strerror(int status) {
+  switch (status) {
+    case PYSDR_OK: return "ok";
+    case PYSDR_ERR_ARG: return "bad argument";
+    case PYSDR_ERR_NO_DEVICE: return "no HIP device";
+    case PYSDR_ERR_HIP: return "HIP runtime error";
+    case PYSDR_ERR_FFT: return "rocFFT error";
+    case PYSDR_ERR_STATE: return "bad state / capacity exceeded";
+    case PYSDR_ERR_RCCL: return "RCCL error";
+    default: return "unknown status";
+  }
+}
+
+const char* pysdr_last_error(void) { return g_err; }
+
+int pysdr_version(void) { return 100; }
+
+int pysdr_device_count(int* n) {
+  if (!n) return PYSDR_ERR_ARG;
+  int k = 0;
+  hipError_t e = hipGetDeviceCount(&k);
+  if (e != hipSuccess) {
+    *n = 0;
+    set_last_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return PYSDR_ERR_NO_DEVICE;
+  }
+  *n = k;
+  return PYSDR_OK;
+}
+
+uint32_t pysdr_freq_word(double f_hz, double fs_hz, double* f_actual) {
+  const double w = std::nearbyint(f_hz / fs_hz * kTwo32);
+  long long wi = (long long)w;
+  long long ws = ((wi + (1LL << 31)) % (1LL << 32) + (1LL << 32)) % (1LL << 32) - (1LL << 31);
+  if (f_actual) *f_actual = (double)ws * fs_hz / kTwo32;
+  return (uint32_t)(ws & 0xFFFFFFFFLL);
+}
+
+int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
+  if (!cfg || !out) return PYSDR_ERR_ARG;
+  if (cfg->up < 1 || cfg->down < 1 || cfg->in_chunk < 1 || cfg->max_chunks < 1 ||
+      cfg->ntaps_dec < 1 || cfg->ntaps_af < 1 || cfg->ntaps_af > 2048 || cfg->srate <= 0) {
+    set_last_error("pysdr_create: invalid cfg");
+    return PYSDR_ERR_ARG;
+  }
+  int rc = use_device(cfg->device);
+  if (rc) return rc;
+  pysdr_ctx* c = new pysdr_ctx();
+  c->cfg = *cfg;
+  c->kdec = (cfg->ntaps_dec + cfg->up - 1) / cfg->up;
+  c->kpad = (c->kdec + 31) / 32 * 32;
+  c->hist_len = c->kpad + 2;
+  c->hy = (cfg->ntaps_af + 1 + 1) & ~1;
+  c->cap_samples = (size_t)cfg->max_chunks * (size_t)cfg->in_chunk;
+  c->mmax = (int)((c->cap_samples * (size_t)cfg->up) / (size_t)cfg->down) + 4;
+  if ((double)c->cap_samples * cfg->up + cfg->down >= 4294967295.0) {
+    set_last_error("pysdr_create: max_chunks*in_chunk*up must stay below 2^32");
+    delete c;
+    return PYSDR_ERR_ARG;
+  }
+  const size_t per = (size_t)cfg->up * c->kpad;
+  c->h_taps.assign((size_t)PYSDR_MAX_RX * per, make_float2(0.f, 0.f));
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_error("pysdr_create: %s -> %s", #e, hipGetErrorString(_e)); pysdr_destroy(c); return PYSDR_ERR_HIP; } } while (0)
+  CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    CK(hipMalloc(&c->d_hist[i], c->hist_len * sizeof(float2)));
+    CK(hipMemset(c->d_hist[i], 0, c->hist_len * sizeof(float2)));
+  }
+  CK(hipMalloc(&c->d_taps, (size_t)PYSDR_MAX_RX * per * sizeof(float2)));
+  CK(hipMemset(c->d_taps, 0, (size_t)PYSDR_MAX_RX * per * sizeof(float2)));
+  CK(hipMalloc(&c->d_peak, (size_t)cfg->max_chunks * sizeof(unsigned)));
+  CK(hipMalloc(&c->d_blkpeak, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
+  CK(hipMalloc(&c->d_gain, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
+  CK(hipMalloc(&c->d_state, PYSDR_MAX_RX * sizeof(RxDevState)));
+  CK(hipMemset(c->d_state, 0, PYSDR_MAX_RX * sizeof(RxDevState)));
+  for (int k = 0; k < pysdr_ctx::kSlots; ++k)
+    for (int i = 0; i < 4; ++i) CK(hipEventCreate(&c->ev[k][i]));
+#undef CK
+  *out = c;
+  return PYSDR_OK;
+}
+
+void pysdr_destroy(pysdr_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  pysdr_comm_destroy(c);
+  for (int r = 0; r < PYSDR_MAX_RX; ++r) {
+    RxHost& x = c->rx[r];
+    if (x.d_y) (void)hipFree(x.d_y);
+    if (x.d_ypll) (void)hipFree(x.d_ypll);
+    if (x.d_a) (void)hipFree(x.d_a);
+    if (x.d_am) (void)hipFree(x.d_am);
+    if (x.d_aftaps) (void)hipFree(x.d_aftaps);
+  }
+  for (int i = 0; i < 2; ++i) if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
+  if (c->d_taps) (void)hipFree(c->d_taps);
+  if (c->d_stage) (void)hipFree(c->d_stage);
+  if (c->d_peak) (void)hipFree(c->d_peak);
+  if (c->d_blkpeak) (void)hipFree(c->d_blkpeak);
+  if (c->d_gain) (void)hipFree(c->d_gain);
+  if (c->d_state) (void)hipFree(c->d_state);
+  for (int k = 0; k < pysdr_ctx::kSlots; ++k)
+    for (int i = 0; i < 4; ++i) if (c->ev[k][i]) (void)hipEventDestroy(c->ev[k][i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int pysdr_rx_add(pysdr_ctx* c, int mode, double lo_freq, const double* h, const double* af,
+                 double bfo, int* irx) {
+  if (!c || !h || !af) return PYSDR_ERR_ARG;
+  if (mode < 0 || mode > PYSDR_RTTY) return PYSDR_ERR_ARG;
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (c->nrx >= PYSDR_MAX_RX) {
+    set_last_error("pysdr_rx_add: more than %d receivers", PYSDR_MAX_RX);
+    return PYSDR_ERR_STATE;
+  }
+  const int r = c->nrx;
+  RxHost& x = c->rx[r];
+  x.mode = mode;
+  x.lo_freq = lo_freq;
+  x.fword = pysdr_freq_word(lo_freq, c->cfg.srate, nullptr);
+  x.phase = 0;
+  x.h.assign(h, h + c->cfg.ntaps_dec);
+  x.af.assign(af, af + 2 * c->cfg.ntaps_af);
+  x.bfo = bfo;
+  const double fs_out = c->cfg.srate * c->cfg.up / c->cfg.down;
+  x.bfo_fword = pysdr_freq_word(bfo, std::floor(fs_out), nullptr);
+  x.agc_enable = mode_has_agc(mode);
+  x.taps_dirty = x.af_dirty = x.agc_dirty = true;
+  x.reset_pending = 3;
+  const size_t ny = (size_t)c->hy + c->mmax;
+  PYSDR_HIP_CHECK(hipMalloc(&x.d_y, ny * sizeof(float2)));
+  PYSDR_HIP_CHECK(hipMemset(x.d_y, 0, ny * sizeof(float2)));
+  PYSDR_HIP_CHECK(hipMalloc(&x.d_a, (size_t)c->mmax * sizeof(float2)));
+  PYSDR_HIP_CHECK(hipMalloc(&x.d_am, (size_t)c->mmax * 2 * sizeof(float)));
+  PYSDR_HIP_CHECK(hipMalloc(&x.d_aftaps, (size_t)c->cfg.ntaps_af * sizeof(float2)));
+  c->nrx = r + 1;
+  if (irx) *irx = r;
+  return PYSDR_OK;
+}
+
+int pysdr_set_lo(pysdr_ctx* c, int irx, double f_hz, double* f_actual) {
+  if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  RxHost& x = c->rx[irx];
+  x.lo_freq = f_hz;
+  x.fword = pysdr_freq_word(f_hz, c->cfg.srate, f_actual);
+  x.taps_dirty = true;
+  return PYSDR_OK;
+}
+
+int pysdr_set_dec_taps(pysdr_ctx* c, int irx, const double* h, int n) {
+  if (!c || !h || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  if (n != c->cfg.ntaps_dec) {
+    set_last_error("pysdr_set_dec_taps: got %d taps, context was created for %d", n, c->cfg.ntaps_dec);
+    return PYSDR_ERR_ARG;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->rx[irx].h.assign(h, h + n);
+  c->rx[irx].taps_dirty = true;
+  return PYSDR_OK;
+}
+
+int pysdr_set_mode(pysdr_ctx* c, int irx, int mode, const double* af, int n, double bfo) {
+  if (!c || irx < 0 || irx >= c->nrx || mode < 0 || mode > PYSDR_RTTY) return PYSDR_ERR_ARG;
+  if (af && n != c->cfg.ntaps_af) {
+    set_last_error("pysdr_set_mode: got %d AF taps, context was created for %d", n, c->cfg.ntaps_af);
+    return PYSDR_ERR_ARG;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  RxHost& x = c->rx[irx];
+  x.mode = mode;
+  if (af) { x.af.assign(af, af + 2 * n); x.af_dirty = true; }
+  x.bfo = bfo;
+  const double fs_out = std::floor(c->cfg.srate * c->cfg.up / c->cfg.down);
+  x.bfo_fword = pysdr_freq_word(bfo, fs_out, nullptr);
+  x.agc_enable = mode_has_agc(mode);
+  x.agc_dirty = true;
+  return PYSDR_OK;
+}
+
+int pysdr_reset(pysdr_ctx* c, int irx, unsigned what) {
+  if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->rx[irx].reset_pending |= (what & 3u);
+  return PYSDR_OK;
+}
+
+int pysdr_set_agc(pysdr_ctx* c, int irx, int enable, float ref) {
+  if (!c || irx < 0 || irx >= c->nrx || !(ref > 0.f)) return PYSDR_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->rx[irx].agc_enable = enable ? 1 : 0;
+  c->rx[irx].agc_ref = ref;
+  c->rx[irx].agc_dirty = true;
+  return PYSDR_OK;
+}
+
+int pysdr_agc_get(pysdr_ctx* c, int irx, pysdr_agc_state* st) {
+  if (!c || !st || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  RxDevState d;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  st->agc = d.env; st->gain = d.gain; st->maxbuf = d.maxbuf; st->ref = d.ref; st->err = d.err;
+  return PYSDR_OK;
+}
+
+int pysdr_set_profile(pysdr_ctx* c, int enable) {
+  if (!c) return PYSDR_ERR_ARG;
+  c->profile = enable;
+  return PYSDR_OK;
+}
+
+int pysdr_set_tile(pysdr_ctx* c, int tile_bytes, int threads) {
+  if (!c || tile_bytes < 4096 || tile_bytes > 150 * 1024 || threads < 64 || threads > 1024 ||
+      (threads & 63))
+    return PYSDR_ERR_ARG;
+  c->tile_bytes = tile_bytes;
+  c->threads = threads;
+  return PYSDR_OK;
+}
+
+int pysdr_get_elapsed_ms(pysdr_ctx* c, int which, int back, float* ms) {
+  if (!c || !ms || which < 0 || which > 2 || back < 0 || back >= pysdr_ctx::kSlots) return PYSDR_ERR_ARG;
+  if ((unsigned long long)back >= c->ncalls) { set_last_error("pysdr_get_elapsed_ms: no such call"); return PYSDR_ERR_STATE; }
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  hipEvent_t* ev = c->ev[(c->ncalls - 1 - back) % pysdr_ctx::kSlots];
+  PYSDR_HIP_CHECK(hipEventSynchronize(ev[3]));
+  hipEvent_t a = ev[0], b = ev[1];
+  if (which == 1) { a = ev[1]; b = ev[2]; }
+  if (which == 2) { a = ev[0]; b = ev[3]; }
+  PYSDR_HIP_CHECK(hipEventElapsedTime(ms, a, b));
+  return PYSDR_OK;
+}
+
+int pysdr_sync(pysdr_ctx* c) {
+  if (!c) return PYSDR_ERR_ARG;
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return PYSDR_OK;
+}
+
+int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_len, int on_device) {
+  if (!c || !iq || nchunks < 1 || chunk_len < 1) return PYSDR_ERR_ARG;
+  if (c->nrx < 1) { set_last_error("pysdr_process_batch: no receivers"); return PYSDR_ERR_STATE; }
+  const size_t n = (size_t)nchunks * chunk_len;
+  if (nchunks > c->cfg.max_chunks || n > c->cap_samples) {
+    set_last_error("pysdr_process_batch: %d chunks x %zu samples exceeds capacity (%d chunks, %zu samples)",
+                   nchunks, chunk_len, c->cfg.max_chunks, c->cap_samples);
+    return PYSDR_ERR_STATE;
+  }
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  const float2* d_x = reinterpret_cast<const float2*>(iq);
+  if (!on_device) {
+    if (c->stage_cap < n) {
+      if (c->d_stage) PYSDR_HIP_CHECK(hipFree(c->d_stage));
+      c->d_stage = nullptr; c->stage_cap = 0;
+      PYSDR_HIP_CHECK(hipMalloc(&c->d_stage, n * sizeof(float2)));
+      c->stage_cap = n;
+    }
+    PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_stage, iq, n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    d_x = c->d_stage;
+  }
+  rc = apply_pending(c);
+  if (rc) return rc;
+
+  const int up = c->cfg.up, down = c->cfg.down;
+  const unsigned long long s0 = c->s_abs, s1 = s0 + n;
+  const unsigned long long m0 = (s0 * up + down - 1) / down, m1 = (s1 * up + down - 1) / down;
+  const int n_out = (int)(m1 - m0);
+  if (n_out > c->mmax) { set_last_error("pysdr_process_batch: n_out %d > capacity %d", n_out, c->mmax); return PYSDR_ERR_STATE; }
+  const uint32_t t0 = (uint32_t)(m0 * down - s0 * up);
+
+  PYSDR_HIP_CHECK(hipMemsetAsync(c->d_peak, 0, (size_t)nchunks * sizeof(unsigned), c->stream));
+  PYSDR_HIP_CHECK(hipMemsetAsync(c->d_blkpeak, 0, (size_t)c->nrx * nchunks * sizeof(unsigned), c->stream));
+
+  MixDecArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = d_x;
+  a.hist = c->d_hist[c->hist_cur];
+  a.hist_len = c->hist_len;
+  a.aligned16 = ((reinterpret_cast<uintptr_t>(d_x) & 15u) == 0) ? 1 : 0;
+  a.n_total = (uint32_t)n;
+  a.t0 = t0;
+  a.n_out = n_out;
+  a.up = up; a.down = down;
+  a.kpad = c->kpad;
+  a.nrx = c->nrx;
+  const int ratio = (down + up - 1) / up;
+  const size_t taps_bytes = (size_t)c->nrx * up * c->kpad * sizeof(float2);
+  long cap = c->tile_bytes / (long)sizeof(float2);
+  if ((size_t)cap * sizeof(float2) + taps_bytes > 160 * 1024)
+    cap = (long)((160 * 1024 - taps_bytes) / sizeof(float2));
+  long tile_out = ((cap - c->kpad - 2L * ratio - 8) * up) / down;
+  tile_out &= ~1L;
+  if (tile_out < 2) {
+    tile_out = 2;
+    cap = c->kpad + 2L * ratio + 8 + (2L * down + up - 1) / up + 2;
+    if ((size_t)cap * sizeof(float2) + taps_bytes > 160 * 1024) {
+      set_last_error("pysdr_process_batch: filter (%d taps, %d rx) does not fit LDS", c->cfg.ntaps_dec, c->nrx);
+      return PYSDR_ERR_ARG;
+    }
+  }
+  a.tile_out = (int)tile_out;
+  a.tile_cap = (int)((cap + 1) & ~1L);
+  a.ntiles = n_out > 0 ? (n_out + a.tile_out - 1) / a.tile_out : 1;
+  a.taps = c->d_taps;
+  for (int r = 0; r < c->nrx; ++r) {
+    a.y[r] = c->rx[r].d_y + c->hy;
+    a.phase0[r] = c->rx[r].phase;
+    a.fword[r] = c->rx[r].fword;
+  }
+  a.peak = c->d_peak;
+  a.chunk_len = (uint32_t)chunk_len;
+
+  hipEvent_t* ev = c->ev[c->ncalls % pysdr_ctx::kSlots];
+  if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[0], c->stream));
+  rc = launch_mixdec(a, c->threads, c->stream);
+  if (rc) return rc;
+  if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[1], c->stream));
+
+  Stage2Args s;
+  memset(&s, 0, sizeof(s));
+  s.nrx = c->nrx; s.n_out = n_out; s.ntaps = c->cfg.ntaps_af; s.hy = c->hy;
+  s.t0 = t0; s.up = up; s.down = down; s.chunk_len = (uint32_t)chunk_len; s.nchunks = nchunks;
+  s.m0_lo = (uint32_t)(m0 & 0xFFFFFFFFull);
+  const double fs_out = std::floor(c->cfg.srate * up / down);
+  s.fm_scale = (float)(fs_out / (2.0 * M_PI * kNfmFullScaleDev));
+  {
+    const double wn = 2.0 * M_PI * kPllBwHz / fs_out;
+    s.pll_kp = (float)(2.0 * kPllZeta * wn);
+    s.pll_ki = (float)(wn * wn);
+  }
+  bool any_pll = false;
+  for (int r = 0; r < c->nrx; ++r) {
+    RxHost& x = c->rx[r];
+    s.y[r] = x.d_y + c->hy;
+    s.ypll[r] = x.d_ypll ? x.d_ypll + c->hy : nullptr;
+    s.aftaps[r] = x.d_aftaps;
+    s.a[r] = x.d_a;
+    s.am[r] = x.d_am;
+    s.det[r] = mode_detector(x.mode);
+    s.out_complex[r] = (x.mode == PYSDR_IQ) ? 1 : 0;
+    s.bfo_fword[r] = x.bfo_fword;
+    c->last_complex[r] = s.out_complex[r];
+    any_pll |= (s.det[r] == kDetPll);
+  }
+  s.blkpeak = c->d_blkpeak; s.gain = c->d_gain; s.state = c->d_state;
+  if (any_pll && n_out > 0) { rc = launch_pll(s, c->stream); if (rc) return rc; }
+  rc = launch_demod_fir(s, c->stream); if (rc) return rc;
+  rc = launch_agc_scan(s, c->stream); if (rc) return rc;
+  rc = launch_apply(s, c->stream); if (rc) return rc;
+  if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[2], c->stream));
+
+  EpilogueArgs e;
+  memset(&e, 0, sizeof(e));
+  e.nrx = c->nrx; e.n_out = n_out; e.hy = c->hy;
+  for (int r = 0; r < c->nrx; ++r) {
+    e.ybase[r] = c->rx[r].d_y;
+    e.ypllbase[r] = (s.det[r] == kDetPll) ? c->rx[r].d_ypll : nullptr;
+  }
+  e.x = d_x; e.hist_old = c->d_hist[c->hist_cur]; e.hist_new = c->d_hist[c->hist_cur ^ 1];
+  e.hist_len = c->hist_len; e.n_total = (uint32_t)n;
+  rc = launch_epilogue(e, c->stream); if (rc) return rc;
+  if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[3], c->stream));
+  c->ncalls++;
+
+  c->hist_cur ^= 1;
+  c->s_abs = s1;
+  for (int r = 0; r < c->nrx; ++r) c->rx[r].phase += c->rx[r].fword * (uint32_t)n;
+  c->last_m0 = (long long)m0; c->last_nout = n_out; c->last_nchunks = nchunks;
+  c->last_chunk_len = chunk_len; c->last_s0 = s0;
+  return PYSDR_OK;
+}
+
+int pysdr_fetch(pysdr_ctx* c, int irx, float* am, float* iq, int cap, int* n_out,
+                int* am_is_complex, int* chunk_nout, float* peaks) {
+  if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  const int n = c->last_nout;
+  if ((am || iq) && cap < n) { set_last_error("pysdr_fetch: cap %d < n_out %d", cap, n); return PYSDR_ERR_ARG; }
+  const int cx = c->last_complex[irx];
+  // The epilogue rolled the last hy outputs into the prefix but left [hy, hy+n) intact.
+  if (am && n > 0)
+    PYSDR_HIP_CHECK(hipMemcpyAsync(am, c->rx[irx].d_am, (size_t)n * (cx ? 2 : 1) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (iq && n > 0)
+    PYSDR_HIP_CHECK(hipMemcpyAsync(iq, c->rx[irx].d_y + c->hy, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+  if (peaks && c->last_nchunks > 0)
+    PYSDR_HIP_CHECK(hipMemcpyAsync(peaks, c->d_peak, (size_t)c->last_nchunks * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (n_out) *n_out = n;
+  if (am_is_complex) *am_is_complex = cx;
+  if (chunk_nout) {
+    const unsigned long long up = c->cfg.up, down = c->cfg.down;
+    for (int k = 0; k < c->last_nchunks; ++k) {
+      const unsigned long long a0 = c->last_s0 + (unsigned long long)k * c->last_chunk_len;
+      const unsigned long long a1 = a0 + c->last_chunk_len;
+      chunk_nout[k] = (int)((a1 * up + down - 1) / down - (a0 * up + down - 1) / down);
+    }
+  }
+  return PYSDR_OK;
+}
+
+int pysdr_process(pysdr_ctx* c, const float* iq, size_t n, pysdr_out* outs) {
+  if (!c || !iq || !outs || n < 1) return PYSDR_ERR_ARG;
+  int rc = pysdr_process_batch(c, iq, 1, n, 0);
+  if (rc) return rc;
+  for (int r = 0; r < c->nrx; ++r) {
+    int nout = 0, cx = 0;
+    float pk = 0.f;
+    rc = pysdr_fetch(c, r, outs[r].am, outs[r].iq, outs[r].cap, &nout, &cx, nullptr, &pk);
+    if (rc) return rc;
+    outs[r].n_out = nout;
+    outs[r].am_is_complex = cx;
+    outs[r].peak_in = pk;
+  }
+  return PYSDR_OK;
+}
+
+// ---------------------------------------------------------------- quad mixer
+int pysdr_quad_mixer(int device, const float* x, float* y, size_t n, uint32_t phase0,
+                     uint32_t fword, uint32_t* phase_out) {
+  if (!x || !y) return PYSDR_ERR_ARG;
+  int rc = use_device(device);
+  if (rc) return rc;
+  if (phase_out) *phase_out = phase0 + fword * (uint32_t)n;
+  if (n == 0) return PYSDR_OK;
+  float2 *dx = nullptr, *dy = nullptr;
+  PYSDR_HIP_CHECK(hipMalloc(&dx, n * sizeof(float2)));
+  hipError_t e = hipMalloc(&dy, n * sizeof(float2));
+  if (e != hipSuccess) { (void)hipFree(dx); set_last_error("hipMalloc: %s", hipGetErrorString(e)); return PYSDR_ERR_HIP; }
+  rc = PYSDR_OK;
+  e = hipMemcpy(dx, x, n * sizeof(float2), hipMemcpyHostToDevice);
+  if (e == hipSuccess) rc = launch_quad_mixer(dx, dy, n, phase0, fword, nullptr);
+  if (e == hipSuccess && rc == PYSDR_OK) e = hipMemcpy(y, dy, n * sizeof(float2), hipMemcpyDeviceToHost);
+  (void)hipFree(dx); (void)hipFree(dy);
+  if (e != hipSuccess) { set_last_error("quad_mixer: %s", hipGetErrorString(e)); return PYSDR_ERR_HIP; }
+  return rc;
+}
+
+// ---------------------------------------------------------------- spectrum
+static int get_plan(pysdr_spectrum* sp, int batch, rocfft_plan* out) {
+  auto it = sp->plans.find(batch);
+  if (it != sp->plans.end()) { *out = it->second; return PYSDR_OK; }
+  rocfft_plan plan = nullptr;
+  size_t len[1] = {(size_t)sp->nfft};
+  rocfft_status s = rocfft_plan_create(&plan, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
+                                       rocfft_precision_single, 1, len, (size_t)batch, nullptr);
+  if (s != rocfft_status_success) { set_last_error("rocfft_plan_create(nfft=%d,batch=%d) = %d", sp->nfft, batch, (int)s); return PYSDR_ERR_FFT; }
+  size_t wbs = 0;
+  rocfft_plan_get_work_buffer_size(plan, &wbs);
+  if (wbs > sp->fftwork_bytes) {
+    if (sp->d_fftwork) (void)hipFree(sp->d_fftwork);
+    sp->d_fftwork = nullptr; sp->fftwork_bytes = 0;
+    PYSDR_HIP_CHECK(hipMalloc(&sp->d_fftwork, wbs));
+    sp->fftwork_bytes = wbs;
+  }
+  if (sp->fftwork_bytes) rocfft_execution_info_set_work_buffer(sp->info, sp->d_fftwork, sp->fftwork_bytes);
+  sp->plans[batch] = plan;
+  *out = plan;
+  return PYSDR_OK;
+}
+
+int pysdr_spectrum_create(int device, int chunk_size, int nfft, int max_frames, const float* window,
+                          pysdr_spectrum** out) {
+  if (!out || !window || chunk_size < 1 || nfft < chunk_size || max_frames < 1) return PYSDR_ERR_ARG;
+  int rc = use_device(device);
+  if (rc) return rc;
+  {
+    std::lock_guard<std::mutex> lk(g_rocfft_mu);
+    if (g_rocfft_users++ == 0) rocfft_setup();
+  }
+  pysdr_spectrum* sp = new pysdr_spectrum();
+  sp->device = device; sp->chunk = chunk_size; sp->nfft = nfft; sp->max_frames = max_frames;
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_error("pysdr_spectrum_create: %s -> %s", #e, hipGetErrorString(_e)); pysdr_spectrum_destroy(sp); return PYSDR_ERR_HIP; } } while (0)
+  CK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
+  CK(hipMalloc(&sp->d_win, (size_t)chunk_size * sizeof(float)));
+  CK(hipMemcpy(sp->d_win, window, (size_t)chunk_size * sizeof(float), hipMemcpyHostToDevice));
+  CK(hipMalloc(&sp->d_work, (size_t)max_frames * nfft * sizeof(float2)));
+  CK(hipMalloc(&sp->d_in, (size_t)chunk_size * sizeof(float2)));
+  CK(hipMalloc(&sp->d_out, (size_t)nfft * sizeof(float)));
+  CK(hipEventCreate(&sp->ev[0]));
+  CK(hipEventCreate(&sp->ev[1]));
+#undef CK
+  if (rocfft_execution_info_create(&sp->info) != rocfft_status_success ||
+      rocfft_execution_info_set_stream(sp->info, sp->stream) != rocfft_status_success) {
+    set_last_error("rocfft_execution_info_create failed");
+    pysdr_spectrum_destroy(sp);
+    return PYSDR_ERR_FFT;
+  }
+  *out = sp;
+  return PYSDR_OK;
+}
+
+void pysdr_spectrum_destroy(pysdr_spectrum* sp) {
+  if (!sp) return;
+  (void)hipSetDevice(sp->device);
+  if (sp->stream) (void)hipStreamSynchronize(sp->stream);
+  for (auto& kv : sp->plans) rocfft_plan_destroy(kv.second);
+  if (sp->info) rocfft_execution_info_destroy(sp->info);
+  if (sp->d_win) (void)hipFree(sp->d_win);
+  if (sp->d_work) (void)hipFree(sp->d_work);
+  if (sp->d_in) (void)hipFree(sp->d_in);
+  if (sp->d_out) (void)hipFree(sp->d_out);
+  if (sp->d_fftwork) (void)hipFree(sp->d_fftwork);
+  for (int i = 0; i < 2; ++i) if (sp->ev[i]) (void)hipEventDestroy(sp->ev[i]);
+  if (sp->stream) (void)hipStreamDestroy(sp->stream);
+  delete sp;
+  std::lock_guard<std::mutex> lk(g_rocfft_mu);
+  if (--g_rocfft_users == 0) rocfft_cleanup();
+}
+
+static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int nframes, int is_complex,
+                        int db, float* d_out) {
+  rocfft_plan plan;
+  int rc = get_plan(sp, nframes, &plan);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipEventRecord(sp->ev[0], sp->stream));
+  rc = launch_psd_pre(d_x, hop, nframes, sp->chunk, sp->nfft, sp->d_win, sp->d_work, is_complex, sp->stream);
+  if (rc) return rc;
+  void* bufs[1] = {sp->d_work};
+  rocfft_status s = rocfft_execute(plan, bufs, nullptr, sp->info);
+  if (s != rocfft_status_success) { set_last_error("rocfft_execute = %d", (int)s); return PYSDR_ERR_FFT; }
+  rc = launch_psd_post(sp->d_work, nframes, sp->nfft, is_complex ? 0 : 1, db, d_out, sp->stream);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipEventRecord(sp->ev[1], sp->stream));
+  return PYSDR_OK;
+}
+
+int pysdr_spectrum_frame(pysdr_spectrum* sp, const float* x, int is_complex, int db, float* psd_out,
+                         int* n_out) {
+  if (!sp || !x || !psd_out) return PYSDR_ERR_ARG;
+  int rc = use_device(sp->device);
+  if (rc) return rc;
+  const size_t bytes = (size_t)sp->chunk * (is_complex ? sizeof(float2) : sizeof(float));
+  PYSDR_HIP_CHECK(hipMemcpyAsync(sp->d_in, x, bytes, hipMemcpyHostToDevice, sp->stream));
+  rc = spectrum_run(sp, sp->d_in, 0, 1, is_complex, db, sp->d_out);
+  if (rc) return rc;
+  const int nout = is_complex ? sp->nfft : sp->nfft / 2;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(psd_out, sp->d_out, (size_t)nout * sizeof(float), hipMemcpyDeviceToHost, sp->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(sp->stream));
+  if (n_out) *n_out = nout;
+  return PYSDR_OK;
+}
+
+int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size_t hop, void* d_out) {
+  if (!sp || !d_iq || !d_out || nframes < 1 || nframes > sp->max_frames) return PYSDR_ERR_ARG;
+  int rc = use_device(sp->device);
+  if (rc) return rc;
+  return spectrum_run(sp, reinterpret_cast<const float2*>(d_iq), hop, nframes, 1, 1,
+                      reinterpret_cast<float*>(d_out));
+}
+
+int pysdr_spectrum_sync(pysdr_spectrum* sp) {
+  if (!sp) return PYSDR_ERR_ARG;
+  int rc = use_device(sp->device);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipStreamSynchronize(sp->stream));
+  return PYSDR_OK;
+}
+
+int pysdr_spectrum_elapsed_ms(pysdr_spectrum* sp, float* ms) {
+  if (!sp || !ms) return PYSDR_ERR_ARG;
+  int rc = use_device(sp->device);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipEventSynchronize(sp->ev[1]));
+  PYSDR_HIP_CHECK(hipEventElapsedTime(ms, sp->ev[0], sp->ev[1]));
+  return PYSDR_OK;
+}
+
+// ---------------------------------------------------------------- device memory
+int pysdr_dev_alloc(int device, size_t bytes, void** out) {
+  if (!out || bytes == 0) return PYSDR_ERR_ARG;
+  int rc = use_device(device);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipMalloc(out, bytes));
+  return PYSDR_OK;
+}
+int pysdr_dev_free(int device, void* p) {
+  if (!p) return PYSDR_OK;
+  int rc = use_device(device);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipFree(p));
+  return PYSDR_OK;
+}
+int pysdr_dev_upload(int device, void* dst, const void* src_host, size_t bytes) {
+  if (!dst || !src_host) return PYSDR_ERR_ARG;
+  int rc = use_device(device);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipMemcpy(dst, src_host, bytes, hipMemcpyHostToDevice));
+  return PYSDR_OK;
+}
+int pysdr_dev_download(int device, void* dst_host, const void* src, size_t bytes) {
+  if (!dst_host || !src) return PYSDR_ERR_ARG;
+  int rc = use_device(device);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost));
+  return PYSDR_OK;
+}
+int pysdr_dev_copy(int device, void* dst, const void* src, size_t bytes) {
+  if (!dst || !src) return PYSDR_ERR_ARG;
+  int rc = use_device(device);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+  return PYSDR_OK;
+}
+
+// ---------------------------------------------------------------- RCCL (lazy dlopen: librccl is ~0.5 GB)
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+
+int rccl_load() {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.lib) return PYSDR_OK;
+  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) { set_last_error("dlopen(librccl.so.1): %s", dlerror()); return PYSDR_ERR_RCCL; }
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+  g_rccl.Broadcast = reinterpret_cast<decltype(g_rccl.Broadcast)>(dlsym(lib, "ncclBroadcast"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+  g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.Broadcast || !g_rccl.CommDestroy) {
+    set_last_error("librccl: missing symbols");
+    dlclose(lib);
+    return PYSDR_ERR_RCCL;
+  }
+  g_rccl.lib = lib;
+  return PYSDR_OK;
+}
+int rccl_fail(const char* what, ncclResult_t r) {
+  set_last_error("%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error");
+  return PYSDR_ERR_RCCL;
+}
+}  // namespace
+
+int pysdr_comm_unique_id(char id_out[128]) {
+  if (!id_out) return PYSDR_ERR_ARG;
+  int rc = rccl_load();
+  if (rc) return rc;
+  ncclUniqueId id;
+  ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
+  memcpy(id_out, id.internal, 128);
+  return PYSDR_OK;
+}
+
+int pysdr_comm_init(pysdr_ctx* c, const char id[128], int rank, int nranks) {
+  if (!c || !id || rank < 0 || rank >= nranks) return PYSDR_ERR_ARG;
+  int rc = rccl_load();
+  if (rc) return rc;
+  rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  if (c->comm) { set_last_error("pysdr_comm_init: already initialised"); return PYSDR_ERR_STATE; }
+  ncclUniqueId uid;
+  memcpy(uid.internal, id, 128);
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, uid, rank);
+  if (r != ncclSuccess) { c->comm = nullptr; return rccl_fail("ncclCommInitRank", r); }
+  return PYSDR_OK;
+}
+
+int pysdr_comm_bcast(pysdr_ctx* c, void* d_buf, size_t bytes, int root) {
+  if (!c || !d_buf) return PYSDR_ERR_ARG;
+  if (!c->comm) { set_last_error("pysdr_comm_bcast: communicator not initialised"); return PYSDR_ERR_STATE; }
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  ncclResult_t r = g_rccl.Broadcast(d_buf, d_buf, bytes, ncclUint8, root, c->comm, c->stream);
+  if (r != ncclSuccess) return rccl_fail("ncclBroadcast", r);
+  return PYSDR_OK;
+}
+
+int pysdr_comm_destroy(pysdr_ctx* c) {
+  if (!c) return PYSDR_ERR_ARG;
+  if (c->comm && g_rccl.CommDestroy) {
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    g_rccl.CommDestroy(c->comm);
+  }
+  c->comm = nullptr;
+  return PYSDR_OK;
+}
+
+}  // extern "C"

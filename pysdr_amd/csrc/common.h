@@ -1,0 +1,108 @@
+// Internal declarations shared by the translation units of libpysdr_hip.so.
+// gfx950 only: wave64, 160 KiB LDS/CU.  Not part of the public ABI (include/pysdr_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pysdr_hip.h"
+
+namespace pysdr {
+
+void set_last_error(const char* fmt, ...);
+
+#define PYSDR_HIP_CHECK(expr)                                                        \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      ::pysdr::set_last_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr,           \
+                              hipGetErrorString(_e));                                \
+      return PYSDR_ERR_HIP;                                                          \
+    }                                                                                \
+  } while (0)
+
+constexpr int kWave = 64;
+constexpr int kDetNone = 0;     // d = y           (SSB/USB/LSB/IQ/RTTY)
+constexpr int kDetAbs = 1;      // d = |y|         (AM)
+constexpr int kDetFm = 2;       // d = discriminator (NFM), sigs/nfm.m:124-127
+constexpr int kDetBfo = 3;      // d = y*exp(j*bfo) (CW)
+constexpr int kDetPll = 4;      // d = Re(y*exp(-j*theta)) from the PLL kernel (AM-Synch)
+
+// ---- mix + decimate (mixdec.hip) -----------------------------------------------------
+struct MixDecArgs {
+  const float2* x;        // this call's samples, x[0] = absolute sample S0
+  const float2* hist;     // hist[hist_len]: samples S0-hist_len .. S0-1
+  int hist_len;           // even, >= kpad + 2
+  int aligned16;          // x is 16-byte aligned
+  uint32_t n_total;       // samples in this call
+  uint32_t t0;            // m0*down - S0*up  (0 <= t0 < down)
+  int n_out;              // outputs of this call
+  int up, down;
+  int kpad;               // taps per polyphase branch, padded to a multiple of 32
+  int nrx;
+  int tile_out;           // outputs per workgroup (even)
+  int tile_cap;           // LDS capacity in samples
+  int ntiles;
+  const float2* taps;     // [nrx][up][kpad] LO-modulated polyphase taps
+  float2* y[PYSDR_MAX_RX];// y[r][i], i = 0 .. n_out-1
+  uint32_t phase0[PYSDR_MAX_RX];
+  uint32_t fword[PYSDR_MAX_RX];
+  unsigned* peak;         // [nchunks] max |x|^2 as float bits (atomicMax)
+  uint32_t chunk_len;
+};
+int launch_mixdec(const MixDecArgs& a, int threads, hipStream_t st);
+size_t mixdec_lds_bytes(const MixDecArgs& a);
+
+// ---- stage 2 at FS_OUT (stage2.hip) --------------------------------------------------
+struct RxDevState {       // one per RX, lives in device memory
+  float env, gain, maxbuf, err, ref;
+  int agc_enable;
+  float pll_theta, pll_w;
+};
+
+struct Stage2Args {
+  int nrx, n_out, ntaps, hy;          // hy = prefix (history) length of y buffers
+  uint32_t t0; int up, down; uint32_t chunk_len; int nchunks;
+  uint32_t m0_lo;                     // low 32 bits of the absolute index of output 0
+  float fm_scale;
+  float pll_kp, pll_ki;
+  const float2* y[PYSDR_MAX_RX];      // points at element for output 0 (prefix before it)
+  float2* ypll[PYSDR_MAX_RX];         // same layout, only for AM-Synch
+  const float2* aftaps[PYSDR_MAX_RX]; // [ntaps]
+  float2* a[PYSDR_MAX_RX];            // AF-filter output
+  float* am[PYSDR_MAX_RX];            // final audio (float, or float2 when IQ)
+  int det[PYSDR_MAX_RX];
+  int out_complex[PYSDR_MAX_RX];
+  uint32_t bfo_fword[PYSDR_MAX_RX];
+  unsigned* blkpeak;                  // [nrx][nchunks] float bits
+  float* gain;                        // [nrx][nchunks]
+  RxDevState* state;                  // [nrx]
+};
+int launch_pll(const Stage2Args& a, hipStream_t st);
+int launch_demod_fir(const Stage2Args& a, hipStream_t st);
+int launch_agc_scan(const Stage2Args& a, hipStream_t st);
+int launch_apply(const Stage2Args& a, hipStream_t st);
+
+struct EpilogueArgs {
+  int nrx, n_out, hy;
+  float2* ybase[PYSDR_MAX_RX];        // buffer start (prefix at [0,hy))
+  float2* ypllbase[PYSDR_MAX_RX];     // may be null
+  const float2* x; const float2* hist_old; float2* hist_new; int hist_len; uint32_t n_total;
+};
+int launch_epilogue(const EpilogueArgs& a, hipStream_t st);
+
+// ---- misc kernels (misc.hip) ---------------------------------------------------------
+int launch_quad_mixer(const float2* x, float2* y, size_t n, uint32_t phase0, uint32_t fword,
+                      hipStream_t st);
+int launch_psd_pre(const float2* x, size_t hop, int nframes, int chunk, int nfft,
+                   const float* win, float2* work, int is_complex, hipStream_t st);
+int launch_psd_post(const float2* work, int nframes, int nfft, int half, int db, float* out,
+                    hipStream_t st);
+
+}  // namespace pysdr

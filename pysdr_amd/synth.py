@@ -1,0 +1,62 @@
+"""Deterministic synthetic wideband IQ (SURVEY.md 8(d) configurations C1-C3): the signal
+source of the synthetic SoapySDR-shaped device (``pysdr_amd/stream.py``), of the tests and
+of ``bench.py``.  NumPy only; nothing here is on the measured path."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def synth_iq(cfg, nsamp, seed, n_start=0):
+    """Deterministic synthetic wideband IQ: a sum of
+    modulated carriers + AWGN.  ``cfg`` = dict(fs=, carriers=[dict(f=, kind=, ...)],
+    noise=)."""
+    fs = cfg['fs']
+    rng = np.random.default_rng(seed)
+    n = np.arange(n_start, n_start + nsamp, dtype=np.float64)
+    t = n / fs
+    x = np.zeros(nsamp, np.complex128)
+    for c in cfg['carriers']:
+        a, f, kind = c.get('amp', 0.2), c['f'], c['kind']
+        ft = c.get('tone', 1000.0)
+        if kind == 'am':
+            env = 1.0 + c.get('depth', 0.5) * np.sin(2 * np.pi * ft * t)
+            x += a * env * np.exp(2j * np.pi * f * t)
+        elif kind == 'fm':
+            dev = c.get('dev', 3000.0)
+            ph = 2 * np.pi * f * t - (dev / ft) * np.cos(2 * np.pi * ft * t)
+            x += a * np.exp(1j * ph)
+        elif kind == 'usb':
+            x += a * np.exp(2j * np.pi * (f + ft) * t)
+            x += 0.5 * a * np.exp(2j * np.pi * (f + 1.7 * ft) * t)
+        elif kind == 'cw':
+            key = (np.floor(t * c.get('wpm_hz', 12.0)) % 2 == 0).astype(np.float64)
+            x += a * key * np.exp(2j * np.pi * f * t)
+        else:
+            raise ValueError(kind)
+    sig = cfg.get('noise', 1e-2)
+    x += sig * (rng.standard_normal(nsamp) + 1j * rng.standard_normal(nsamp)) / math.sqrt(2)
+    return x.astype(np.complex64)
+
+
+CONFIGS = {
+    # am.py path
+    'C1': dict(fs=2.048e6, fs_out=48e3, ntaps_dec=1001, noise=2e-3,
+               carriers=[dict(f=100e3, kind='am', amp=0.3, tone=1000.0, depth=0.5)],
+               rx=[dict(frq=100e3, mode='AM', video_bw=10e3, af_bw=5e3)]),
+    # C2: 8 MS/s, 1 RX NBFM, 255-tap prototype
+    'C2': dict(fs=8e6, fs_out=48e3, ntaps_dec=255, noise=2e-3,
+               carriers=[dict(f=455e3, kind='fm', amp=0.3, tone=1000.0, dev=3000.0)],
+               rx=[dict(frq=455e3, mode='NFM', video_bw=20e3, af_bw=4e3)]),
+    # C3: 8 MS/s, 4 RX USB/CW/NBFM/AM (+ RF PSD in the harness)
+    'C3': dict(fs=8e6, fs_out=48e3, ntaps_dec=255, noise=2e-3,
+               carriers=[dict(f=200e3, kind='usb', amp=0.15, tone=900.0),
+                         dict(f=-310e3, kind='cw', amp=0.15),
+                         dict(f=455e3, kind='fm', amp=0.2, tone=1000.0, dev=3000.0),
+                         dict(f=-1.2e6, kind='am', amp=0.2, tone=700.0, depth=0.6)],
+               rx=[dict(frq=200e3, mode='USB', video_bw=10e3, af_bw=3e3),
+                   dict(frq=-310e3, mode='CW', video_bw=10e3, af_bw=500.0, bfo=700.0),
+                   dict(frq=455e3, mode='NFM', video_bw=20e3, af_bw=4e3),
+                   dict(frq=-1.2e6, mode='AM', video_bw=10e3, af_bw=5e3)]),
+}
