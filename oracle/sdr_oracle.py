@@ -369,42 +369,40 @@ class Demodulator:
         self.filter_bank_real = af_filter_bank_real(fs_out, ntaps_af)
         self.filter_bank_cmpx = af_filter_bank_cmpx(fs_out, ntaps_af)
         self.am_pll = CarrierPLL(fs_out, dtype)
-        self.yhist = np.zeros(2, self.cd)
-        self.dhist = np.zeros(self.ntaps - 1, self.cd)
+        self.yhist = np.zeros(self.ntaps + 1, self.cd)     # y[m-(ntaps+1)] .. y[m-1]
+        self.vhist = np.zeros(self.ntaps - 1, self.cd)     # PLL outputs (AM-Synch only)
         self.m_abs = 0
         self.taps = None
 
     def set_taps(self, c):
         self.taps = np.asarray(c, np.complex128).astype(self.cd)
 
-    def detect(self, y, mode, bfo):
-        n = len(y)
-        if mode == "AM":
-            d = np.abs(y).astype(self.rd).astype(self.cd)
-        elif mode == "AM-Synch":
-            d = self.am_pll.process(y).astype(self.cd)
+    def process(self, y, mode, bfo):
+        """detector + AF FIR for the new samples ``y``.  The detector is re-applied to
+        the kept y history, so a mode change takes effect on the whole AF-filter window
+        (DESIGN.md 3.5); only the AM-Synch PLL output has a history of its own."""
+        y = np.asarray(y, self.cd)
+        n, hl = len(y), self.ntaps - 1
+        ybuf = np.concatenate((self.yhist, y))            # ybuf[j] <-> output m_abs-(hl+2)+j
+        if mode == "AM-Synch":
+            v = self.am_pll.process(y).astype(self.cd)
+            d = np.concatenate((self.vhist, v))
+            self.vhist = d[len(d) - hl:]
+        elif mode == "AM":
+            d = np.abs(ybuf[2:]).astype(self.rd).astype(self.cd)
         elif mode == "NFM":
-            y3 = np.concatenate((self.yhist, y))
             scale = self.rd(self.fs_out / (2 * math.pi * NFM_FULL_SCALE_DEV))
-            d = (nfm_discriminator(y3, self.rd) * scale).astype(self.cd)
+            d = (nfm_discriminator(ybuf, self.rd) * scale).astype(self.cd)
         elif mode == "CW":
             fw, _ = freq_word(bfo, self.fs_out)
-            ph = ((self.m_abs + np.arange(n, dtype=np.uint64)) * np.uint64(fw)) % TWO32
-            d = y * phase_to_cplx(ph.astype(np.uint32), self.cd)
+            idx = self.m_abs - hl + np.arange(hl + n, dtype=np.int64)
+            ph = ((idx % TWO32) * fw) % TWO32
+            d = (ybuf[2:] * phase_to_cplx(ph.astype(np.uint32), self.cd)).astype(self.cd)
         else:                       # SSB/USB/LSB/IQ/RTTY: the AF filter does the work
-            d = y.astype(self.cd)
-        if n >= 2:
-            self.yhist = y[-2:].copy()
-        elif n == 1:
-            self.yhist = np.array([self.yhist[1], y[0]], self.cd)
+            d = ybuf[2:]
+        a = np.convolve(d, self.taps, mode='valid') if n else d[:0]
+        self.yhist = ybuf[len(ybuf) - (hl + 2):]
         self.m_abs += n
-        return d
-
-    def af_filter(self, d):
-        buf = np.concatenate((self.dhist, d))
-        a = np.convolve(buf, self.taps, mode='valid') if len(d) else d
-        hl = self.ntaps - 1
-        self.dhist = buf[len(buf) - hl:]
         return a.astype(self.cd)
 
 
@@ -486,8 +484,7 @@ class Receiver:
         self.dec.hist = v[:hl]
         y = self.dec.process(v[hl:])
         self.xhist = raw[len(raw) - hl:] if hl else raw[:0]
-        d = self.demod.detect(y, self.mode, self.bfo)
-        a = self.demod.af_filter(d)
+        a = self.demod.process(y, self.mode, self.bfo)
         if self.mode == "IQ":
             peak = np.max(np.abs(a)) if len(a) else 0.0
         else:

@@ -520,6 +520,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   }
   a.peak = c->d_peak;
   a.chunk_len = (uint32_t)chunk_len;
+  { const char* e = getenv("PYSDR_DEBUG_FLAGS"); a.dbg = e ? atoi(e) : 0; }
 
   hipEvent_t* ev = c->ev[c->ncalls % pysdr_ctx::kSlots];
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[0], c->stream));

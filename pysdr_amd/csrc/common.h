@@ -55,6 +55,7 @@ struct MixDecArgs {
   uint32_t fword[PYSDR_MAX_RX];
   unsigned* peak;         // [nchunks] max |x|^2 as float bits (atomicMax)
   uint32_t chunk_len;
+  int dbg;                // diagnostic build switches (PYSDR_DEBUG_FLAGS); 0 in production
 };
 int launch_mixdec(const MixDecArgs& a, int threads, hipStream_t st);
 size_t mixdec_lds_bytes(const MixDecArgs& a);

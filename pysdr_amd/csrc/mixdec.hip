@@ -52,6 +52,13 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return v;
 }
 
+// one 16-byte LDS-DMA element: LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)src,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -99,62 +106,87 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   int hi = need_hi > own_hi ? need_hi : own_hi;
   const int npairs = (hi - lo + 2) >> 1;
 
-  // ---- stage the LO-modulated taps
-  {
+  const int wave = tid >> 6, nwaves = nthr >> 6;
+  const int lane = tid & 63;
+
+  if (a.dbg & 2) {
+  } else if (a.aligned16) {
+    // ---- LDS-DMA staging (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR
+    // round trip, every piece of the tile in flight at once).  The LDS image is
+    // lane-linear: piece q covers float4 slots [64q, 64q+64).
+    {
+      const int nt4 = (R * a.up * a.kpad) >> 1;                 // taps as 16-B slots
+      const float4* src = reinterpret_cast<const float4*>(a.taps);
+      float4* dst = reinterpret_cast<float4*>(tl);
+      for (int q = wave; q * 64 < nt4; q += nwaves) {
+        const int slot = q * 64 + lane;
+        if (slot < nt4) glds16(src + slot, dst + q * 64);
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(xs);
+    for (int q = wave; q * 64 < npairs; q += nwaves) {
+      const int pi = q * 64 + lane;
+      const int rel = lo + 2 * pi;
+      // a pair is DMA-able when both samples exist: history (rel < 0) or rel+1 < n_total
+      const bool ok = pi < npairs && (rel < 0 || (uint32_t)rel + 1u < a.n_total);
+      const float2* src = (rel >= 0) ? (a.x + rel) : (a.hist + (a.hist_len + rel));
+      if (ok) glds16(src, dst + q * 64);
+    }
+    // the one pair that straddles the end of an odd-length call
+    if (tid == 0 && (a.n_total & 1u)) {
+      const int rel = (int)a.n_total - 1;
+      if (rel >= lo && rel <= hi) {
+        const float2 p0 = a.x[rel];
+        *reinterpret_cast<float4*>(xs + (rel - lo)) = make_float4(p0.x, p0.y, 0.f, 0.f);
+      }
+    }
+  } else {
+    // ---- generic staging for inputs that are only 8-byte aligned (slow path)
     const int nt = R * a.up * a.kpad;
     for (int i = tid; i < nt; i += nthr) tl[i] = a.taps[i];
-  }
-
-  // ---- stage the input span, reduce the raw peak on the way
-  const uint32_t c_lo = own_lo >= 0 ? (uint32_t)own_lo / a.chunk_len : 0u;
-  const uint32_t c_hi = own_hi >= 0 ? (uint32_t)own_hi / a.chunk_len : 0u;
-  const bool one_chunk = (c_lo == c_hi);
-  float pk = 0.f;
-  for (int pi = tid; pi < npairs; pi += nthr) {
-    const int rel = lo + 2 * pi;
-    float4 v;
-    if (rel >= 0) {
-      if ((uint32_t)rel + 1u < a.n_total) {
-        if (a.aligned16) {
-          v = *reinterpret_cast<const float4*>(a.x + rel);
-        } else {
-          const float2 p0 = a.x[rel], p1 = a.x[rel + 1];
-          v = make_float4(p0.x, p0.y, p1.x, p1.y);
-        }
-      } else if ((uint32_t)rel < a.n_total) {
-        const float2 p0 = a.x[rel];
-        v = make_float4(p0.x, p0.y, 0.f, 0.f);
-      } else {
-        v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pi = tid; pi < npairs; pi += nthr) {
+      const int rel = lo + 2 * pi;
+      float2 p0 = make_float2(0.f, 0.f), p1 = make_float2(0.f, 0.f);
+      if (rel < 0) { p0 = a.hist[a.hist_len + rel]; p1 = a.hist[a.hist_len + rel + 1]; }
+      else {
+        if ((uint32_t)rel < a.n_total) p0 = a.x[rel];
+        if ((uint32_t)rel + 1u < a.n_total) p1 = a.x[rel + 1];
       }
-    } else {
-      v = *reinterpret_cast<const float4*>(a.hist + (a.hist_len + rel));
+      xs[2 * pi] = p0;
+      xs[2 * pi + 1] = p1;
     }
-    *reinterpret_cast<float4*>(xs + 2 * pi) = v;
-    const float e0 = v.x * v.x + v.y * v.y;
-    const float e1 = v.z * v.z + v.w * v.w;
-    if (one_chunk) {
-      if (rel >= own_lo && rel <= own_hi) pk = fmaxf(pk, e0);
-      if (rel + 1 >= own_lo && rel + 1 <= own_hi) pk = fmaxf(pk, e1);
-    } else {
-      if (rel >= own_lo && rel <= own_hi)
-        atomicMax(a.peak + (uint32_t)rel / a.chunk_len, __float_as_uint(e0));
-      if (rel + 1 >= own_lo && rel + 1 <= own_hi)
-        atomicMax(a.peak + (uint32_t)(rel + 1) / a.chunk_len, __float_as_uint(e1));
-    }
-  }
-  if (one_chunk && own_hi >= own_lo) {
-    pk = wave_max(pk);
-    if ((tid & 63) == 0 && pk > 0.f) atomicMax(a.peak + c_lo, __float_as_uint(pk));
   }
   __syncthreads();
 
+  // ---- raw-chunk peak |x|^2 over the samples this tile owns (rx.auto_mute input).
+  // A tile may straddle chunk boundaries: one wave-reduced scan + one atomic per wave
+  // for every chunk it touches (same-address atomics are slow: never one per sample).
+  if (own_hi >= own_lo && !(a.dbg & 4)) {
+    const uint32_t c_lo = (uint32_t)own_lo / a.chunk_len;
+    const uint32_t c_hi = (uint32_t)own_hi / a.chunk_len;
+    for (uint32_t c = c_lo; c <= c_hi; ++c) {
+      const long long cb = (long long)c * a.chunk_len;
+      const int s_lo = own_lo > cb ? own_lo : (int)cb;
+      const long long ce = cb + a.chunk_len - 1;
+      const int s_hi = own_hi < ce ? own_hi : (int)ce;
+      const int p_lo = (s_lo - lo) >> 1, p_hi = (s_hi - lo) >> 1;
+      float pk = 0.f;
+      for (int pi = p_lo + tid; pi <= p_hi; pi += nthr) {
+        const float4 v = *reinterpret_cast<const float4*>(xs + 2 * pi);
+        const int rel = lo + 2 * pi;
+        const float e0 = (rel >= s_lo) ? v.x * v.x + v.y * v.y : 0.f;
+        const float e1 = (rel + 1 <= s_hi) ? v.z * v.z + v.w * v.w : 0.f;
+        pk = fmaxf(pk, fmaxf(e0, e1));
+      }
+      pk = wave_max(pk);
+      if (lane == 0 && pk > 0.f) atomicMax(a.peak + c, __float_as_uint(pk));
+    }
+  }
+
   // ---- polyphase dot products: one output per 32-lane half
-  const int wave = tid >> 6, nwaves = nthr >> 6;
-  const int lane = tid & 63;
   const int half = lane >> 5, s = lane & 31;
   const int npq = (tile_n + 1) >> 1;
-  for (int pq = wave; pq < npq; pq += nwaves) {
+  for (int pq = wave; pq < ((a.dbg & 1) ? 0 : npq); pq += nwaves) {
     int i = i_first + 2 * pq + half;
     const bool valid = (i <= i_last);
     if (!valid) i = i_last;
@@ -178,21 +210,23 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
       }
     }
     float sr = 0.f, si = 0.f;
+    uint32_t p0 = 0u, fw = 0u;
+    float2* yp = nullptr;
     const int myr = s - 16;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const float tr = half_wave_sum(ar[r]);
       const float ti = half_wave_sum(ai[r]);
-      if (myr == r) { sr = tr; si = ti; }
+      if (myr == r) { sr = tr; si = ti; p0 = a.phase0[r]; fw = a.fword[r]; yp = a.y[r]; }
     }
     if (valid && myr >= 0 && myr < R) {
-      const uint32_t ph = a.phase0[myr] + a.fword[myr] * rel;
+      const uint32_t ph = p0 + fw * rel;
       float sn, cs;
       sincospif((float)(int)ph * (1.0f / 2147483648.0f), &sn, &cs);
       float2 o;
       o.x = sr * cs - si * sn;
       o.y = sr * sn + si * cs;
-      a.y[myr][i] = o;
+      yp[i] = o;
     }
   }
 }

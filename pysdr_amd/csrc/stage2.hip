@@ -125,24 +125,37 @@ __global__ __launch_bounds__(kFirTile) void demod_fir_kernel(const Stage2Args a)
 }
 
 // ---- AGC recursion over the blocks of this call (sigs/agc.m:6-12 loop filter on decay,
-// immediate attack).  One lane per RX; nchunks steps.
-__global__ void agc_scan_kernel(const Stage2Args a) {
-  const int r = threadIdx.x;
-  if (r >= a.nrx) return;
-  RxDevState st = a.state[r];
-  const float beta = 0.1f;
-  for (int c = 0; c < a.nchunks; ++c) {
-    const float peak = __uint_as_float(a.blkpeak[(size_t)r * a.nchunks + c]);
-    st.maxbuf = peak;
-    if (peak > st.env) st.env = peak;
-    else st.env = __fadd_rn(st.env, __fmul_rn(beta, __fsub_rn(peak, st.env)));
-    float g = 1.f;
-    if (st.agc_enable) g = fminf(__fdiv_rn(st.ref, fmaxf(st.env, 1e-12f)), 1.0e4f);
-    st.gain = g;
-    st.err = __fsub_rn(st.ref, __fmul_rn(g, peak));
-    a.gain[(size_t)r * a.nchunks + c] = g;
+// immediate attack).  One workgroup per RX: the block peaks are staged in LDS by all
+// lanes, lane 0 runs the serial recursion out of LDS (the only dependent chain is
+// cmp/sub/mul/add/select on env), gains go back through LDS and are stored in parallel.
+__global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float agc_lds[];
+  const int r = blockIdx.x;
+  const int tid = threadIdx.x;
+  float* pk = agc_lds;                 // [nchunks]
+  float* gn = agc_lds + a.nchunks;     // [nchunks]
+  for (int c = tid; c < a.nchunks; c += 256)
+    pk[c] = __uint_as_float(a.blkpeak[(size_t)r * a.nchunks + c]);
+  __syncthreads();
+  if (tid == 0) {
+    RxDevState st = a.state[r];
+    const float beta = 0.1f;
+    float env = st.env, g = st.gain, peak = st.maxbuf;
+    for (int c = 0; c < a.nchunks; ++c) {
+      peak = pk[c];
+      const float dec = __fadd_rn(env, __fmul_rn(beta, __fsub_rn(peak, env)));
+      env = (peak > env) ? peak : dec;
+      g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(env, 1e-12f)), 1.0e4f) : 1.f;
+      gn[c] = g;
+    }
+    if (a.nchunks > 0) {
+      st.env = env; st.gain = g; st.maxbuf = peak;
+      st.err = __fsub_rn(st.ref, __fmul_rn(g, peak));
+      a.state[r] = st;
+    }
   }
-  a.state[r] = st;
+  __syncthreads();
+  for (int c = tid; c < a.nchunks; c += 256) a.gain[(size_t)r * a.nchunks + c] = gn[c];
 }
 
 // ---- apply the block gain, emit rx.am (real, or complex in IQ mode)
@@ -198,7 +211,7 @@ int launch_demod_fir(const Stage2Args& a, hipStream_t st) {
 }
 
 int launch_agc_scan(const Stage2Args& a, hipStream_t st) {
-  hipLaunchKernelGGL(agc_scan_kernel, dim3(1), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(agc_scan_kernel, dim3(a.nrx), dim3(256), (size_t)a.nchunks * 2 * sizeof(float), st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }

