@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
     ap.add_argument("--chunks", type=int, default=512, help="chunks per step (batch resident in HBM)")
     ap.add_argument("--no-psd", action="store_true")
+    ap.add_argument("--no-demod", action="store_true", help="diagnostic: PSD only")
     ap.add_argument("--tile-bytes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -147,7 +148,8 @@ def main():
         _lib.check(lib.pysdr_dev_alloc(device, nframes * PSD_NFFT * 4, C.byref(d_psd)), "alloc psd")
 
     def step():
-        ctx.process_batch(d_x.value, B, L, on_device=True)
+        if not args.no_demod:
+            ctx.process_batch(d_x.value, B, L, on_device=True)
         if sp is not None:
             _lib.check(lib.pysdr_spectrum_batch(sp, d_x, nframes, PSD_CHUNK, d_psd), "spectrum_batch")
 
@@ -173,7 +175,7 @@ def main():
     dt = time.perf_counter() - t0
 
     # dominant kernel (fused mix+decimate): HIP events on its stream, averaged over the timed steps
-    nev = min(args.steps, 64)
+    nev = 0 if args.no_demod else min(args.steps, 64)
     ms = C.c_float(0)
     k1 = []
     k2 = []
@@ -182,7 +184,7 @@ def main():
         k1.append(ms.value)
         _lib.check(lib.pysdr_get_elapsed_ms(ctx.h, 1, back, C.byref(ms)), "elapsed")
         k2.append(ms.value)
-    k1_ms = float(np.mean(k1))
+    k1_ms = float(np.mean(k1)) if k1 else float('nan')
     psd_ms = None
     if sp is not None:
         _lib.check(lib.pysdr_spectrum_elapsed_ms(sp, C.byref(ms)), "psd elapsed")
@@ -234,7 +236,7 @@ def main():
             "algorithmic_bytes_per_launch": k1_bytes,
             "avg_launch_ms": k1_ms,
         },
-        "kernel_ms": {"mixdec": k1_ms, "stage2": float(np.mean(k2)), "psd_last": psd_ms},
+        "kernel_ms": {"mixdec": k1_ms, "stage2": float(np.mean(k2)) if k2 else None, "psd_last": psd_ms},
         "job_bytes_per_sample": bytes_per_sample_job,
         "job_hbm_frac_per_gpu": (nsamp * args.steps / dt) * bytes_per_sample_job / 1e9 / HBM_PEAK_GBPS,
     }

@@ -549,7 +549,9 @@ class Spectrum:
             y = y[-self.chunk_size:]
             n = self.chunk_size
         self.buf = np.concatenate((self.buf[n:], y.astype(self.cd)))
-        xw = (self.buf * self.win).astype(self.cd)
+        # a real input stream (AF PSD) is transformed as a real signal
+        src = self.buf.real.astype(self.cd) if is_real else self.buf
+        xw = (src * self.win).astype(self.cd)
         X = np.fft.fft(xw, self.NFFT).astype(self.cd)
         p = (X.real * X.real + X.imag * X.imag).astype(self.rd)
         if db:

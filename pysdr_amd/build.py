@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpysdr_hip.so")
-SOURCES = ["api.hip", "mixdec.hip", "stage2.hip", "misc.hip"]
+SOURCES = ["api.hip", "mixdec.hip", "stage2.hip", "misc.hip", "psdfft.hip"]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 

@@ -722,8 +722,25 @@ void pysdr_spectrum_destroy(pysdr_spectrum* sp) {
 
 static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int nframes, int is_complex,
                         int db, float* d_out) {
+  int rc;
+  if (is_complex && sp->chunk == 32768 && sp->nfft == 65536 && !getenv("PYSDR_PSD_ROCFFT")) {
+    // the RF-waterfall size: fused four-step transform.  Frames go through in groups so the
+    // 512 KB/frame intermediate is re-read while it is still in L2 / Infinity Cache.
+    const char* ge = getenv("PYSDR_PSD_GROUP");
+    int group = ge ? atoi(ge) : 128;
+    if (group < 1) group = 1;
+    PYSDR_HIP_CHECK(hipEventRecord(sp->ev[0], sp->stream));
+    for (int f0 = 0; f0 < nframes; f0 += group) {
+      const int nf = (nframes - f0 < group) ? nframes - f0 : group;
+      rc = launch_psd64k(d_x + (size_t)f0 * hop, hop, nf, sp->d_win, sp->d_work,
+                         d_out + (size_t)f0 * sp->nfft, db, sp->stream);
+      if (rc) return rc;
+    }
+    PYSDR_HIP_CHECK(hipEventRecord(sp->ev[1], sp->stream));
+    return PYSDR_OK;
+  }
   rocfft_plan plan;
-  int rc = get_plan(sp, nframes, &plan);
+  rc = get_plan(sp, nframes, &plan);
   if (rc) return rc;
   PYSDR_HIP_CHECK(hipEventRecord(sp->ev[0], sp->stream));
   rc = launch_psd_pre(d_x, hop, nframes, sp->chunk, sp->nfft, sp->d_win, sp->d_work, is_complex, sp->stream);

@@ -106,4 +106,8 @@ int launch_psd_pre(const float2* x, size_t hop, int nframes, int chunk, int nfft
 int launch_psd_post(const float2* work, int nframes, int nfft, int half, int db, float* out,
                     hipStream_t st);
 
+// fused 32768 -> 65536 PSD path (psdfft.hip): two kernels, `work` = nframes x 65536 complex
+int launch_psd64k(const float2* x, size_t hop, int nframes, const float* win, float2* work,
+                  float* out, int db, hipStream_t st);
+
 }  // namespace pysdr

@@ -1,0 +1,214 @@
+// Fused PSD frame path for the RF waterfall (spectrum.periodogram, Plotting.py:462; sizes
+// gui.py:611-616 after the 2^16 clamp of Plotting.py:370-375): window -> zero-pad
+// 32768 -> 65536 -> FFT -> re^2+im^2 -> 10*log10 -> fftshift (formula pinned by
+// rtty.py:839-841).  rocFFT needs a pad kernel, two transform kernels and a dB kernel
+// (~3.5 MB of traffic per frame); here the 64k transform is a four-step 256 x 256
+// decomposition in TWO kernels with the window/zero-pad fused into the first and the
+// power/dB/fftshift into the second:
+//
+//   n = 256 a + b (a < 128 non-zero rows),  k = p + 256 q
+//   psd_cols:  Y[p][b] = W_65536^(b p) * sum_a xw[256 a + b] W_256^(a p)     (256-pt over a)
+//   psd_rows:  X[p + 256 q] = sum_b Y[p][b] W_256^(b q)                      (256-pt over b)
+//
+// HBM traffic per frame = 256 KB in + 256 KB out; the 512 KB intermediate Y of a group of
+// frames is written and re-read immediately, so it lives in L2 / Infinity Cache.  Each
+// 256-point transform is radix 16 x 16 (one 16-point butterfly per thread per pass), data
+// exchanged through LDS with conflict-free strides.
+#include "common.h"
+
+namespace pysdr {
+
+namespace {
+
+constexpr int kN = 65536, kM = 32768;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// exp(-j*pi*t)
+__device__ __forceinline__ float2 expmpi(float t) {
+  float s, c;
+  sincospif(t, &s, &c);
+  return make_float2(c, -s);
+}
+
+// 4-point DFT in place (W4 = -j): (a,b,c,d) -> (X0,X1,X2,X3)
+__device__ __forceinline__ void dft4(float2& a, float2& b, float2& c, float2& d) {
+  const float2 s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
+  a = cadd(s0, s2);
+  c = csub(s0, s2);
+  b = make_float2(s1.x + s3.y, s1.y - s3.x);   // s1 - j*s3
+  d = make_float2(s1.x - s3.y, s1.y + s3.x);   // s1 + j*s3
+}
+
+// 16-point DFT in place, natural order in and out.  n = n0 + 4 n1, k = k1 + 4 k0:
+// DFT4 over n1, twiddle W16^(n0 k1), DFT4 over n0.
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f;   // cos, sin(pi/8)
+  const float h = 0.70710678118654752f;
+#pragma unroll
+  for (int n0 = 0; n0 < 4; ++n0) dft4(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);
+  // now v[n0 + 4*k1] = A[n0][k1]; twiddles W16^(n0*k1)
+  v[5] = cmul(v[5], make_float2(c1, -s1));     // n0=1,k1=1 : W^1
+  v[9] = cmul(v[9], make_float2(h, -h));       // n0=1,k1=2 : W^2
+  v[13] = cmul(v[13], make_float2(s1, -c1));   // n0=1,k1=3 : W^3
+  v[6] = cmul(v[6], make_float2(h, -h));       // n0=2,k1=1 : W^2
+  v[10] = make_float2(v[10].y, -v[10].x);      // n0=2,k1=2 : W^4 = -j
+  v[14] = cmul(v[14], make_float2(-h, -h));    // n0=2,k1=3 : W^6
+  v[7] = cmul(v[7], make_float2(s1, -c1));     // n0=3,k1=1 : W^3
+  v[11] = cmul(v[11], make_float2(-h, -h));    // n0=3,k1=2 : W^6
+  v[15] = cmul(v[15], make_float2(-c1, s1));   // n0=3,k1=3 : W^9
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+  // now v[4*k1 + k0] = X[k1 + 4*k0]: transpose the 4x4 index to natural order
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = i + 1; j < 4; ++j) {
+      const float2 t = v[4 * i + j];
+      v[4 * i + j] = v[4 * j + i];
+      v[4 * j + i] = t;
+    }
+}
+
+// v[k] *= w0 * w^k, k = 0..15 (powers built with depth <= 4 multiplications)
+__device__ __forceinline__ void twiddle_pow0(float2 (&v)[16], float2 w, float2 w0) {
+  const float2 w2 = cmul(w, w), w4 = cmul(w2, w2), w8 = cmul(w4, w4);
+  const float2 b0 = w0, b4 = cmul(w0, w4), b8 = cmul(w0, w8), b12 = cmul(b4, w8);
+  const float2 w3 = cmul(w2, w);
+  v[0] = cmul(v[0], b0); v[1] = cmul(v[1], cmul(b0, w)); v[2] = cmul(v[2], cmul(b0, w2)); v[3] = cmul(v[3], cmul(b0, w3));
+  v[4] = cmul(v[4], b4); v[5] = cmul(v[5], cmul(b4, w)); v[6] = cmul(v[6], cmul(b4, w2)); v[7] = cmul(v[7], cmul(b4, w3));
+  v[8] = cmul(v[8], b8); v[9] = cmul(v[9], cmul(b8, w)); v[10] = cmul(v[10], cmul(b8, w2)); v[11] = cmul(v[11], cmul(b8, w3));
+  v[12] = cmul(v[12], b12); v[13] = cmul(v[13], cmul(b12, w)); v[14] = cmul(v[14], cmul(b12, w2)); v[15] = cmul(v[15], cmul(b12, w3));
+}
+// v[k] *= w^k, k = 1..15
+__device__ __forceinline__ void twiddle_pow(float2 (&v)[16], float2 w) {
+  const float2 w2 = cmul(w, w), w3 = cmul(w2, w), w4 = cmul(w2, w2);
+  const float2 w8 = cmul(w4, w4), w12 = cmul(w8, w4);
+  v[1] = cmul(v[1], w); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+  v[5] = cmul(v[5], cmul(w4, w)); v[6] = cmul(v[6], cmul(w4, w2)); v[7] = cmul(v[7], cmul(w4, w3));
+  v[8] = cmul(v[8], w8);
+  v[9] = cmul(v[9], cmul(w8, w)); v[10] = cmul(v[10], cmul(w8, w2)); v[11] = cmul(v[11], cmul(w8, w3));
+  v[12] = cmul(v[12], w12);
+  v[13] = cmul(v[13], cmul(w12, w)); v[14] = cmul(v[14], cmul(w12, w2)); v[15] = cmul(v[15], cmul(w12, w3));
+}
+
+// ---- step 1: 16 columns of one frame per workgroup (grid = 16 x frames, 256 threads).
+//   a = a0 + 16 a1 (a1 < 8: the rest is zero padding), p = p1 + 16 p0
+//   pass 1 thread (b, a0): DFT16 over a1, * W_256^(a0 p1)      -> LDS[p1][a0][b]
+//   pass 2 thread (b, p1): DFT16 over a0, * W_65536^(bb p)      -> Y[p][bb], bb = 16 cb + b
+// LDS slot(p1, a0, b) = 272 p1 + 16 a0 + b: consecutive lanes write consecutive slots in
+// pass 1, and the 16-slot pad per p1 spreads pass 2's two p1 per half-wave over all banks.
+constexpr int kColsPerWg = 16;
+constexpr int kColLds = 16 * 272;
+
+__global__ __launch_bounds__(256) void psd_cols_kernel(const float2* __restrict__ x, size_t hop,
+                                                       const float* __restrict__ win,
+                                                       float2* __restrict__ work) {
+  __shared__ __attribute__((aligned(16))) float2 lds[kColLds];
+  const int tid = threadIdx.x;
+  const int f = blockIdx.y, cb = blockIdx.x;
+  const int b = tid & 15, hi = tid >> 4;
+  const int bb = cb * kColsPerWg + b;
+  const float2* xf = x + (size_t)f * hop;
+  float2* yf = work + (size_t)f * kN;
+
+  {
+    const int a0 = hi;
+    float2 u[16];
+#pragma unroll
+    for (int a1 = 0; a1 < 8; ++a1) {
+      const int n = 256 * (a0 + 16 * a1) + bb;
+      const float2 s = xf[n];
+      const float g = win[n];
+      u[a1] = make_float2(s.x * g, s.y * g);
+    }
+#pragma unroll
+    for (int a1 = 8; a1 < 16; ++a1) u[a1] = make_float2(0.f, 0.f);
+    dft16(u);
+    twiddle_pow(u, expmpi((float)a0 * (1.0f / 128.0f)));              // W_256^(a0 p1)
+    float2* p = lds + 16 * a0 + b;
+#pragma unroll
+    for (int p1 = 0; p1 < 16; ++p1) p[272 * p1] = u[p1];
+  }
+  __syncthreads();
+  {
+    const int p1 = hi;
+    const float2* p = lds + 272 * p1 + b;
+    float2 v[16];
+#pragma unroll
+    for (int a0 = 0; a0 < 16; ++a0) v[a0] = p[16 * a0];
+    dft16(v);
+    // four-step twiddle W_65536^(bb * (p1 + 16 p0)) = W^(bb p1) * (W^(16 bb))^p0
+    twiddle_pow0(v, expmpi((float)(16 * bb) * (1.0f / 32768.0f)),
+                 expmpi((float)(bb * p1) * (1.0f / 32768.0f)));
+    float2* o = yf + (size_t)p1 * 256 + bb;
+#pragma unroll
+    for (int p0 = 0; p0 < 16; ++p0) o[(size_t)p0 * 16 * 256] = v[p0];
+  }
+}
+
+// ---- step 2: 32 rows p of one frame per workgroup (grid = 8 x frames, 512 threads).
+//   b = c0 + 16 c1, q = q1 + 16 q0
+//   pass 1 thread (c0, pl): DFT16 over c1, * W_256^(c0 q1)     -> LDS[q1][pl][c0]
+//   pass 2 thread (pl, q1): DFT16 over c0 -> X[p + 256 (q1 + 16 q0)] -> dB -> fftshift
+// LDS slot(q1, pl, c0) = 544 q1 + 17 pl + c0: pass 1's 16-lane groups write 16 consecutive
+// slots; pass 2's 32 lanes (pl) are 17 slots apart = 34 dwords, a permutation of the even
+// banks, so both are conflict free.  32 consecutive p per store = one full 128-B line.
+constexpr int kRowsPerWg = 32;
+constexpr int kRowLds = 16 * 544;
+
+__global__ __launch_bounds__(512) void psd_rows_kernel(const float2* __restrict__ work,
+                                                       float* __restrict__ out, int db) {
+  __shared__ __attribute__((aligned(16))) float2 lds[kRowLds];
+  const int tid = threadIdx.x;
+  const int f = blockIdx.y, rb = blockIdx.x;
+  const float2* yf = work + (size_t)f * kN;
+  float* of = out + (size_t)f * kN;
+  {
+    const int c0 = tid & 15, pl = tid >> 4;
+    const float2* src = yf + (size_t)(rb * kRowsPerWg + pl) * 256 + c0;
+    float2 u[16];
+#pragma unroll
+    for (int c1 = 0; c1 < 16; ++c1) u[c1] = src[16 * c1];
+    dft16(u);
+    twiddle_pow(u, expmpi((float)c0 * (1.0f / 128.0f)));              // W_256^(c0 q1)
+    float2* p = lds + 17 * pl + c0;
+#pragma unroll
+    for (int q1 = 0; q1 < 16; ++q1) p[544 * q1] = u[q1];
+  }
+  __syncthreads();
+  {
+    const int pl = tid & 31, q1 = tid >> 5;
+    const float2* p = lds + 544 * q1 + 17 * pl;
+    float2 v[16];
+#pragma unroll
+    for (int c0 = 0; c0 < 16; ++c0) v[c0] = p[c0];
+    dft16(v);
+    const int kb = rb * kRowsPerWg + pl + 256 * q1;
+#pragma unroll
+    for (int q0 = 0; q0 < 16; ++q0) {
+      const int k = kb + 4096 * q0;
+      float pw = v[q0].x * v[q0].x + v[q0].y * v[q0].y;
+      if (db) pw = 10.f * log10f(pw + 1.0e-30f);
+      of[(k + kM) & (kN - 1)] = pw;
+    }
+  }
+}
+
+}  // namespace
+
+// nframes frames; `work` holds nframes x 65536 complex of intermediate.
+int launch_psd64k(const float2* x, size_t hop, int nframes, const float* win, float2* work,
+                  float* out, int db, hipStream_t st) {
+  hipLaunchKernelGGL(psd_cols_kernel, dim3(256 / kColsPerWg, nframes), dim3(256), 0, st, x, hop, win,
+                     work);
+  PYSDR_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(psd_rows_kernel, dim3(256 / kRowsPerWg, nframes), dim3(512), 0, st, work, out, db);
+  PYSDR_HIP_CHECK(hipGetLastError());
+  return PYSDR_OK;
+}
+
+}  // namespace pysdr
