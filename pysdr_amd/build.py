@@ -15,6 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpysdr_hip.so")
 SOURCES = ["api.hip", "mixdec.hip", "stage2.hip", "misc.hip", "psdfft.hip"]
+# per-file extra flags (none needed today; -fno-slp-vectorize on mixdec.hip folds the DPP
+# reduction into v_add_f32_dpp but measured the same 96-99 us, so the default stays)
+EXTRA_FLAGS = {"mixdec.hip": os.environ.get("PYSDR_MIXDEC_FLAGS", "").split()}
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 
@@ -38,6 +41,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
                "-Wno-unused-function", "-ffp-contract=off",
+               *EXTRA_FLAGS.get(src, []),
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

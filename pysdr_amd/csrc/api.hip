@@ -92,7 +92,8 @@ struct pysdr_ctx {
   unsigned long long last_s0 = 0;
   int last_complex[PYSDR_MAX_RX] = {0};
   // tuning / profiling
-  int tile_bytes = 56 * 1024, threads = 256;
+  int tile_bytes = 64 * 1024, threads = 1024;  // per LDS buffer (two buffers per workgroup)
+  int wgs_per_cu = 1, num_cus = 256;
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
   hipEvent_t ev[kSlots][4] = {};
@@ -249,11 +250,16 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   pysdr_ctx* c = new pysdr_ctx();
   c->cfg = *cfg;
   c->kdec = (cfg->ntaps_dec + cfg->up - 1) / cfg->up;
-  c->kpad = (c->kdec + 31) / 32 * 32;
+  c->kpad = (c->kdec + 15) / 16 * 16;
   c->hist_len = c->kpad + 2;
   c->hy = (cfg->ntaps_af + 1 + 1) & ~1;
   c->cap_samples = (size_t)cfg->max_chunks * (size_t)cfg->in_chunk;
   c->mmax = (int)((c->cap_samples * (size_t)cfg->up) / (size_t)cfg->down) + 4;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+      c->num_cus = prop.multiProcessorCount;
+  }
   if ((double)c->cap_samples * cfg->up + cfg->down >= 4294967295.0) {
     set_last_error("pysdr_create: max_chunks*in_chunk*up must stay below 2^32");
     delete c;
@@ -493,18 +499,24 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   a.n_out = n_out;
   a.up = up; a.down = down;
   a.kpad = c->kpad;
+  a.magic = (up == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned)up) + 1u;
   a.nrx = c->nrx;
   const int ratio = (down + up - 1) / up;
   const size_t taps_bytes = (size_t)c->nrx * up * c->kpad * sizeof(float2);
+  // two tile buffers + the taps must fit the LDS share of one workgroup
+  int wgs = c->wgs_per_cu;
+  { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) wgs = atoi(e); }
+  const long lds_share = (160L * 1024) / wgs - 512;
   long cap = c->tile_bytes / (long)sizeof(float2);
-  if ((size_t)cap * sizeof(float2) + taps_bytes > 160 * 1024)
-    cap = (long)((160 * 1024 - taps_bytes) / sizeof(float2));
+  if (2 * cap * (long)sizeof(float2) + (long)taps_bytes > lds_share)
+    cap = (lds_share - (long)taps_bytes) / (2 * (long)sizeof(float2));
   long tile_out = ((cap - c->kpad - 2L * ratio - 8) * up) / down;
+  if (tile_out >= 4L * up) tile_out -= tile_out % (4L * up);   // whole quads of every polyphase branch
   tile_out &= ~1L;
   if (tile_out < 2) {
     tile_out = 2;
     cap = c->kpad + 2L * ratio + 8 + (2L * down + up - 1) / up + 2;
-    if ((size_t)cap * sizeof(float2) + taps_bytes > 160 * 1024) {
+    if (2 * (size_t)cap * sizeof(float2) + taps_bytes > 160 * 1024) {
       set_last_error("pysdr_process_batch: filter (%d taps, %d rx) does not fit LDS", c->cfg.ntaps_dec, c->nrx);
       return PYSDR_ERR_ARG;
     }
@@ -520,11 +532,12 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   }
   a.peak = c->d_peak;
   a.chunk_len = (uint32_t)chunk_len;
+  a.magic_chunk = (chunk_len == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned long long)chunk_len) + 1u;
   { const char* e = getenv("PYSDR_DEBUG_FLAGS"); a.dbg = e ? atoi(e) : 0; }
 
   hipEvent_t* ev = c->ev[c->ncalls % pysdr_ctx::kSlots];
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[0], c->stream));
-  rc = launch_mixdec(a, c->threads, c->stream);
+  rc = launch_mixdec(a, c->threads, c->num_cus * wgs, c->stream);
   if (rc) return rc;
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[1], c->stream));
 

@@ -44,10 +44,11 @@ struct MixDecArgs {
   uint32_t t0;            // m0*down - S0*up  (0 <= t0 < down)
   int n_out;              // outputs of this call
   int up, down;
-  int kpad;               // taps per polyphase branch, padded to a multiple of 32
+  int kpad;               // taps per polyphase branch, padded to a multiple of 16
+  uint32_t magic;         // floor(2^32/up)+1: exact t/up by multiply-high (see divmod_up)
   int nrx;
   int tile_out;           // outputs per workgroup (even)
-  int tile_cap;           // LDS capacity in samples
+  int tile_cap;           // capacity of ONE of the two LDS tile buffers, in samples
   int ntiles;
   const float2* taps;     // [nrx][up][kpad] LO-modulated polyphase taps
   float2* y[PYSDR_MAX_RX];// y[r][i], i = 0 .. n_out-1
@@ -55,9 +56,10 @@ struct MixDecArgs {
   uint32_t fword[PYSDR_MAX_RX];
   unsigned* peak;         // [nchunks] max |x|^2 as float bits (atomicMax)
   uint32_t chunk_len;
+  uint32_t magic_chunk;   // floor(2^32/chunk_len)+1
   int dbg;                // diagnostic build switches (PYSDR_DEBUG_FLAGS); 0 in production
 };
-int launch_mixdec(const MixDecArgs& a, int threads, hipStream_t st);
+int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st);
 size_t mixdec_lds_bytes(const MixDecArgs& a);
 
 // ---- stage 2 at FS_OUT (stage2.hip) --------------------------------------------------

@@ -8,18 +8,24 @@
 //   n_m = floor(m*DOWN/UP), p_m = (m*DOWN) mod UP.
 //
 // So the NCO runs at the OUTPUT rate (48 kHz) only, and the input is touched once:
-// HBM-bound streaming read of interleaved IQ, shared by every RX.
+// an HBM-bound streaming read of interleaved IQ shared by every RX.
 //
-// Work decomposition
-//   workgroup  = `tile_out` consecutive outputs = one contiguous input span
-//                (tile_out*DOWN/UP + K samples) staged in LDS with 16-B/lane coalesced
-//                loads; the raw-chunk peak |x|^2 (rx.auto_mute, receiver.py:239) is
-//                reduced on the way in, so every input sample is read exactly once.
-//   half-wave  = one output: 32 lanes split the K taps (ds_read_b64 of x is
-//                conflict-free: 32 consecutive float2 = all 64 banks), each lane
-//                accumulates all RX from one x read, then a DPP row reduction + one
-//                row_bcast folds 32 lanes; lanes 16..16+nrx-1 of the half rotate by the
-//                LO phase and store.
+// Structure: a PERSISTENT grid (one or two workgroups per CU).  Each workgroup walks a
+// contiguous run of tiles with two LDS buffers: while the half-waves compute the dot
+// products of tile t out of one buffer, the LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+// wave-instruction, no VGPR round trip) of tile t+1 is in flight into the other, so HBM
+// never waits for the VALU.  The LO-modulated taps are staged once per workgroup.
+//   tile       = `tile_out` consecutive outputs = one contiguous input span
+//                (tile_out*DOWN/UP + K samples).  The raw-chunk peak |x|^2
+//                (rx.auto_mute, receiver.py:239) is reduced from LDS, so every input
+//                sample is read from HBM exactly once (+ the K-sample halo).
+//   DPP row    = one output: 16 lanes split the K taps, each lane accumulates all RX from
+//                one x read (2 packed FMAs per tap and RX), then four DPP steps fold the
+//                row; lanes 0..nrx-1 of the row rotate by the LO phase (v_sin/v_cos take
+//                revolutions: exact 32-bit phase -> 1.2e-7 abs error) and store.  The four
+//                outputs of a wave belong to the same polyphase branch (outputs UP apart),
+//                so their tap reads are one broadcast address and the x reads of the four
+//                rows (DOWN samples apart) overlap on few banks.
 #include "common.h"
 
 namespace pysdr {
@@ -38,114 +44,120 @@ __device__ __forceinline__ float dpp_half_mirror(float v) {
 __device__ __forceinline__ float dpp_mirror(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
 }
-// rows 1 and 3 receive lane 15 of the previous row, rows 0 and 2 receive 0
-__device__ __forceinline__ float dpp_bcast15(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
-}
-// sum over each 32-lane half; valid in lanes 16..31 and 48..63
-__device__ __forceinline__ float half_wave_sum(float v) {
+// sum over each row of 16 lanes; every lane of the row gets the total
+__device__ __forceinline__ float row_sum(float v) {
   v += dpp_quad_xor1(v);
   v += dpp_quad_xor2(v);
   v += dpp_half_mirror(v);
   v += dpp_mirror(v);
-  v += dpp_bcast15(v);
   return v;
 }
 
-// one 16-byte LDS-DMA element: LDS destination = wave-uniform base + lane*16
-__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(
-      (const __attribute__((address_space(1))) void*)src,
-      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// t / d and t % d with the host's magic = floor(2^32/d)+1 (exact for any 32-bit t: the
+// multiply-high estimate is q or q+1); d == 1 has magic 0
+__device__ __forceinline__ void divmod_magic(uint32_t t, uint32_t d, uint32_t magic, uint32_t& q,
+                                             uint32_t& r) {
+  q = (d == 1u) ? t : __umulhi(t, magic);
+  r = t - q * d;
+  if (r >= d) { q -= 1u; r += d; }
+}
+__device__ __forceinline__ uint32_t div_magic(uint32_t t, uint32_t d, uint32_t magic) {
+  uint32_t q, r;
+  divmod_magic(t, d, magic, q, r);
+  return q;
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+// max over the 64 lanes (DPP only); result valid in lane 63
+__device__ __forceinline__ float wave_max63(float v) {
+  v = fmaxf(v, dpp_quad_xor1(v));
+  v = fmaxf(v, dpp_quad_xor2(v));
+  v = fmaxf(v, dpp_half_mirror(v));
+  v = fmaxf(v, dpp_mirror(v));
+  // row_bcast15: rows 1,3 <- lane 15 of rows 0,2 ; row_bcast31: rows 2,3 <- lane 31
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)));
   return v;
 }
 
-template <int R>
-__global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  float2* xs = lds;                       // [tile_cap]
-  float2* tl = lds + a.tile_cap;          // [R][up][kpad]
+// One 16-byte LDS-DMA element per lane: LDS destination = wave-uniform base (M0) +
+// lane*16, source = per-lane global address.  Issued from inline asm on purpose: hipcc
+// counts a __builtin_amdgcn_global_load_lds as a pending LDS write and drains it
+// (s_waitcnt vmcnt(0)) in front of EVERY later ds_read, which would serialise the copy
+// of tile t+1 with the compute of tile t.  The asm form is invisible to that bookkeeping;
+// the kernel waits for it explicitly (dma_wait) before the barrier that publishes a tile.
+__device__ __forceinline__ void glds16(const void* gsrc, const void* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds_wave_base);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(dst)
+      : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-  const int tid = threadIdx.x;
-  const int nthr = blockDim.x;
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), give
-  // each XCD a contiguous run of tiles so neighbouring halos hit the same L2.
-  int b = blockIdx.x;
-  {
-    const int nb = gridDim.x;
-    const int per = nb >> 3;
-    if (per > 0 && b < (per << 3)) b = (b & 7) * per + (b >> 3);
-  }
-  const int i_first = b * a.tile_out;
-  int tile_n = a.n_out - i_first;
-  if (tile_n > a.tile_out) tile_n = a.tile_out;
-  if (tile_n < 0) tile_n = 0;
-  const int i_last = i_first + tile_n - 1;
-  const bool last_tile = (b == a.ntiles - 1);
+// Geometry of tile b: outputs [i_first, i_last], LDS image = samples [lo, hi] (relative to
+// the first sample of the call; negative = history), samples [own_lo, own_hi] are the ones
+// this tile contributes to the raw-chunk peak.
+struct Tile {
+  int i_first, i_last, tile_n;
+  int lo, hi, own_lo, own_hi, npairs;
+};
 
-  // input span needed by the outputs + the samples this tile "owns" for the peak scan
-  int own_lo, own_hi, need_lo, need_hi;
-  if (tile_n > 0) {
-    need_hi = (int)((a.t0 + (uint32_t)i_last * (uint32_t)a.down) / (uint32_t)a.up);
-    need_lo = (int)((a.t0 + (uint32_t)i_first * (uint32_t)a.down) / (uint32_t)a.up) - (a.kpad - 1);
-    own_hi = need_hi;
+__device__ __forceinline__ Tile tile_geometry(const MixDecArgs& a, int b) {
+  Tile t;
+  t.i_first = b * a.tile_out;
+  int n = a.n_out - t.i_first;
+  if (n > a.tile_out) n = a.tile_out;
+  if (n < 0) n = 0;
+  t.tile_n = n;
+  t.i_last = t.i_first + n - 1;
+  int need_lo, need_hi;
+  if (n > 0) {
+    need_hi = (int)div_magic(a.t0 + (uint32_t)t.i_last * (uint32_t)a.down, (uint32_t)a.up, a.magic);
+    need_lo = (int)div_magic(a.t0 + (uint32_t)t.i_first * (uint32_t)a.down, (uint32_t)a.up, a.magic) - (a.kpad - 1);
+    t.own_hi = need_hi;
   } else {
-    need_hi = -1; need_lo = 0; own_hi = -1;
+    need_hi = -1; need_lo = 0; t.own_hi = -1;
   }
-  own_lo = (b == 0) ? 0
-                    : (int)((a.t0 + (uint32_t)(i_first - 1) * (uint32_t)a.down) / (uint32_t)a.up) + 1;
-  if (last_tile) own_hi = (int)a.n_total - 1;
-  int lo = need_lo < own_lo ? need_lo : own_lo;
-  if (tile_n == 0) lo = own_lo;
-  lo &= ~1;
-  int hi = need_hi > own_hi ? need_hi : own_hi;
-  const int npairs = (hi - lo + 2) >> 1;
+  t.own_lo = (b == 0) ? 0
+                      : (int)div_magic(a.t0 + (uint32_t)(t.i_first - 1) * (uint32_t)a.down, (uint32_t)a.up, a.magic) + 1;
+  if (b == a.ntiles - 1) t.own_hi = (int)a.n_total - 1;
+  int lo = need_lo < t.own_lo ? need_lo : t.own_lo;
+  if (n == 0) lo = t.own_lo;
+  t.lo = lo & ~1;
+  t.hi = need_hi > t.own_hi ? need_hi : t.own_hi;
+  t.npairs = (t.hi - t.lo + 2) >> 1;
+  return t;
+}
 
-  const int wave = tid >> 6, nwaves = nthr >> 6;
-  const int lane = tid & 63;
-
-  if (a.dbg & 2) {
-  } else if (a.aligned16) {
-    // ---- LDS-DMA staging (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR
-    // round trip, every piece of the tile in flight at once).  The LDS image is
-    // lane-linear: piece q covers float4 slots [64q, 64q+64).
-    {
-      const int nt4 = (R * a.up * a.kpad) >> 1;                 // taps as 16-B slots
-      const float4* src = reinterpret_cast<const float4*>(a.taps);
-      float4* dst = reinterpret_cast<float4*>(tl);
-      for (int q = wave; q * 64 < nt4; q += nwaves) {
-        const int slot = q * 64 + lane;
-        if (slot < nt4) glds16(src + slot, dst + q * 64);
-      }
-    }
+// Start the copy of tile `t` into `xs` (does not wait).
+__device__ __forceinline__ void stage_tile(const MixDecArgs& a, const Tile& t, float2* xs, int tid,
+                                           int nthr) {
+  if (a.aligned16) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6, lane = tid & 63;
     float4* dst = reinterpret_cast<float4*>(xs);
-    for (int q = wave; q * 64 < npairs; q += nwaves) {
+    for (int q = wave; q * 64 < t.npairs; q += nwaves) {
       const int pi = q * 64 + lane;
-      const int rel = lo + 2 * pi;
+      const int rel = t.lo + 2 * pi;
       // a pair is DMA-able when both samples exist: history (rel < 0) or rel+1 < n_total
-      const bool ok = pi < npairs && (rel < 0 || (uint32_t)rel + 1u < a.n_total);
+      const bool ok = pi < t.npairs && (rel < 0 || (uint32_t)rel + 1u < a.n_total);
       const float2* src = (rel >= 0) ? (a.x + rel) : (a.hist + (a.hist_len + rel));
       if (ok) glds16(src, dst + q * 64);
     }
     // the one pair that straddles the end of an odd-length call
     if (tid == 0 && (a.n_total & 1u)) {
       const int rel = (int)a.n_total - 1;
-      if (rel >= lo && rel <= hi) {
+      if (rel >= t.lo && rel <= t.hi) {
         const float2 p0 = a.x[rel];
-        *reinterpret_cast<float4*>(xs + (rel - lo)) = make_float4(p0.x, p0.y, 0.f, 0.f);
+        *reinterpret_cast<float4*>(xs + (rel - t.lo)) = make_float4(p0.x, p0.y, 0.f, 0.f);
       }
     }
   } else {
-    // ---- generic staging for inputs that are only 8-byte aligned (slow path)
-    const int nt = R * a.up * a.kpad;
-    for (int i = tid; i < nt; i += nthr) tl[i] = a.taps[i];
-    for (int pi = tid; pi < npairs; pi += nthr) {
-      const int rel = lo + 2 * pi;
+    // generic staging for inputs that are only 8-byte aligned (slow path)
+    for (int pi = tid; pi < t.npairs; pi += nthr) {
+      const int rel = t.lo + 2 * pi;
       float2 p0 = make_float2(0.f, 0.f), p1 = make_float2(0.f, 0.f);
       if (rel < 0) { p0 = a.hist[a.hist_len + rel]; p1 = a.hist[a.hist_len + rel + 1]; }
       else {
@@ -156,83 +168,166 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
       xs[2 * pi + 1] = p1;
     }
   }
-  __syncthreads();
-
-  // ---- raw-chunk peak |x|^2 over the samples this tile owns (rx.auto_mute input).
-  // A tile may straddle chunk boundaries: one wave-reduced scan + one atomic per wave
-  // for every chunk it touches (same-address atomics are slow: never one per sample).
-  if (own_hi >= own_lo && !(a.dbg & 4)) {
-    const uint32_t c_lo = (uint32_t)own_lo / a.chunk_len;
-    const uint32_t c_hi = (uint32_t)own_hi / a.chunk_len;
-    for (uint32_t c = c_lo; c <= c_hi; ++c) {
-      const long long cb = (long long)c * a.chunk_len;
-      const int s_lo = own_lo > cb ? own_lo : (int)cb;
-      const long long ce = cb + a.chunk_len - 1;
-      const int s_hi = own_hi < ce ? own_hi : (int)ce;
-      const int p_lo = (s_lo - lo) >> 1, p_hi = (s_hi - lo) >> 1;
-      float pk = 0.f;
-      for (int pi = p_lo + tid; pi <= p_hi; pi += nthr) {
-        const float4 v = *reinterpret_cast<const float4*>(xs + 2 * pi);
-        const int rel = lo + 2 * pi;
-        const float e0 = (rel >= s_lo) ? v.x * v.x + v.y * v.y : 0.f;
-        const float e1 = (rel + 1 <= s_hi) ? v.z * v.z + v.w * v.w : 0.f;
-        pk = fmaxf(pk, fmaxf(e0, e1));
-      }
-      pk = wave_max(pk);
-      if (lane == 0 && pk > 0.f) atomicMax(a.peak + c, __float_as_uint(pk));
-    }
-  }
-
-  // ---- polyphase dot products: one output per 32-lane half
-  const int half = lane >> 5, s = lane & 31;
-  const int npq = (tile_n + 1) >> 1;
-  for (int pq = wave; pq < ((a.dbg & 1) ? 0 : npq); pq += nwaves) {
-    int i = i_first + 2 * pq + half;
-    const bool valid = (i <= i_last);
-    if (!valid) i = i_last;
-    const uint32_t t = a.t0 + (uint32_t)i * (uint32_t)a.down;
-    const uint32_t rel = t / (uint32_t)a.up;
-    const uint32_t p = t - rel * (uint32_t)a.up;
-    const float2* xp = xs + ((int)rel - lo - s);
-    const float2* tp = tl + p * a.kpad + s;
-    float ar[R], ai[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { ar[r] = 0.f; ai[r] = 0.f; }
-    for (int j = 0; j < a.kpad; j += 32) {
-      const float2 xv = xp[-j];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float2 g = tp[r * a.up * a.kpad + j];
-        ar[r] = fmaf(g.x, xv.x, ar[r]);
-        ar[r] = fmaf(-g.y, xv.y, ar[r]);
-        ai[r] = fmaf(g.x, xv.y, ai[r]);
-        ai[r] = fmaf(g.y, xv.x, ai[r]);
-      }
-    }
-    float sr = 0.f, si = 0.f;
-    uint32_t p0 = 0u, fw = 0u;
-    float2* yp = nullptr;
-    const int myr = s - 16;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float tr = half_wave_sum(ar[r]);
-      const float ti = half_wave_sum(ai[r]);
-      if (myr == r) { sr = tr; si = ti; p0 = a.phase0[r]; fw = a.fword[r]; yp = a.y[r]; }
-    }
-    if (valid && myr >= 0 && myr < R) {
-      const uint32_t ph = p0 + fw * rel;
-      float sn, cs;
-      sincospif((float)(int)ph * (1.0f / 2147483648.0f), &sn, &cs);
-      float2 o;
-      o.x = sr * cs - si * sn;
-      o.y = sr * sn + si * cs;
-      yp[i] = o;
-    }
-  }
 }
 
 template <int R>
-int launch_r(const MixDecArgs& a, int threads, size_t lds, hipStream_t st) {
+__global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  float2* const buf0 = lds;                    // [tile_cap]
+  float2* const buf1 = lds + a.tile_cap;       // [tile_cap]
+  float2* const tl = lds + 2 * a.tile_cap;     // [R][up][kpad]
+
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;   // wave-uniform: SALU
+  const int lane = tid & 63;
+  const int g = lane >> 4, s = lane & 15;       // DPP row, lane within the row
+
+  // contiguous run of tiles for this workgroup
+  const int ng = gridDim.x;
+  const int base = a.ntiles / ng, rem = a.ntiles % ng;
+  const int wb = blockIdx.x;
+  const int t_begin = wb * base + (wb < rem ? wb : rem);
+  const int t_end = t_begin + base + (wb < rem ? 1 : 0);
+  if (t_begin >= t_end) return;
+
+  // ---- stage the LO-modulated taps once
+  if (a.aligned16) {
+    const int nt4 = (R * a.up * a.kpad) >> 1;                   // taps as 16-B slots
+    const float4* src = reinterpret_cast<const float4*>(a.taps);
+    float4* dst = reinterpret_cast<float4*>(tl);
+    for (int q = wave; q * 64 < nt4; q += nwaves) {
+      const int slot = q * 64 + lane;
+      if (slot < nt4) glds16(src + slot, dst + q * 64);
+    }
+  } else {
+    const int nt = R * a.up * a.kpad;
+    for (int i = tid; i < nt; i += nthr) tl[i] = a.taps[i];
+  }
+  Tile cur = tile_geometry(a, t_begin);
+  float pk_run = 0.f;            // running raw-chunk peak of chunk pk_chunk (per lane)
+  uint32_t pk_chunk = 0u;
+  if (!(a.dbg & 2)) stage_tile(a, cur, buf0, tid, nthr);
+
+  for (int tb = t_begin; tb < t_end; ++tb) {
+    float2* const xs = ((tb - t_begin) & 1) ? buf1 : buf0;
+    float2* const xn = ((tb - t_begin) & 1) ? buf0 : buf1;
+    // tile tb has landed; after the barrier everybody is also done reading the other
+    // buffer (tile tb-1), so it can be refilled while we compute.
+    dma_wait();
+    __syncthreads();
+    Tile nxt = cur;
+    if (tb + 1 < t_end) {
+      nxt = tile_geometry(a, tb + 1);
+      if (!(a.dbg & 2)) stage_tile(a, nxt, xn, tid, nthr);
+    }
+
+    // ---- raw-chunk peak |x|^2 over the samples this tile owns (rx.auto_mute input).
+    // A tile may straddle chunk boundaries: one wave-reduced scan + one atomic per wave
+    // for every chunk it touches (same-address atomics are slow: never one per sample).
+    if (cur.own_hi >= cur.own_lo && !(a.dbg & 4)) {
+      const uint32_t c_lo = div_magic((uint32_t)cur.own_lo, a.chunk_len, a.magic_chunk);
+      const uint32_t c_hi = div_magic((uint32_t)cur.own_hi, a.chunk_len, a.magic_chunk);
+      for (uint32_t c = c_lo; c <= c_hi; ++c) {
+        const long long cb = (long long)c * a.chunk_len;
+        const int s_lo = cur.own_lo > cb ? cur.own_lo : (int)cb;
+        const long long ce = cb + a.chunk_len - 1;
+        const int s_hi = cur.own_hi < ce ? cur.own_hi : (int)ce;
+        const int p_lo = (s_lo - cur.lo) >> 1, p_hi = (s_hi - cur.lo) >> 1;
+        const float4* xv = reinterpret_cast<const float4*>(xs);
+        // The running maximum of a chunk stays in a register across tiles; the atomic is
+        // only issued when the run moves on to another chunk (and once at the end): an
+        // atomic per tile would sit in vmcnt and stall the next tile's dma_wait.
+        if (c != pk_chunk) {
+          pk_run = wave_max63(pk_run);
+          if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
+          pk_run = 0.f;
+          pk_chunk = c;
+        }
+        // interior pairs need no masking; the two edge pairs are handled by one lane
+        for (int pi = p_lo + 1 + tid; pi < p_hi; pi += nthr) {
+          const float4 v = xv[pi];
+          pk_run = fmaxf(pk_run, fmaxf(fmaf(v.x, v.x, v.y * v.y), fmaf(v.z, v.z, v.w * v.w)));
+        }
+        if (tid == 0) {
+          const float4 v0 = xv[p_lo], v1 = xv[p_hi];
+          const int r0 = cur.lo + 2 * p_lo, r1 = cur.lo + 2 * p_hi;
+          if (r0 >= s_lo) pk_run = fmaxf(pk_run, fmaf(v0.x, v0.x, v0.y * v0.y));
+          if (r0 + 1 <= s_hi) pk_run = fmaxf(pk_run, fmaf(v0.z, v0.z, v0.w * v0.w));
+          if (r1 >= s_lo) pk_run = fmaxf(pk_run, fmaf(v1.x, v1.x, v1.y * v1.y));
+          if (r1 + 1 <= s_hi) pk_run = fmaxf(pk_run, fmaf(v1.z, v1.z, v1.w * v1.w));
+        }
+      }
+    }
+
+    // ---- polyphase dot products: one output per DPP row (16 lanes), four outputs of the
+    // same polyphase branch per wave
+    const int upc = a.up;
+    const int tpc = (((a.tile_out + upc - 1) / upc) + 3) >> 2;     // tasks per branch
+    const int ntasks = (cur.tile_n > 0 && !(a.dbg & 1)) ? upc * tpc : 0;
+    for (int task = wave; task < ntasks; task += nwaves) {
+      const int c = task / tpc, qq = task - c * tpc;
+      int i = cur.i_first + c + upc * (4 * qq + g);
+      const bool valid = (i <= cur.i_last);
+      if (!valid) i = cur.i_last;
+      uint32_t rel, p;
+      divmod_magic(a.t0 + (uint32_t)i * (uint32_t)a.down, (uint32_t)upc, a.magic, rel, p);
+      const float2* xp = xs + ((int)rel - cur.lo - s);
+      const float2* tp = tl + p * a.kpad + s;
+      // A += g*x.re, B += g*x.im per RX (two packed FMAs per tap, no operand shuffles);
+      // y = (A.re - B.im, A.im + B.re)
+      float2 A[R], B[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { A[r] = make_float2(0.f, 0.f); B[r] = make_float2(0.f, 0.f); }
+#pragma unroll 3
+      for (int j = 0; j < a.kpad; j += 16) {
+        const float2 xv = xp[-j];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float2 gg = tp[r * upc * a.kpad + j];
+          A[r].x = fmaf(gg.x, xv.x, A[r].x);
+          A[r].y = fmaf(gg.y, xv.x, A[r].y);
+          B[r].x = fmaf(gg.x, xv.y, B[r].x);
+          B[r].y = fmaf(gg.y, xv.y, B[r].y);
+        }
+      }
+      // fold the 16 lanes of each row: all 2R partial sums advance one DPP step at a time,
+      // so consecutive instructions are independent (no DPP hazard stalls)
+      float red[2 * R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { red[2 * r] = A[r].x - B[r].y; red[2 * r + 1] = A[r].y + B[r].x; }
+#pragma unroll
+      for (int q = 0; q < 2 * R; ++q) red[q] += dpp_quad_xor1(red[q]);
+#pragma unroll
+      for (int q = 0; q < 2 * R; ++q) red[q] += dpp_quad_xor2(red[q]);
+#pragma unroll
+      for (int q = 0; q < 2 * R; ++q) red[q] += dpp_half_mirror(red[q]);
+#pragma unroll
+      for (int q = 0; q < 2 * R; ++q) red[q] += dpp_mirror(red[q]);
+      float sr = 0.f, si = 0.f;
+      uint32_t p0 = 0u, fw = 0u;
+      float2* yp = nullptr;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (s == r) { sr = red[2 * r]; si = red[2 * r + 1]; p0 = a.phase0[r]; fw = a.fword[r]; yp = a.y[r]; }
+      if (valid && s < R) {
+        const uint32_t ph = p0 + fw * rel;
+        const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+        const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+        float2 o;
+        o.x = sr * cs - si * sn;
+        o.y = sr * sn + si * cs;
+        yp[i] = o;
+      }
+    }
+    cur = nxt;
+  }
+  pk_run = wave_max63(pk_run);
+  if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
+}
+
+template <int R>
+int launch_r(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mixdec_kernel<R>),
@@ -243,7 +338,7 @@ int launch_r(const MixDecArgs& a, int threads, size_t lds, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(mixdec_kernel<R>, dim3(a.ntiles), dim3(threads), lds, st, a);
+  hipLaunchKernelGGL(mixdec_kernel<R>, dim3(grid), dim3(threads), lds, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }
@@ -251,24 +346,26 @@ int launch_r(const MixDecArgs& a, int threads, size_t lds, hipStream_t st) {
 }  // namespace
 
 size_t mixdec_lds_bytes(const MixDecArgs& a) {
-  return ((size_t)a.tile_cap + (size_t)a.nrx * a.up * a.kpad) * sizeof(float2);
+  return (2 * (size_t)a.tile_cap + (size_t)a.nrx * a.up * a.kpad) * sizeof(float2);
 }
 
-int launch_mixdec(const MixDecArgs& a, int threads, hipStream_t st) {
+int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st) {
   const size_t lds = mixdec_lds_bytes(a);
   if (lds > 160 * 1024) {
     set_last_error("mixdec: LDS request %zu > 160 KiB", lds);
     return PYSDR_ERR_ARG;
   }
+  if (grid > a.ntiles) grid = a.ntiles;
+  if (grid < 1) grid = 1;
   switch (a.nrx) {
-    case 1: return launch_r<1>(a, threads, lds, st);
-    case 2: return launch_r<2>(a, threads, lds, st);
-    case 3: return launch_r<3>(a, threads, lds, st);
-    case 4: return launch_r<4>(a, threads, lds, st);
-    case 5: return launch_r<5>(a, threads, lds, st);
-    case 6: return launch_r<6>(a, threads, lds, st);
-    case 7: return launch_r<7>(a, threads, lds, st);
-    case 8: return launch_r<8>(a, threads, lds, st);
+    case 1: return launch_r<1>(a, threads, grid, lds, st);
+    case 2: return launch_r<2>(a, threads, grid, lds, st);
+    case 3: return launch_r<3>(a, threads, grid, lds, st);
+    case 4: return launch_r<4>(a, threads, grid, lds, st);
+    case 5: return launch_r<5>(a, threads, grid, lds, st);
+    case 6: return launch_r<6>(a, threads, grid, lds, st);
+    case 7: return launch_r<7>(a, threads, grid, lds, st);
+    case 8: return launch_r<8>(a, threads, grid, lds, st);
     default: set_last_error("mixdec: nrx=%d", a.nrx); return PYSDR_ERR_ARG;
   }
 }

@@ -27,11 +27,10 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-// exp(-j*pi*t)
+// exp(-j*pi*t): v_sin_f32 / v_cos_f32 take revolutions (1.2e-7 abs error on gfx950)
 __device__ __forceinline__ float2 expmpi(float t) {
-  float s, c;
-  sincospif(t, &s, &c);
-  return make_float2(c, -s);
+  const float rev = 0.5f * t;
+  return make_float2(__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev));
 }
 
 // 4-point DFT in place (W4 = -j): (a,b,c,d) -> (X0,X1,X2,X3)

@@ -79,9 +79,8 @@ __global__ __launch_bounds__(kFirTile) void demod_fir_kernel(const Stage2Args a)
         d.x = (fm / den) * a.fm_scale;
       } else if (det == kDetBfo) {
         const uint32_t ph = a.bfo_fword[r] * (a.m0_lo + (uint32_t)i);
-        float s, c;
-        sincospif((float)(int)ph * (1.0f / 2147483648.0f), &s, &c);
-        d = cmul(yc, make_float2(c, s));
+        const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+        d = cmul(yc, make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)));
       } else if (det == kDetPll) {
         d.x = yc.x;
       } else {
