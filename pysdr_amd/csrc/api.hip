@@ -62,7 +62,8 @@ struct RxHost {
   float2* d_ypll = nullptr;     // [hy + mmax], allocated on first AM-Synch use
   float2* d_a = nullptr;        // [mmax]
   float* d_am = nullptr;        // [2*mmax]
-  float2* d_aftaps = nullptr;   // [ntaps_af]
+  float2* d_aftaps = nullptr;   // [ntaps_af rounded up to 4], zero padded
+  int taps_real = 0;
 };
 
 }  // namespace
@@ -162,9 +163,12 @@ int apply_pending(pysdr_ctx* c) {
       x.taps_dirty = false;
     }
     if (x.af_dirty) {
-      std::vector<float2> t(c->cfg.ntaps_af);
-      for (int k = 0; k < c->cfg.ntaps_af; ++k)
+      std::vector<float2> t((c->cfg.ntaps_af + 3) & ~3, make_float2(0.f, 0.f));
+      x.taps_real = 1;
+      for (int k = 0; k < c->cfg.ntaps_af; ++k) {
         t[k] = make_float2((float)x.af[2 * k], (float)x.af[2 * k + 1]);
+        if (t[k].y != 0.f) x.taps_real = 0;
+      }
       PYSDR_HIP_CHECK(hipMemcpyAsync(x.d_aftaps, t.data(), t.size() * sizeof(float2),
                                      hipMemcpyHostToDevice, c->stream));
       PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));   // t goes out of scope
@@ -252,7 +256,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   c->kdec = (cfg->ntaps_dec + cfg->up - 1) / cfg->up;
   c->kpad = (c->kdec + 15) / 16 * 16;
   c->hist_len = c->kpad + 2;
-  c->hy = (cfg->ntaps_af + 1 + 1) & ~1;
+  c->hy = (((cfg->ntaps_af + 3) & ~3) + 4 + 1) & ~1;   // FIR history (padded taps) + discriminator
   c->cap_samples = (size_t)cfg->max_chunks * (size_t)cfg->in_chunk;
   c->mmax = (int)((c->cap_samples * (size_t)cfg->up) / (size_t)cfg->down) + 4;
   {
@@ -277,6 +281,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   CK(hipMemset(c->d_taps, 0, (size_t)PYSDR_MAX_RX * per * sizeof(float2)));
   CK(hipMalloc(&c->d_peak, (size_t)cfg->max_chunks * sizeof(unsigned)));
   CK(hipMalloc(&c->d_blkpeak, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
+  CK(hipMemset(c->d_blkpeak, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
   CK(hipMalloc(&c->d_gain, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
   CK(hipMalloc(&c->d_state, PYSDR_MAX_RX * sizeof(RxDevState)));
   CK(hipMemset(c->d_state, 0, PYSDR_MAX_RX * sizeof(RxDevState)));
@@ -343,7 +348,7 @@ int pysdr_rx_add(pysdr_ctx* c, int mode, double lo_freq, const double* h, const 
   PYSDR_HIP_CHECK(hipMemset(x.d_y, 0, ny * sizeof(float2)));
   PYSDR_HIP_CHECK(hipMalloc(&x.d_a, (size_t)c->mmax * sizeof(float2)));
   PYSDR_HIP_CHECK(hipMalloc(&x.d_am, (size_t)c->mmax * 2 * sizeof(float)));
-  PYSDR_HIP_CHECK(hipMalloc(&x.d_aftaps, (size_t)c->cfg.ntaps_af * sizeof(float2)));
+  PYSDR_HIP_CHECK(hipMalloc(&x.d_aftaps, (size_t)((c->cfg.ntaps_af + 3) & ~3) * sizeof(float2)));
   c->nrx = r + 1;
   if (irx) *irx = r;
   return PYSDR_OK;
@@ -486,7 +491,6 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   const uint32_t t0 = (uint32_t)(m0 * down - s0 * up);
 
   PYSDR_HIP_CHECK(hipMemsetAsync(c->d_peak, 0, (size_t)nchunks * sizeof(unsigned), c->stream));
-  PYSDR_HIP_CHECK(hipMemsetAsync(c->d_blkpeak, 0, (size_t)c->nrx * nchunks * sizeof(unsigned), c->stream));
 
   MixDecArgs a;
   memset(&a, 0, sizeof(a));
@@ -559,6 +563,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     s.y[r] = x.d_y + c->hy;
     s.ypll[r] = x.d_ypll ? x.d_ypll + c->hy : nullptr;
     s.aftaps[r] = x.d_aftaps;
+    s.taps_real[r] = x.taps_real;
     s.a[r] = x.d_a;
     s.am[r] = x.d_am;
     s.det[r] = mode_detector(x.mode);

@@ -77,7 +77,8 @@ struct Stage2Args {
   float pll_kp, pll_ki;
   const float2* y[PYSDR_MAX_RX];      // points at element for output 0 (prefix before it)
   float2* ypll[PYSDR_MAX_RX];         // same layout, only for AM-Synch
-  const float2* aftaps[PYSDR_MAX_RX]; // [ntaps]
+  const float2* aftaps[PYSDR_MAX_RX]; // [4*ceil(ntaps/4)], zero padded
+  int taps_real[PYSDR_MAX_RX];        // all AF taps have zero imaginary part
   float2* a[PYSDR_MAX_RX];            // AF-filter output
   float* am[PYSDR_MAX_RX];            // final audio (float, or float2 when IQ)
   int det[PYSDR_MAX_RX];

@@ -9,8 +9,6 @@ namespace pysdr {
 
 namespace {
 
-constexpr int kFirTile = 256;
-
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -49,112 +47,188 @@ __global__ void pll_kernel(const Stage2Args a) {
   st->pll_w = w;
 }
 
-// ---- detector + AF FIR + block peak.  grid = (tiles, nrx), 256 outputs per workgroup.
-__global__ __launch_bounds__(kFirTile) void demod_fir_kernel(const Stage2Args a) {
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+// ---- detector + AF FIR + block peak.  grid = (tiles, nrx), 1024 outputs per workgroup,
+// four consecutive outputs per thread.  The detector output d is staged in LDS as four
+// de-interleaved sub-arrays D_m[q] = d[4q+m]: thread t owns outputs 4t..4t+3, and at tap k
+// needs d[4t+j-k] -- a window that slides by ONE element per tap, so each tap costs one
+// conflict-free LDS read (lanes read consecutive q of one sub-array) for four outputs.
+// The taps are wave-uniform and come through the scalar cache (s_load), not LDS.
+// Arithmetic is specialised by what the mode needs (kFir* below): AM/NFM/AM-Synch have a
+// real detector and real taps (1 FMA per tap), the SSB family needs only Re(c*d) (2 FMA).
+constexpr int kFirOut = 1024;          // outputs per workgroup
+constexpr int kFirThreads = 256;
+constexpr int kFirRealReal = 0;        // d real, c real    -> real
+constexpr int kFirRePart = 1;          // d cplx, c cplx    -> Re(c*d)
+constexpr int kFirCplx = 2;            // d cplx, c cplx    -> cplx (IQ)
+
+__device__ __forceinline__ float2 detect(const Stage2Args& a, int r, int det, const float2* y, int i) {
+  float2 d = make_float2(0.f, 0.f);
+  if (i >= a.n_out) return d;
+  const float2 yc = y[i];
+  if (det == kDetAbs) {
+    d.x = sqrtf(yc.x * yc.x + yc.y * yc.y);
+  } else if (det == kDetFm) {
+    // sigs/nfm.m:124-127: fm = Re(y1)*Im(d) - Im(y1)*Re(d), d = y[n+1]-y[n-1]
+    const float2 y1 = y[i - 1], ya = y[i - 2];
+    const float dr = yc.x - ya.x, di = yc.y - ya.y;
+    const float fm = y1.x * di - y1.y * dr;
+    const float den = 2.f * (y1.x * y1.x + y1.y * y1.y) + 1e-20f;
+    d.x = (fm / den) * a.fm_scale;
+  } else if (det == kDetBfo) {
+    const uint32_t ph = a.bfo_fword[r] * (a.m0_lo + (uint32_t)i);
+    const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+    d = cmul(yc, make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)));
+  } else if (det == kDetPll) {
+    d.x = yc.x;
+  } else {
+    d = yc;
+  }
+  return d;
+}
+
+template <int KIND>
+__device__ __forceinline__ void fir4(const Stage2Args& a, int r, int hq, const float2* __restrict__ taps,
+                                     int ntaps4, const float* dre, const float* dim, int sub, int tid,
+                                     float2 (&acc)[4]) {
+  // window w[j] = d[e0 + j - k], e0 = 4*(hq + tid); element e lives at D[e&3][e>>2]
+  float wr[4], wi[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    wr[j] = dre[j * sub + hq + tid];
+    wi[j] = (KIND == kFirRealReal) ? 0.f : dim[j * sub + hq + tid];
+    acc[j] = make_float2(0.f, 0.f);
+  }
+  for (int g = 0; g < ntaps4; ++g) {
+    const int q = hq + tid - g - 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float2 c = taps[4 * g + u];                    // wave-uniform: scalar load
+      // outputs j use window slot (j - u) mod 4 ... slots rotate instead of moving registers
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sl = (j - u) & 3;
+        if (KIND == kFirRealReal) {
+          acc[j].x = fmaf(c.x, wr[sl], acc[j].x);
+        } else {
+          acc[j].x = fmaf(c.x, wr[sl], acc[j].x);
+          acc[j].x = fmaf(-c.y, wi[sl], acc[j].x);
+          if (KIND == kFirCplx) {
+            acc[j].y = fmaf(c.x, wi[sl], acc[j].y);
+            acc[j].y = fmaf(c.y, wr[sl], acc[j].y);
+          }
+        }
+      }
+      // next tap: the window moves down by one element; the slot that held the newest
+      // element d[e0+3-k] is refilled with d[e0-k-1] = D[(3-u)][q + (u==3 ? ... )]
+      const int sl_new = (3 - u) & 3;                      // slot of j=3 at this u
+      const int m = (3 - u) & 3;                           // (e0 - k - 1) mod 4 with k = 4g+u
+      wr[sl_new] = dre[m * sub + q];
+      if (KIND != kFirRealReal) wi[sl_new] = dim[m * sub + q];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
   const int r = blockIdx.y;
-  const int nt = a.ntaps;
-  float2* ds = lds;                    // [kFirTile + nt - 1]   detector output d[i0-(nt-1) ..]
-  float2* cs = lds + kFirTile + nt - 1;// [nt]
   const int tid = threadIdx.x;
-  const int i0 = blockIdx.x * kFirTile;
+  const int i0 = blockIdx.x * kFirOut;
   const int det = a.det[r];
   const float2* y = (det == kDetPll) ? a.ypll[r] : a.y[r];
+  const int ntaps4 = (a.ntaps + 3) >> 2;                 // taps are zero padded to 4*ntaps4
+  const int hq = ntaps4;                                 // history quads in front of the tile
+  const int sub = kFirOut / 4 + hq;                      // length of one sub-array
+  float* dre = lds_f;                                    // [4][sub]
+  float* dim = lds_f + 4 * sub;                          // [4][sub]
+  const bool real_det = (det == kDetAbs || det == kDetFm || det == kDetPll);
 
-  for (int k = tid; k < nt; k += kFirTile) cs[k] = a.aftaps[r][k];
-  const int nd = kFirTile + nt - 1;
-  for (int j = tid; j < nd; j += kFirTile) {
-    const int i = i0 - (nt - 1) + j;          // may be negative: history prefix
-    float2 d = make_float2(0.f, 0.f);
-    if (i < a.n_out) {
-      const float2 yc = y[i];
-      if (det == kDetAbs) {
-        d.x = sqrtf(yc.x * yc.x + yc.y * yc.y);
-      } else if (det == kDetFm) {
-        // sigs/nfm.m:124-127: fm = Re(y1)*Im(d) - Im(y1)*Re(d), d = y[n+1]-y[n-1]
-        const float2 y1 = y[i - 1], ya = y[i - 2];
-        const float dr = yc.x - ya.x, di = yc.y - ya.y;
-        const float fm = y1.x * di - y1.y * dr;
-        const float den = 2.f * (y1.x * y1.x + y1.y * y1.y) + 1e-20f;
-        d.x = (fm / den) * a.fm_scale;
-      } else if (det == kDetBfo) {
-        const uint32_t ph = a.bfo_fword[r] * (a.m0_lo + (uint32_t)i);
-        const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
-        d = cmul(yc, make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)));
-      } else if (det == kDetPll) {
-        d.x = yc.x;
-      } else {
-        d = yc;
-      }
-    }
-    ds[j] = d;
+  const float2* taps = a.aftaps[r];
+  const int kind = a.out_complex[r] ? kFirCplx : (real_det && a.taps_real[r] ? kFirRealReal : kFirRePart);
+  // stage d[i0 - 4 hq + e], e = 0 .. 4*sub-1
+  for (int e = tid; e < 4 * sub; e += kFirThreads) {
+    const float2 d = detect(a, r, det, y, i0 - 4 * hq + e);
+    dre[(e & 3) * sub + (e >> 2)] = d.x;
+    if (kind != kFirRealReal) dim[(e & 3) * sub + (e >> 2)] = d.y;
   }
   __syncthreads();
 
-  const int i = i0 + tid;
-  float2 acc = make_float2(0.f, 0.f);
-  const float2* dp = ds + (nt - 1) + tid;
-  for (int k = 0; k < nt; ++k) {
-    const float2 c = cs[k];
-    const float2 d = dp[-k];
-    acc.x = fmaf(c.x, d.x, acc.x);
-    acc.x = fmaf(-c.y, d.y, acc.x);
-    acc.y = fmaf(c.x, d.y, acc.y);
-    acc.y = fmaf(c.y, d.x, acc.y);
-  }
+  float2 acc[4];
+  if (kind == kFirRealReal) fir4<kFirRealReal>(a, r, hq, taps, ntaps4, dre, dim, sub, tid, acc);
+  else if (kind == kFirRePart) fir4<kFirRePart>(a, r, hq, taps, ntaps4, dre, dim, sub, tid, acc);
+  else fir4<kFirCplx>(a, r, hq, taps, ntaps4, dre, dim, sub, tid, acc);
+
+  const int ib = i0 + 4 * tid;
   float mag = 0.f;
-  uint32_t blk = 0xFFFFFFFFu;
-  if (i < a.n_out) {
-    a.a[r][i] = acc;
-    mag = a.out_complex[r] ? sqrtf(acc.x * acc.x + acc.y * acc.y) : fabsf(acc.x);
-    blk = block_of(a, i);
+  uint32_t blk_lo = 0xFFFFFFFFu, blk_hi = 0xFFFFFFFFu;
+  if (ib < a.n_out) {
+    const int last = (ib + 3 < a.n_out) ? ib + 3 : a.n_out - 1;
+    blk_lo = block_of(a, ib);
+    blk_hi = block_of(a, last);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ib + j < a.n_out) {
+        a.a[r][ib + j] = acc[j];
+        const float m = a.out_complex[r] ? sqrtf(acc[j].x * acc[j].x + acc[j].y * acc[j].y) : fabsf(acc[j].x);
+        if (blk_lo == blk_hi) mag = fmaxf(mag, m);
+        else atomicMax(a.blkpeak + (size_t)r * a.nchunks + block_of(a, ib + j), __float_as_uint(m));
+      }
   }
-  // block peak: one atomic per wave when the wave sits inside one block
-  const uint32_t b0 = __shfl(blk, 0);
-  const bool uniform = __all(blk == b0 || blk == 0xFFFFFFFFu);
+  // block peak: one atomic per wave when the whole wave sits inside one block
+  const uint32_t b0 = __shfl(blk_lo, 0);
+  const bool uniform = __all((blk_lo == b0 && blk_hi == b0) || blk_lo == 0xFFFFFFFFu);
   if (uniform) {
     float m = mag;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((tid & 63) == 0 && b0 != 0xFFFFFFFFu)
       atomicMax(a.blkpeak + (size_t)r * a.nchunks + b0, __float_as_uint(m));
-  } else if (blk != 0xFFFFFFFFu) {
-    atomicMax(a.blkpeak + (size_t)r * a.nchunks + blk, __float_as_uint(mag));
+  } else if (blk_lo != 0xFFFFFFFFu && blk_lo == blk_hi) {
+    atomicMax(a.blkpeak + (size_t)r * a.nchunks + blk_lo, __float_as_uint(mag));
   }
 }
 
 // ---- AGC recursion over the blocks of this call (sigs/agc.m:6-12 loop filter on decay,
-// immediate attack).  One workgroup per RX: the block peaks are staged in LDS by all
-// lanes, lane 0 runs the serial recursion out of LDS (the only dependent chain is
-// cmp/sub/mul/add/select on env), gains go back through LDS and are stored in parallel.
+// immediate attack).  One workgroup per RX.  Only the envelope recursion is serial
+// (lane 0, out of LDS, ~5 dependent VALU ops per block); the gains -- one IEEE division
+// each -- are then computed by all lanes in parallel.
 __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
   extern __shared__ __attribute__((aligned(16))) float agc_lds[];
   const int r = blockIdx.x;
   const int tid = threadIdx.x;
-  float* pk = agc_lds;                 // [nchunks]
-  float* gn = agc_lds + a.nchunks;     // [nchunks]
+  float* pk = agc_lds;                 // [nchunks] block peaks, then envelopes
   for (int c = tid; c < a.nchunks; c += 256)
     pk[c] = __uint_as_float(a.blkpeak[(size_t)r * a.nchunks + c]);
   __syncthreads();
+  const RxDevState st = a.state[r];
+  float last_peak = st.maxbuf;
   if (tid == 0) {
-    RxDevState st = a.state[r];
     const float beta = 0.1f;
-    float env = st.env, g = st.gain, peak = st.maxbuf;
+    float env = st.env;
     for (int c = 0; c < a.nchunks; ++c) {
-      peak = pk[c];
+      const float peak = pk[c];
       const float dec = __fadd_rn(env, __fmul_rn(beta, __fsub_rn(peak, env)));
       env = (peak > env) ? peak : dec;
-      g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(env, 1e-12f)), 1.0e4f) : 1.f;
-      gn[c] = g;
-    }
-    if (a.nchunks > 0) {
-      st.env = env; st.gain = g; st.maxbuf = peak;
-      st.err = __fsub_rn(st.ref, __fmul_rn(g, peak));
-      a.state[r] = st;
+      pk[c] = env;
+      last_peak = peak;
     }
   }
   __syncthreads();
-  for (int c = tid; c < a.nchunks; c += 256) a.gain[(size_t)r * a.nchunks + c] = gn[c];
+  for (int c = tid; c < a.nchunks; c += 256) {
+    const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(pk[c], 1e-12f)), 1.0e4f) : 1.f;
+    a.gain[(size_t)r * a.nchunks + c] = g;
+    // the raw block peaks are consumed: leave them zeroed for the next call
+    a.blkpeak[(size_t)r * a.nchunks + c] = 0u;
+  }
+  if (tid == 0 && a.nchunks > 0) {
+    const float env = pk[a.nchunks - 1];
+    const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(env, 1e-12f)), 1.0e4f) : 1.f;
+    RxDevState o = st;
+    o.env = env;
+    o.gain = g;
+    o.maxbuf = last_peak;
+    o.err = __fsub_rn(st.ref, __fmul_rn(g, last_peak));
+    a.state[r] = o;
+  }
 }
 
 // ---- apply the block gain, emit rx.am (real, or complex in IQ mode)
@@ -202,15 +276,16 @@ int launch_pll(const Stage2Args& a, hipStream_t st) {
 
 int launch_demod_fir(const Stage2Args& a, hipStream_t st) {
   if (a.n_out <= 0) return PYSDR_OK;
-  const size_t lds = (size_t)(kFirTile + 2 * a.ntaps - 1) * sizeof(float2);
-  dim3 grid((a.n_out + kFirTile - 1) / kFirTile, a.nrx);
-  hipLaunchKernelGGL(demod_fir_kernel, grid, dim3(kFirTile), lds, st, a);
+  const int ntaps4 = (a.ntaps + 3) >> 2;
+  const size_t lds = (size_t)8 * (kFirOut / 4 + ntaps4) * sizeof(float);
+  dim3 grid((a.n_out + kFirOut - 1) / kFirOut, a.nrx);
+  hipLaunchKernelGGL(demod_fir_kernel, grid, dim3(kFirThreads), lds, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }
 
 int launch_agc_scan(const Stage2Args& a, hipStream_t st) {
-  hipLaunchKernelGGL(agc_scan_kernel, dim3(a.nrx), dim3(256), (size_t)a.nchunks * 2 * sizeof(float), st, a);
+  hipLaunchKernelGGL(agc_scan_kernel, dim3(a.nrx), dim3(256), (size_t)a.nchunks * sizeof(float), st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }
