@@ -1,0 +1,234 @@
+"""Headless receiver executive: the caller side of the hot path, with the same names, call
+order and per-chunk post-processing as the reference's ``receiver.py`` (``SDR_EXECUTIVE.Run``
+:684, ``read_chunk`` :538, ``mode_freq_change`` :633, ``demodulate_data`` :231,
+``audio_out`` :153) and the ``am.py`` harness (:54-75), minus everything that needs a
+display, a sound card or a radio.  It drives ``dsp.Receiver`` objects -- by default
+``pysdr_amd.sig_proc`` (the GPU) -- through exactly the calls the reference makes, so the
+parity tests read like the reference's main loop.
+
+MP_SCHEME 1 only (one RX thread, all sub-receivers served per chunk, ``receiver.py:723-725``);
+the GPU context shares the chunk between sub-receivers instead of MP_SCHEME 3's process
+fan-out (``receiver.py:726-739``)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .stream import SOAPY_SDR_CF32, SOAPY_SDR_RX
+from .tables import AF_BWs, VIDEO_BWs
+
+
+class NullPlayer:
+    """Stands in for ``audio_io.AudioIO`` (``receiver.py:850``): owns the ring buffer the
+    audio would be pulled from; never opens a sound device."""
+
+    def __init__(self, rb, fs, tag=''):
+        self.rb = rb
+        self.fs = fs
+        self.tag = tag
+        self.active = False
+        self.Start_Time = 0.0
+
+    def start_playback(self, delay, flag):
+        self.active = True
+        return True
+
+    def pause(self):
+        self.active = False
+
+    def resume(self):
+        self.active = True
+
+    def stop(self):
+        self.active = False
+
+
+def demodulate_data(P, x, irx):
+    """One sub-receiver, one chunk (``receiver.py:231-297``)."""
+    rx = P.rx[irx]
+    am = rx.demod_data(x)
+
+    if getattr(P, 'ENABLE_AUTO_MUTE', False):           # receiver.py:238-245
+        P.AUTO_MUTED = bool(rx.auto_mute(x))
+
+    mode = rx.mode if getattr(rx, 'mode', None) is not None else P.MODE
+    if mode == 'AM' or mode == 'USB':                   # receiver.py:250-252: DC removal
+        am = am - np.mean(am)
+        rx.am = am
+
+    if P.SHOW_AF_PSD and irx == P.PLOT_RX:              # receiver.py:257-274
+        P.rb_af.push(rx.iq if P.PANADAPTOR else am)
+    if P.SHOW_BASEBAND_PSD and irx == P.PLOT_RX:        # receiver.py:276-284
+        P.rb_baseband.push(rx.iq)
+    if P.SAVE_BASEBAND and irx == 0:                    # receiver.py:293-297
+        P.baseband_iq_io.save_data(rx.iq)
+    if P.SAVE_DEMOD and irx == 0:
+        P.demod_io.save_data(am)
+    return am
+
+
+def audio_out(P):
+    """Route demodulated audio to the players' ring buffers (``receiver.py:153-225``)."""
+    if P.AUDIO_SCHEME == 2:                             # two mono RX per stereo player
+        n2 = int((P.NUM_RX + 1) / 2)
+        for iplay in range(n2):
+            g1 = 0. if P.MUTED[iplay] else pow(10., P.AF_GAIN) - 1
+            am1 = P.rx[iplay].am.real
+            if iplay + n2 < P.NUM_RX:
+                g2 = 0. if P.MUTED[iplay + n2] else pow(10., P.AF_GAIN) - 1
+                am2 = P.rx[iplay + n2].am.real
+                n = min(len(am1), len(am2))
+                am1, am2 = am1[:n], am2[:n]
+            else:
+                g2, am2 = 0., 0
+            if P.audio_playback:
+                player = P.players[iplay]
+                player.rb.push(am1 * g1 + 1j * am2 * g2)
+                if not player.active:
+                    player.start_playback(P.DELAY, False)
+        return
+    for irx in range(P.NUM_RX):                         # default: one player per RX
+        am = P.rx[irx].am
+        player = P.players[irx]
+        gain = 0. if (P.MUTED[irx] or P.AUTO_MUTED) else pow(10., P.AF_GAIN) - 1
+        if P.audio_playback:
+            player.rb.push(am * gain)
+            if not player.active:
+                player.start_playback(P.DELAY, False)
+
+
+class SDR_EXECUTIVE:
+    def __init__(self, P, GUI=False, dsp=None):
+        if dsp is None:
+            from . import sig_proc as dsp
+        self.dsp = dsp
+        self.P = P
+        P.SDR_EXEC = self
+        P.RX_DONE = False
+        P.nchunks = 0
+        self.create_Receivers()
+        self.create_Audio_Players()
+        # buffers: grab enough RF samples to produce one block of OUT_CHUNK_SIZE audio
+        self.xold = np.zeros(0, np.complex64)
+        self.xx = np.zeros(P.IN_CHUNK_SIZE, np.complex64)
+        self.x = np.zeros(P.IN_CHUNK_SIZE, np.complex64)
+        self.raw = None
+        self.praw = 0
+
+    # -- receiver.py:826-835
+    def create_Receivers(self):
+        P = self.P
+        for irx in range(P.NUM_RX):
+            if P.SOURCE[irx] >= 0:
+                frq = P.FC[irx] - P.FC[P.SOURCE[irx]]
+            else:
+                frq = P.FOFFSET + P.FC[irx] - P.FC[0]
+            P.rx[irx] = self.dsp.Receiver(P, frq, irx, str(irx + 1), VIDEO_BWs, AF_BWs)
+
+    # -- receiver.py:838-851 without the sound card
+    def create_Audio_Players(self):
+        P = self.P
+        P.players = []
+        for irx in range(P.NUM_PLAYERS):
+            rb = self.dsp.ring_buffer2('Audio' + str(irx + 1), P.RB_SIZE)
+            P.players.append(NullPlayer(rb, P.FS_OUT, 'RX ' + str(irx)))
+
+    # -- receiver.py:504-534
+    def Startup(self):
+        P = self.P
+        if P.REPLAY_MODE:
+            self.raw = P.sdr.read_data()
+            self.praw = 0
+        else:
+            P.rxStream = P.sdr.setupStream(SOAPY_SDR_RX, SOAPY_SDR_CF32)
+            P.sdr.activateStream(P.rxStream)
+
+    # -- receiver.py:538-631
+    def read_chunk(self):
+        P = self.P
+        n = P.IN_CHUNK_SIZE
+        if P.REPLAY_MODE:
+            if self.praw + n < len(self.raw):
+                x1 = self.raw[self.praw:self.praw + n]
+                self.praw += n
+                lo = getattr(P, 'lo', None)
+                self.x = lo.quad_mixer(x1) if (lo is not None and lo.fo != 0) else x1
+            else:
+                P.RX_DONE = True
+            return
+        # readStream does not block: keep reading until the chunk is full, carrying the
+        # surplus of the last read over to the next chunk
+        nn = len(self.xold)
+        if nn > 0:
+            self.x[0:nn] = self.xold
+            self.xold = self.xold[:0]
+        n1 = nn
+        idle = 0
+        while n1 < n and not (P.Stopper and P.Stopper.is_set()):
+            try:
+                sr = P.sdr.readStream(P.rxStream, [self.xx], n)
+                got = sr.ret
+            except Exception:                           # receiver.py:603-605: trap, treat as 0
+                got = 0
+            if got > 0:
+                n2 = min(n1 + got, n)
+                m = n1 + got - n2
+                self.x[n1:n2] = self.xx[0:got - m]
+                self.xold = self.xx[got - m:got].copy()
+                n1 = n2
+                idle = 0
+            else:
+                idle += 1
+                exhausted = getattr(P.sdr, 'exhausted', None)
+                if (exhausted is not None and exhausted()) or idle > 1000:
+                    P.RX_DONE = True                    # synthetic source ran dry
+                    return
+
+    # -- receiver.py:633-650
+    def mode_freq_change(self):
+        P = self.P
+        if P.MODE_CHANGE:
+            if P.NEW_MODE == 'FM':
+                P.NEW_MODE = 'NFM'
+            if P.MODE != P.NEW_MODE:
+                P.MODE = P.NEW_MODE
+                P.rx[0].agc.reset()
+                P.rx[0].demod.am_pll.reset()
+            P.MODE_CHANGE = False
+
+    # -- receiver.py:684-773
+    def Run(self, on_chunk=None):
+        P = self.P
+        dt = float(P.IN_CHUNK_SIZE) / P.SRATE
+        t = 0.0
+        self.Startup()
+        while not P.RX_DONE:
+            t += dt
+            P.nchunks += 1
+            if P.Stopper and P.Stopper.is_set():
+                P.RX_DONE = True
+                break
+            self.read_chunk()
+            if P.RX_DONE:
+                break
+            self.mode_freq_change()
+            for irx in range(P.NUM_RX):
+                demodulate_data(P, self.x, irx)
+            audio_out(P)
+            if P.SHOW_RF_PSD:
+                P.rb_rf.push(self.x)
+            if P.SAVE_IQ:
+                P.raw_iq_io.save_data(self.x)
+            if on_chunk is not None:
+                on_chunk(self)
+            P.RX_DONE = P.RX_DONE or t >= P.DURATION
+        self.quit_rx()
+
+    # -- receiver.py:461-500
+    def quit_rx(self):
+        P = self.P
+        for pl in P.players:
+            if pl.active:
+                pl.stop()
+        if not P.REPLAY_MODE and P.sdr is not None:
+            P.sdr.deactivateStream(P.rxStream)
+            P.sdr.closeStream(P.rxStream)
