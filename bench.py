@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--tile-bytes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-chunks", type=int, default=48)
+    ap.add_argument("--cpu-chunks", type=int, default=640, help="chunks timed on the CPU oracle (about 10 s)")
     return ap.parse_args()
 
 
@@ -74,19 +74,20 @@ def cpu_baseline(cfg, nchunks, with_psd, seed):
     except Exception:
         limiter = None
     L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
-    x = so.synth_iq(cfg, nchunks * L, seed)
+    uniq = 8                              # same 8-chunk synthetic loop the GPU batch is built from
+    x = so.synth_iq(cfg, uniq * L, seed)
     rxs = so.make_receivers(cfg, np.float32)
     sp = so.Spectrum(cfg['fs'] / 1e3, PSD_CHUNK, PSD_NFFT, 0.0, np.float32)
     for rx in rxs:                       # warm-up chunk (BLAS init, page faults)
         rx.demod_data(x[:L])
     t0 = time.perf_counter()
     for k in range(nchunks):
-        xc = x[k * L:(k + 1) * L]
+        xc = x[(k % uniq) * L:(k % uniq + 1) * L]
         for rx in rxs:
             rx.demod_data(xc)
-    if with_psd:
-        for i in range(0, nchunks * L - PSD_CHUNK + 1, PSD_CHUNK):
-            sp.periodogram(x[i:i + PSD_CHUNK], True)
+        if with_psd:                     # every sample PSD'd: L/32768 frames per chunk
+            for i in range(0, L - PSD_CHUNK + 1, PSD_CHUNK):
+                sp.periodogram(xc[i:i + PSD_CHUNK], True)
     dt = time.perf_counter() - t0
     if limiter is not None:
         limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
@@ -94,6 +95,18 @@ def cpu_baseline(cfg, nchunks, with_psd, seed):
                 sample=f"{nchunks} chunks x {L} samples ({nchunks * L / cfg['fs']:.2f} s of signal), "
                        f"{len(rxs)} RX serial{' + 64k PSD' if with_psd else ''}, float32 NumPy/SciPy oracle, "
                        f"{dt:.1f} s wall; host has {os.cpu_count()} cores")
+
+
+def measured_traffic(args, nrx, B):
+    """HBM bytes per mix+decimate launch from the committed PMC passes (FETCH_SIZE x2 on
+    gfx950 + WRITE_SIZE), valid only for the configuration that was profiled."""
+    if args.workload != "c3" or B != 512 or nrx != 4:
+        return None
+    try:
+        rows = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        return [r["hbm_bytes_per_launch"] for r in rows if r["kernel"] == "mixdec_kernel"][0]
+    except Exception:
+        return None
 
 
 def main():
@@ -232,7 +245,8 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": measured_traffic(args, nrx, B),
+            "traffic_source": "profiles/r01_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE of mixdec_kernel, separate rocprofv3 --pmc passes of this same command (null when the config differs from the profiled one)",
             "algorithmic_bytes_per_launch": k1_bytes,
             "avg_launch_ms": k1_ms,
         },

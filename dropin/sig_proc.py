@@ -6,5 +6,5 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from pysdr_amd.sig_proc import (Receiver, bpf, ring_buffer2, ring_buffer3,  # noqa: E402,F401
+from pysdr_amd.sig_proc import (Receiver, bpf, convolver, ring_buffer2, ring_buffer3,  # noqa: E402,F401
                                 signal_generator, spectrum, up_dn)

@@ -140,6 +140,10 @@ int pysdr_quad_mixer(int device, const float* x, float* y, size_t n, uint32_t ph
                      uint32_t fword, uint32_t* phase_out);
 uint32_t pysdr_freq_word(double f_hz, double fs_hz, double* f_actual);
 
+/* ---- convolver.convolve_fast (receiver.py:207,216,862): streaming real FIR.
+ * xx = [ntaps-1 history samples | n new samples]; y[i] = sum_k h[k]*xx[i+ntaps-1-k] */
+int pysdr_fir_real(int device, const float* xx, const float* h, int ntaps, float* y, size_t n);
+
 /* ---- spectrum (Plotting.py:376,462; gui.py:611-631) --------------------------- */
 int  pysdr_spectrum_create(int device, int chunk_size, int nfft, int max_frames,
                            const float* window, pysdr_spectrum** out);

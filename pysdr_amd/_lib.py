@@ -62,6 +62,7 @@ PROTOTYPES = {
     "pysdr_set_tile": (_i, [_vp, _i, _i]),
     "pysdr_quad_mixer": (_i, [_i, _pf, _pf, _sz, _u32, _u32, C.POINTER(_u32)]),
     "pysdr_freq_word": (_u32, [_d, _d, _pd]),
+    "pysdr_fir_real": (_i, [_i, _pf, _pf, _i, _pf, _sz]),
     "pysdr_spectrum_create": (_i, [_i, _i, _i, _i, _pf, C.POINTER(_vp)]),
     "pysdr_spectrum_destroy": (None, [_vp]),
     "pysdr_spectrum_frame": (_i, [_vp, _pf, _i, _i, _pf, _pi]),

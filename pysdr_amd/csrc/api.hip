@@ -666,6 +666,29 @@ int pysdr_quad_mixer(int device, const float* x, float* y, size_t n, uint32_t ph
   return rc;
 }
 
+// ---------------------------------------------------------------- convolver
+int pysdr_fir_real(int device, const float* xx, const float* h, int ntaps, float* y, size_t n) {
+  if (!xx || !h || !y || ntaps < 1) return PYSDR_ERR_ARG;
+  if (n == 0) return PYSDR_OK;
+  int rc = use_device(device);
+  if (rc) return rc;
+  const size_t nin = n + (size_t)ntaps - 1;
+  float *dx = nullptr, *dh = nullptr, *dy = nullptr;
+  hipError_t e = hipMalloc(&dx, nin * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&dh, (size_t)ntaps * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&dy, n * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(dx, xx, nin * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dh, h, (size_t)ntaps * sizeof(float), hipMemcpyHostToDevice);
+  rc = PYSDR_OK;
+  if (e == hipSuccess) rc = launch_fir_real(dx, dh, ntaps, dy, (int)n, nullptr);
+  if (e == hipSuccess && rc == PYSDR_OK) e = hipMemcpy(y, dy, n * sizeof(float), hipMemcpyDeviceToHost);
+  if (dx) (void)hipFree(dx);
+  if (dh) (void)hipFree(dh);
+  if (dy) (void)hipFree(dy);
+  if (e != hipSuccess) { set_last_error("pysdr_fir_real: %s", hipGetErrorString(e)); return PYSDR_ERR_HIP; }
+  return rc;
+}
+
 // ---------------------------------------------------------------- spectrum
 static int get_plan(pysdr_spectrum* sp, int batch, rocfft_plan* out) {
   auto it = sp->plans.find(batch);

@@ -104,6 +104,7 @@ int launch_epilogue(const EpilogueArgs& a, hipStream_t st);
 // ---- misc kernels (misc.hip) ---------------------------------------------------------
 int launch_quad_mixer(const float2* x, float2* y, size_t n, uint32_t phase0, uint32_t fword,
                       hipStream_t st);
+int launch_fir_real(const float* xx, const float* h, int nt, float* y, int n, hipStream_t st);
 int launch_psd_pre(const float2* x, size_t hop, int nframes, int chunk, int nfft,
                    const float* win, float2* work, int is_complex, hipStream_t st);
 int launch_psd_post(const float2* work, int nframes, int nfft, int half, int db, float* out,

@@ -37,6 +37,20 @@ __global__ __launch_bounds__(256) void quad_mixer_kernel(const float2* __restric
   }
 }
 
+// convolver.convolve_fast (receiver.py:207,216,862): y[i] = sum_k h[k] * xx[i + nt-1 - k],
+// xx = [history (nt-1) | new samples].  Audio-rate data (1024 samples per call): one output
+// per lane, taps through the scalar cache, input from L2.
+__global__ __launch_bounds__(256) void fir_real_kernel(const float* __restrict__ xx,
+                                                       const float* __restrict__ h, int nt,
+                                                       float* __restrict__ y, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* p = xx + i + (nt - 1);
+  float acc = 0.f;
+  for (int k = 0; k < nt; ++k) acc = fmaf(h[k], p[-k], acc);
+  y[i] = acc;
+}
+
 // work[f][i] = x[f*hop + i]*win[i] (i < chunk), 0 (chunk <= i < nfft)
 __global__ __launch_bounds__(256) void psd_pre_kernel(const float2* __restrict__ xc,
                                                       const float* __restrict__ xr, size_t hop,
@@ -86,6 +100,13 @@ int launch_quad_mixer(const float2* x, float2* y, size_t n, uint32_t phase0, uin
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(quad_mixer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, n, phase0,
                      fword);
+  PYSDR_HIP_CHECK(hipGetLastError());
+  return PYSDR_OK;
+}
+
+int launch_fir_real(const float* xx, const float* h, int nt, float* y, int n, hipStream_t st) {
+  if (n <= 0) return PYSDR_OK;
+  hipLaunchKernelGGL(fir_real_kernel, dim3((n + 255) / 256), dim3(256), 0, st, xx, h, nt, y, n);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }

@@ -438,6 +438,38 @@ class spectrum:
 
 
 # ----------------------------------------------------------------------------------------
+class convolver:
+    """``dsp.convolver(h, dtype)`` with ``convolve_fast(x)`` (``receiver.py:207,216,862``):
+    streaming FIR with carried state (the aux-audio band-pass).  Complex input is filtered
+    as two real streams."""
+
+    def __init__(self, h, dtype=np.float32, device=0):
+        self.h = np.ascontiguousarray(h, np.float32)
+        self.dtype = dtype
+        self.device = device
+        self._hist = np.zeros(len(self.h) - 1, np.complex64)
+
+    def _run(self, xx):
+        n = len(xx) - (len(self.h) - 1)
+        y = np.empty(n, np.float32)
+        xx = np.ascontiguousarray(xx, np.float32)
+        check(_lib.lib().pysdr_fir_real(self.device, _lib.as_pf(xx), _lib.as_pf(self.h), len(self.h),
+                                        _lib.as_pf(y), n), "pysdr_fir_real")
+        return y
+
+    def convolve_fast(self, x):
+        _lib.require_gpu()
+        x = np.asarray(x)
+        if len(x) == 0:
+            return x.astype(np.float32)
+        buf = np.concatenate((self._hist, x.astype(np.complex64)))
+        self._hist = buf[len(buf) - (len(self.h) - 1):]
+        if np.iscomplexobj(x):
+            return (self._run(buf.real) + 1j * self._run(buf.imag)).astype(np.complex64)
+        return self._run(buf.real)
+
+
+# ----------------------------------------------------------------------------------------
 class ring_buffer2:
     """Thread-safe sample FIFO between the RX thread and audio/PSD consumers
     (``pySDR.py:103-109``; ``receiver.py:72,848``).  Pure plumbing, no arithmetic.

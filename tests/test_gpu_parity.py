@@ -239,3 +239,20 @@ def test_spectrum_periodogram(chunk, nfft, overlap):
     assert len(pr) == nfft // 2
     strong = pw > pw.max() - 60.0
     assert np.max(np.abs(pr[strong] - pw[strong])) < 0.01
+
+
+def test_convolver_streaming_fir_matches_scipy():
+    """dsp.convolver(bpf(800,1300,FS_OUT,1001), float32).convolve_fast (receiver.py:861-862,216)"""
+    from scipy import signal
+    from pysdr_amd import sig_proc
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal(5 * 1024).astype(np.float32)
+    h = sig_proc.bpf(800., 1300., 48000, 1001)
+    assert np.allclose(h, so.bpf(800., 1300., 48000, 1001))
+    cv = sig_proc.convolver(h, np.float32)
+    got = np.concatenate([cv.convolve_fast(x[i:i + 1024]) for i in range(0, len(x), 1024)])
+    want = signal.lfilter(h, [1.0], x.astype(np.float64))
+    assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+    z = (x[:2048] + 1j * x[2048:4096]).astype(np.complex64)
+    cz = sig_proc.convolver(h, np.float32).convolve_fast(z)
+    assert np.max(np.abs(cz - signal.lfilter(h, [1.0], z.astype(np.complex128)))) <= TOL * np.max(np.abs(want))
