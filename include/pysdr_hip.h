@@ -104,6 +104,12 @@ int pysdr_set_dec_taps(pysdr_ctx* ctx, int irx, const double* h, int n);
 /* P.MODE / P.AF_FILTER_NUM / P.BFO as read by Receiver each chunk
  * (receiver.py:114-116,130-131; gui.py:1756-1757) */
 int pysdr_set_mode(pysdr_ctx* ctx, int irx, int mode, const double* af, int n, double bfo);
+/* Broadcast FM (modes WFM/WFM2; gui.py:1703-1704 `rx.demod.wfm_video.h = wfm_filter_bank[idx]`):
+ * video = pre-detection low-pass at SRATE (ntaps_dec doubles); resamp = prototype of the
+ * fs1 -> FS_OUT resampler (a multiple of up2 doubles).  pysdr_wfm_params gives the IF
+ * decimation d1 (fs1 = SRATE/d1 ~ 250 kHz) and up2/down2 = up_dn(fs1, FS_OUT). */
+int pysdr_wfm_params(double srate, double fs_out, int* d1, int* up2, int* down2);
+int pysdr_set_wfm_taps(pysdr_ctx* ctx, int irx, const double* video, int nv, const double* resamp, int nr);
 /* rx.agc.reset() / rx.demod.am_pll.reset() (receiver.py:648-649): what = 1 AGC, 2 PLL, 3 both */
 int pysdr_reset(pysdr_ctx* ctx, int irx, unsigned what);
 int pysdr_agc_get(pysdr_ctx* ctx, int irx, pysdr_agc_state* st);

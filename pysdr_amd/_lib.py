@@ -50,6 +50,8 @@ PROTOTYPES = {
     "pysdr_set_lo": (_i, [_vp, _i, _d, _pd]),
     "pysdr_set_dec_taps": (_i, [_vp, _i, _pd, _i]),
     "pysdr_set_mode": (_i, [_vp, _i, _i, _pd, _i, _d]),
+    "pysdr_wfm_params": (_i, [_d, _d, _pi, _pi, _pi]),
+    "pysdr_set_wfm_taps": (_i, [_vp, _i, _pd, _i, _pd, _i]),
     "pysdr_reset": (_i, [_vp, _i, C.c_uint]),
     "pysdr_agc_get": (_i, [_vp, _i, C.POINTER(AgcState)]),
     "pysdr_set_agc": (_i, [_vp, _i, _i, _f]),

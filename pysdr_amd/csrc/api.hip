@@ -6,6 +6,7 @@
 #include <rocfft/rocfft.h>
 
 #include <cmath>
+#include <algorithm>
 #include <cstdarg>
 #include <map>
 
@@ -46,6 +47,18 @@ inline int mode_detector(int m) {
   }
 }
 
+// One polyphase decimator instance (mixdec kernel): geometry, raw-sample history (double
+// buffered), LO-modulated taps on the device, absolute input counter.
+struct Decim {
+  int up = 1, down = 1, ntaps = 0, kdec = 0, kpad = 0, hist_len = 0, max_rx = 0;
+  float2* d_hist[2] = {nullptr, nullptr};
+  int hist_cur = 0;
+  float2* d_taps = nullptr;            // [max_rx][up][kpad]
+  std::vector<float2> h_taps;
+  unsigned long long s_abs = 0;        // absolute index of the next input sample
+  size_t per() const { return (size_t)up * kpad; }
+};
+
 struct RxHost {
   int mode = PYSDR_AM;
   double lo_freq = 0;
@@ -64,6 +77,13 @@ struct RxHost {
   float* d_am = nullptr;        // [2*mmax]
   float2* d_aftaps = nullptr;   // [ntaps_af rounded up to 4], zero padded
   int taps_real = 0;
+  // broadcast FM (WFM / WFM2)
+  std::vector<double> wfm_video;   // pre-detection filter at SRATE (ntaps_dec)
+  std::vector<double> wfm_resamp;  // fs1 -> FS_OUT prototype (up2 * taps per phase)
+  bool wfm_dirty = true;
+  Decim wfm_audio;                 // per-RX resampler fs1 -> FS_OUT
+  float2* d_y1 = nullptr;          // [2 + m1max] IF-rate IQ (1-sample history in slot 1)
+  float2* d_w = nullptr;           // [m1max] composite * (1 + 2j sin 2theta)
 };
 
 }  // namespace
@@ -74,20 +94,20 @@ struct pysdr_ctx {
   RxHost rx[PYSDR_MAX_RX];
   std::mutex mu;
   hipStream_t stream = nullptr;
-  int kdec = 0, kpad = 0, hist_len = 0, hy = 0, mmax = 0;
+  int hy = 0, mmax = 0;
   size_t cap_samples = 0;
-  float2* d_hist[2] = {nullptr, nullptr};
-  int hist_cur = 0;
-  float2* d_taps = nullptr;      // [MAX_RX][up][kpad]
+  Decim main;                    // SRATE -> FS_OUT (UP/DOWN) for the narrow-band modes
+  Decim wfm_front;               // SRATE -> fs1 = SRATE/d1 for WFM/WFM2
+  int d1 = 0, up2 = 0, down2 = 0, m1max = 0;
+  int last_wfm = 0;              // the last call ran the broadcast-FM pipeline
   float2* d_stage = nullptr;
   size_t stage_cap = 0;
   unsigned* d_peak = nullptr;    // [max_chunks]
+  unsigned* d_peak_scratch = nullptr;  // [1] sink for decimators whose raw peak is not wanted
   unsigned* d_blkpeak = nullptr; // [MAX_RX][max_chunks]
   float* d_gain = nullptr;       // [MAX_RX][max_chunks]
   RxDevState* d_state = nullptr; // [MAX_RX]
-  unsigned long long s_abs = 0;  // absolute input sample index of the next call
   // last call
-  long long last_m0 = 0;
   int last_nout = 0, last_nchunks = 0;
   size_t last_chunk_len = 0;
   unsigned long long last_s0 = 0;
@@ -99,7 +119,6 @@ struct pysdr_ctx {
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
   hipEvent_t ev[kSlots][4] = {};
   unsigned long long ncalls = 0;
-  std::vector<float2> h_taps;
   // RCCL
   void* rccl_lib = nullptr;
   ncclComm_t comm = nullptr;
@@ -134,33 +153,171 @@ int use_device(int dev) {
 }
 
 // g[p][k] = h[p + up*k] * exp(-j*w*k), w = 2*pi*fword/2^32
-void build_taps(const pysdr_ctx* c, const RxHost& r, float2* out) {
-  const int up = c->cfg.up, kpad = c->kpad, nt = c->cfg.ntaps_dec;
-  for (int p = 0; p < up; ++p) {
-    for (int k = 0; k < kpad; ++k) {
-      const int j = p + up * k;
+void build_taps(const Decim& d, const double* h, int nt, uint32_t fword, float2* out) {
+  for (int p = 0; p < d.up; ++p) {
+    for (int k = 0; k < d.kpad; ++k) {
+      const int j = p + d.up * k;
       float2 g = make_float2(0.f, 0.f);
       if (j < nt) {
-        const uint32_t ph = (uint32_t)((uint64_t)r.fword * (uint64_t)k);   // mod 2^32
+        const uint32_t ph = (uint32_t)((uint64_t)fword * (uint64_t)k);   // mod 2^32
         const double ang = -2.0 * M_PI * ((double)(int32_t)ph / kTwo32);
-        g.x = (float)(r.h[j] * std::cos(ang));
-        g.y = (float)(r.h[j] * std::sin(ang));
+        g.x = (float)(h[j] * std::cos(ang));
+        g.y = (float)(h[j] * std::sin(ang));
       }
-      out[(size_t)p * kpad + k] = g;
+      out[(size_t)p * d.kpad + k] = g;
     }
   }
 }
 
+int decim_init(Decim& d, int up, int down, int ntaps, int max_rx) {
+  d.up = up; d.down = down; d.ntaps = ntaps; d.max_rx = max_rx;
+  d.kdec = (ntaps + up - 1) / up;
+  d.kpad = (d.kdec + 15) / 16 * 16;
+  d.hist_len = d.kpad + 2;
+  d.h_taps.assign((size_t)max_rx * d.per(), make_float2(0.f, 0.f));
+  for (int i = 0; i < 2; ++i) {
+    PYSDR_HIP_CHECK(hipMalloc(&d.d_hist[i], d.hist_len * sizeof(float2)));
+    PYSDR_HIP_CHECK(hipMemset(d.d_hist[i], 0, d.hist_len * sizeof(float2)));
+  }
+  PYSDR_HIP_CHECK(hipMalloc(&d.d_taps, (size_t)max_rx * d.per() * sizeof(float2)));
+  PYSDR_HIP_CHECK(hipMemset(d.d_taps, 0, (size_t)max_rx * d.per() * sizeof(float2)));
+  return PYSDR_OK;
+}
+
+void decim_free(Decim& d) {
+  for (int i = 0; i < 2; ++i) if (d.d_hist[i]) { (void)hipFree(d.d_hist[i]); d.d_hist[i] = nullptr; }
+  if (d.d_taps) { (void)hipFree(d.d_taps); d.d_taps = nullptr; }
+}
+
+int decim_upload_taps(pysdr_ctx* c, Decim& d, int slot, const double* h, int nt, uint32_t fword) {
+  float2* dst = d.h_taps.data() + (size_t)slot * d.per();
+  build_taps(d, h, nt, fword, dst);
+  PYSDR_HIP_CHECK(hipMemcpyAsync(d.d_taps + (size_t)slot * d.per(), dst, d.per() * sizeof(float2),
+                                 hipMemcpyHostToDevice, c->stream));
+  return PYSDR_OK;
+}
+
+// The divisor of SRATE whose quotient is closest to 250 kHz
+int wfm_if_decim(double srate) {
+  const long long sr = (long long)std::llround(srate);
+  long long best = 1;
+  double bd = -1.0;
+  const long long lim = std::max<long long>(2, sr / 100000);
+  for (long long d = 1; d <= lim; ++d) {
+    if (sr % d) continue;
+    const double err = std::fabs((double)sr / (double)d - 250e3);
+    if (bd < 0 || err < bd) { best = d; bd = err; }
+  }
+  return (int)best;
+}
+
+inline bool is_wfm(int m) { return m == PYSDR_WFM || m == PYSDR_WFM2; }
+
+// One launch of the fused mix+decimate kernel on `nrx` receivers that share `d`.
+struct DecimResult { int n_out; uint32_t t0; unsigned long long m0; };
+int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, float2* const* y,
+              const uint32_t* phase0, const uint32_t* fword, unsigned* peak, size_t chunk_len,
+              int y_cap, DecimResult* res) {
+  const int up = d.up, down = d.down;
+  const unsigned long long s0 = d.s_abs, s1 = s0 + n;
+  const unsigned long long m0 = (s0 * up + down - 1) / down, m1 = (s1 * up + down - 1) / down;
+  const int n_out = (int)(m1 - m0);
+  if (n_out > y_cap) { set_last_error("decimator: n_out %d > capacity %d", n_out, y_cap); return PYSDR_ERR_STATE; }
+  if ((double)n * up + down >= 4294967295.0) { set_last_error("decimator: call too long for 32-bit indices"); return PYSDR_ERR_ARG; }
+  MixDecArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = d_x;
+  a.hist = d.d_hist[d.hist_cur];
+  a.hist_len = d.hist_len;
+  a.aligned16 = ((reinterpret_cast<uintptr_t>(d_x) & 15u) == 0) ? 1 : 0;
+  a.n_total = (uint32_t)n;
+  a.t0 = (uint32_t)(m0 * down - s0 * up);
+  a.n_out = n_out;
+  a.up = up; a.down = down;
+  a.kpad = d.kpad;
+  a.magic = (up == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned)up) + 1u;
+  a.nrx = nrx;
+  const int ratio = (down + up - 1) / up;
+  const size_t taps_bytes = (size_t)nrx * up * d.kpad * sizeof(float2);
+  // two tile buffers + the taps must fit the LDS share of one workgroup
+  int wgs = c->wgs_per_cu;
+  { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) wgs = atoi(e); }
+  const long lds_share = (160L * 1024) / wgs - 512;
+  long cap = c->tile_bytes / (long)sizeof(float2);
+  if (2 * cap * (long)sizeof(float2) + (long)taps_bytes > lds_share)
+    cap = (lds_share - (long)taps_bytes) / (2 * (long)sizeof(float2));
+  long tile_out = ((cap - d.kpad - 2L * ratio - 8) * up) / down;
+  if (tile_out >= 4L * up) tile_out -= tile_out % (4L * up);   // whole quads of every polyphase branch
+  tile_out &= ~1L;
+  if (tile_out < 2) {
+    tile_out = 2;
+    cap = d.kpad + 2L * ratio + 8 + (2L * down + up - 1) / up + 2;
+    if (2 * (size_t)cap * sizeof(float2) + taps_bytes > 160 * 1024) {
+      set_last_error("decimator: filter (%d taps, %d rx, up %d) does not fit LDS", d.ntaps, nrx, up);
+      return PYSDR_ERR_ARG;
+    }
+  }
+  a.tile_out = (int)tile_out;
+  a.tile_cap = (int)((cap + 1) & ~1L);
+  a.ntiles = n_out > 0 ? (n_out + a.tile_out - 1) / a.tile_out : 1;
+  a.taps = d.d_taps;
+  for (int r = 0; r < nrx; ++r) { a.y[r] = y[r]; a.phase0[r] = phase0[r]; a.fword[r] = fword[r]; }
+  a.peak = peak ? peak : c->d_peak_scratch;
+  a.chunk_len = peak ? (uint32_t)chunk_len : (uint32_t)std::max<size_t>(n, 1);
+  a.magic_chunk = (a.chunk_len == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned long long)a.chunk_len) + 1u;
+  { const char* e = getenv("PYSDR_DEBUG_FLAGS"); a.dbg = e ? atoi(e) : 0; }
+  int rc = launch_mixdec(a, c->threads, c->num_cus * wgs, c->stream);
+  if (rc) return rc;
+  rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, c->stream);
+  if (rc) return rc;
+  d.hist_cur ^= 1;
+  d.s_abs = s1;
+  if (res) { res->n_out = n_out; res->t0 = a.t0; res->m0 = m0; }
+  return PYSDR_OK;
+}
+
+int wfm_setup(pysdr_ctx* c) {
+  if (c->d1) return PYSDR_OK;
+  c->d1 = wfm_if_decim(c->cfg.srate);
+  const double fs1 = c->cfg.srate / c->d1;
+  const long long a = (long long)std::llround(std::floor(c->cfg.srate * c->cfg.up / c->cfg.down));
+  const long long b = (long long)std::llround(fs1);
+  long long g = std::__gcd(a, b);
+  c->up2 = (int)(a / g);
+  c->down2 = (int)(b / g);
+  c->m1max = (int)(c->cap_samples / (size_t)c->d1) + 4;
+  return decim_init(c->wfm_front, 1, c->d1, c->cfg.ntaps_dec, PYSDR_MAX_RX);
+}
+
 int apply_pending(pysdr_ctx* c) {
   std::lock_guard<std::mutex> lk(c->mu);
-  const size_t per = (size_t)c->cfg.up * c->kpad;
   for (int r = 0; r < c->nrx; ++r) {
     RxHost& x = c->rx[r];
     if (x.taps_dirty) {
-      build_taps(c, x, c->h_taps.data() + r * per);
-      PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_taps + r * per, c->h_taps.data() + r * per,
-                                     per * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+      int rc = decim_upload_taps(c, c->main, r, x.h.data(), c->cfg.ntaps_dec, x.fword);
+      if (rc) return rc;
       x.taps_dirty = false;
+      x.wfm_dirty = true;             // the LO moved: the WFM front taps carry it too
+    }
+    if (is_wfm(x.mode) && x.wfm_dirty) {
+      if (x.wfm_video.empty() || x.wfm_resamp.empty()) {
+        set_last_error("rx %d is in WFM mode but pysdr_set_wfm_taps was never called", r);
+        return PYSDR_ERR_STATE;
+      }
+      int rc = wfm_setup(c);
+      if (rc) return rc;
+      if (!x.d_y1) {
+        PYSDR_HIP_CHECK(hipMalloc(&x.d_y1, ((size_t)c->m1max + 2) * sizeof(float2)));
+        PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y1, 0, ((size_t)c->m1max + 2) * sizeof(float2), c->stream));
+        PYSDR_HIP_CHECK(hipMalloc(&x.d_w, (size_t)c->m1max * sizeof(float2)));
+        rc = decim_init(x.wfm_audio, c->up2, c->down2, (int)x.wfm_resamp.size(), 1);
+        if (rc) return rc;
+      }
+      rc = decim_upload_taps(c, c->wfm_front, r, x.wfm_video.data(), c->cfg.ntaps_dec, x.fword);
+      if (rc) return rc;
+      rc = decim_upload_taps(c, x.wfm_audio, 0, x.wfm_resamp.data(), (int)x.wfm_resamp.size(), 0u);
+      if (rc) return rc;
+      x.wfm_dirty = false;
     }
     if (x.af_dirty) {
       std::vector<float2> t((c->cfg.ntaps_af + 3) & ~3, make_float2(0.f, 0.f));
@@ -179,7 +336,7 @@ int apply_pending(pysdr_ctx* c) {
       PYSDR_HIP_CHECK(hipMemcpyAsync(&st, c->d_state + r, sizeof(st), hipMemcpyDeviceToHost, c->stream));
       PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (x.reset_pending & 1u) { st.env = 0.f; st.gain = 1.f; st.maxbuf = 0.f; st.err = 0.f; }
-      if (x.reset_pending & 2u) { st.pll_theta = 0.f; st.pll_w = 0.f; }
+      if (x.reset_pending & 2u) { st.pll_theta = 0.f; st.pll_w = 0.f; st.wfm_phase = 0u; st.wfm_w = 0.f; }
       st.ref = x.agc_ref; st.agc_enable = x.agc_enable;
       PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_state + r, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
       PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -253,9 +410,6 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   if (rc) return rc;
   pysdr_ctx* c = new pysdr_ctx();
   c->cfg = *cfg;
-  c->kdec = (cfg->ntaps_dec + cfg->up - 1) / cfg->up;
-  c->kpad = (c->kdec + 15) / 16 * 16;
-  c->hist_len = c->kpad + 2;
   c->hy = (((cfg->ntaps_af + 3) & ~3) + 4 + 1) & ~1;   // FIR history (padded taps) + discriminator
   c->cap_samples = (size_t)cfg->max_chunks * (size_t)cfg->in_chunk;
   c->mmax = (int)((c->cap_samples * (size_t)cfg->up) / (size_t)cfg->down) + 4;
@@ -269,17 +423,12 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
     delete c;
     return PYSDR_ERR_ARG;
   }
-  const size_t per = (size_t)cfg->up * c->kpad;
-  c->h_taps.assign((size_t)PYSDR_MAX_RX * per, make_float2(0.f, 0.f));
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_error("pysdr_create: %s -> %s", #e, hipGetErrorString(_e)); pysdr_destroy(c); return PYSDR_ERR_HIP; } } while (0)
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (int i = 0; i < 2; ++i) {
-    CK(hipMalloc(&c->d_hist[i], c->hist_len * sizeof(float2)));
-    CK(hipMemset(c->d_hist[i], 0, c->hist_len * sizeof(float2)));
-  }
-  CK(hipMalloc(&c->d_taps, (size_t)PYSDR_MAX_RX * per * sizeof(float2)));
-  CK(hipMemset(c->d_taps, 0, (size_t)PYSDR_MAX_RX * per * sizeof(float2)));
+  rc = decim_init(c->main, cfg->up, cfg->down, cfg->ntaps_dec, PYSDR_MAX_RX);
+  if (rc) { pysdr_destroy(c); return rc; }
   CK(hipMalloc(&c->d_peak, (size_t)cfg->max_chunks * sizeof(unsigned)));
+  CK(hipMalloc(&c->d_peak_scratch, 64 * sizeof(unsigned)));
   CK(hipMalloc(&c->d_blkpeak, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
   CK(hipMemset(c->d_blkpeak, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
   CK(hipMalloc(&c->d_gain, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
@@ -304,11 +453,15 @@ void pysdr_destroy(pysdr_ctx* c) {
     if (x.d_a) (void)hipFree(x.d_a);
     if (x.d_am) (void)hipFree(x.d_am);
     if (x.d_aftaps) (void)hipFree(x.d_aftaps);
+    if (x.d_y1) (void)hipFree(x.d_y1);
+    if (x.d_w) (void)hipFree(x.d_w);
+    decim_free(x.wfm_audio);
   }
-  for (int i = 0; i < 2; ++i) if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
-  if (c->d_taps) (void)hipFree(c->d_taps);
+  decim_free(c->main);
+  decim_free(c->wfm_front);
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->d_peak) (void)hipFree(c->d_peak);
+  if (c->d_peak_scratch) (void)hipFree(c->d_peak_scratch);
   if (c->d_blkpeak) (void)hipFree(c->d_blkpeak);
   if (c->d_gain) (void)hipFree(c->d_gain);
   if (c->d_state) (void)hipFree(c->d_state);
@@ -458,6 +611,38 @@ int pysdr_sync(pysdr_ctx* c) {
   return PYSDR_OK;
 }
 
+int pysdr_wfm_params(double srate, double fs_out, int* d1, int* up2, int* down2) {
+  if (srate <= 0 || fs_out <= 0) return PYSDR_ERR_ARG;
+  const int d = wfm_if_decim(srate);
+  const long long a = (long long)std::llround(fs_out), b = (long long)std::llround(srate / d);
+  const long long g = std::__gcd(a, b);
+  if (d1) *d1 = d;
+  if (up2) *up2 = (int)(a / g);
+  if (down2) *down2 = (int)(b / g);
+  return PYSDR_OK;
+}
+
+int pysdr_set_wfm_taps(pysdr_ctx* c, int irx, const double* video, int nv, const double* resamp, int nr) {
+  if (!c || !video || !resamp || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  int d1 = 0, up2 = 0, down2 = 0;
+  pysdr_wfm_params(c->cfg.srate, std::floor(c->cfg.srate * c->cfg.up / c->cfg.down), &d1, &up2, &down2);
+  if (nv != c->cfg.ntaps_dec || nr < up2 || nr % up2) {
+    set_last_error("pysdr_set_wfm_taps: need %d video taps and a multiple of %d resampler taps (got %d, %d)",
+                   c->cfg.ntaps_dec, up2, nv, nr);
+    return PYSDR_ERR_ARG;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  RxHost& x = c->rx[irx];
+  if (!x.wfm_resamp.empty() && (int)x.wfm_resamp.size() != nr) {
+    set_last_error("pysdr_set_wfm_taps: resampler length cannot change (%zu -> %d)", x.wfm_resamp.size(), nr);
+    return PYSDR_ERR_ARG;
+  }
+  x.wfm_video.assign(video, video + nv);
+  x.wfm_resamp.assign(resamp, resamp + nr);
+  x.wfm_dirty = true;
+  return PYSDR_OK;
+}
+
 int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_len, int on_device) {
   if (!c || !iq || nchunks < 1 || chunk_len < 1) return PYSDR_ERR_ARG;
   if (c->nrx < 1) { set_last_error("pysdr_process_batch: no receivers"); return PYSDR_ERR_STATE; }
@@ -480,76 +665,82 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_stage, iq, n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
     d_x = c->d_stage;
   }
+  int nwfm = 0;
+  for (int r = 0; r < c->nrx; ++r) nwfm += is_wfm(c->rx[r].mode) ? 1 : 0;
+  if (nwfm != 0 && nwfm != c->nrx) {
+    // the reference's mode is global (P.MODE) and the rate-reduction order differs for
+    // broadcast FM (receiver.py:718-719): one context runs one pipeline
+    set_last_error("pysdr_process_batch: WFM/WFM2 cannot be mixed with narrow-band modes in one context");
+    return PYSDR_ERR_STATE;
+  }
+  const bool wfm = nwfm > 0;
   rc = apply_pending(c);
   if (rc) return rc;
 
   const int up = c->cfg.up, down = c->cfg.down;
-  const unsigned long long s0 = c->s_abs, s1 = s0 + n;
-  const unsigned long long m0 = (s0 * up + down - 1) / down, m1 = (s1 * up + down - 1) / down;
-  const int n_out = (int)(m1 - m0);
-  if (n_out > c->mmax) { set_last_error("pysdr_process_batch: n_out %d > capacity %d", n_out, c->mmax); return PYSDR_ERR_STATE; }
-  const uint32_t t0 = (uint32_t)(m0 * down - s0 * up);
-
+  const unsigned long long s0 = wfm ? c->wfm_front.s_abs : c->main.s_abs;
   PYSDR_HIP_CHECK(hipMemsetAsync(c->d_peak, 0, (size_t)nchunks * sizeof(unsigned), c->stream));
 
-  MixDecArgs a;
-  memset(&a, 0, sizeof(a));
-  a.x = d_x;
-  a.hist = c->d_hist[c->hist_cur];
-  a.hist_len = c->hist_len;
-  a.aligned16 = ((reinterpret_cast<uintptr_t>(d_x) & 15u) == 0) ? 1 : 0;
-  a.n_total = (uint32_t)n;
-  a.t0 = t0;
-  a.n_out = n_out;
-  a.up = up; a.down = down;
-  a.kpad = c->kpad;
-  a.magic = (up == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned)up) + 1u;
-  a.nrx = c->nrx;
-  const int ratio = (down + up - 1) / up;
-  const size_t taps_bytes = (size_t)c->nrx * up * c->kpad * sizeof(float2);
-  // two tile buffers + the taps must fit the LDS share of one workgroup
-  int wgs = c->wgs_per_cu;
-  { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) wgs = atoi(e); }
-  const long lds_share = (160L * 1024) / wgs - 512;
-  long cap = c->tile_bytes / (long)sizeof(float2);
-  if (2 * cap * (long)sizeof(float2) + (long)taps_bytes > lds_share)
-    cap = (lds_share - (long)taps_bytes) / (2 * (long)sizeof(float2));
-  long tile_out = ((cap - c->kpad - 2L * ratio - 8) * up) / down;
-  if (tile_out >= 4L * up) tile_out -= tile_out % (4L * up);   // whole quads of every polyphase branch
-  tile_out &= ~1L;
-  if (tile_out < 2) {
-    tile_out = 2;
-    cap = c->kpad + 2L * ratio + 8 + (2L * down + up - 1) / up + 2;
-    if (2 * (size_t)cap * sizeof(float2) + taps_bytes > 160 * 1024) {
-      set_last_error("pysdr_process_batch: filter (%d taps, %d rx) does not fit LDS", c->cfg.ntaps_dec, c->nrx);
-      return PYSDR_ERR_ARG;
-    }
-  }
-  a.tile_out = (int)tile_out;
-  a.tile_cap = (int)((cap + 1) & ~1L);
-  a.ntiles = n_out > 0 ? (n_out + a.tile_out - 1) / a.tile_out : 1;
-  a.taps = c->d_taps;
-  for (int r = 0; r < c->nrx; ++r) {
-    a.y[r] = c->rx[r].d_y + c->hy;
-    a.phase0[r] = c->rx[r].phase;
-    a.fword[r] = c->rx[r].fword;
-  }
-  a.peak = c->d_peak;
-  a.chunk_len = (uint32_t)chunk_len;
-  a.magic_chunk = (chunk_len == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned long long)chunk_len) + 1u;
-  { const char* e = getenv("PYSDR_DEBUG_FLAGS"); a.dbg = e ? atoi(e) : 0; }
+  float2* yptr[PYSDR_MAX_RX];
+  uint32_t ph[PYSDR_MAX_RX], fw[PYSDR_MAX_RX];
+  for (int r = 0; r < c->nrx; ++r) { ph[r] = c->rx[r].phase; fw[r] = c->rx[r].fword; }
 
   hipEvent_t* ev = c->ev[c->ncalls % pysdr_ctx::kSlots];
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[0], c->stream));
-  rc = launch_mixdec(a, c->threads, c->num_cus * wgs, c->stream);
-  if (rc) return rc;
+  DecimResult res;
+  int n1 = 0;
+  if (!wfm) {
+    for (int r = 0; r < c->nrx; ++r) yptr[r] = c->rx[r].d_y + c->hy;
+    rc = decim_run(c, c->main, d_x, n, c->nrx, yptr, ph, fw, c->d_peak, chunk_len, c->mmax, &res);
+    if (rc) return rc;
+    c->wfm_front.s_abs = c->main.s_abs;       // both pipelines count the same input stream
+  } else {
+    // SRATE -> fs1 (video filter, all RX in one launch), discriminator + pilot PLL at fs1,
+    // then each RX's own fs1 -> FS_OUT resampler
+    for (int r = 0; r < c->nrx; ++r) yptr[r] = c->rx[r].d_y1 + 2;
+    DecimResult r1;
+    rc = decim_run(c, c->wfm_front, d_x, n, c->nrx, yptr, ph, fw, c->d_peak, chunk_len, c->m1max, &r1);
+    if (rc) return rc;
+    c->main.s_abs = c->wfm_front.s_abs;
+    n1 = r1.n_out;
+    WfmArgs w;
+    memset(&w, 0, sizeof(w));
+    w.nrx = c->nrx; w.n1 = n1;
+    const double fs1 = c->cfg.srate / c->d1;
+    w.scale = (float)(fs1 / (2.0 * M_PI * 75e3));
+    {
+      const double wn = 2.0 * M_PI * 30.0 / fs1;
+      w.kp = (float)(2.0 * 0.7071 * wn);
+      w.ki = (float)(wn * wn);
+      w.norm = (float)(2.0 / 0.1);
+      w.rad2word = (float)(kTwo32 / (2.0 * M_PI));
+      w.fword0 = pysdr_freq_word(19000.0, fs1, nullptr);
+    }
+    for (int r = 0; r < c->nrx; ++r) {
+      w.y1[r] = c->rx[r].d_y1 + 2;
+      w.y1base[r] = c->rx[r].d_y1;
+      w.w[r] = c->rx[r].d_w;
+      w.stereo[r] = (c->rx[r].mode == PYSDR_WFM2) ? 1 : 0;
+    }
+    w.state = c->d_state;
+    rc = launch_wfm(w, c->stream);
+    if (rc) return rc;
+    const uint32_t zero = 0u;
+    for (int r = 0; r < c->nrx; ++r) {
+      float2* y1 = c->rx[r].d_y + c->hy;
+      rc = decim_run(c, c->rx[r].wfm_audio, c->rx[r].d_w, (size_t)n1, 1, &y1, &zero, &zero, nullptr, 0,
+                     c->mmax, &res);
+      if (rc) return rc;
+    }
+  }
+  const int n_out = res.n_out;
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[1], c->stream));
 
   Stage2Args s;
   memset(&s, 0, sizeof(s));
   s.nrx = c->nrx; s.n_out = n_out; s.ntaps = c->cfg.ntaps_af; s.hy = c->hy;
-  s.t0 = t0; s.up = up; s.down = down; s.chunk_len = (uint32_t)chunk_len; s.nchunks = nchunks;
-  s.m0_lo = (uint32_t)(m0 & 0xFFFFFFFFull);
+  s.t0 = res.t0; s.up = up; s.down = down; s.chunk_len = (uint32_t)chunk_len; s.nchunks = nchunks;
+  s.m0_lo = (uint32_t)(res.m0 & 0xFFFFFFFFull);
   const double fs_out = std::floor(c->cfg.srate * up / down);
   s.fm_scale = (float)(fs_out / (2.0 * M_PI * kNfmFullScaleDev));
   {
@@ -567,15 +758,19 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     s.a[r] = x.d_a;
     s.am[r] = x.d_am;
     s.det[r] = mode_detector(x.mode);
-    s.out_complex[r] = (x.mode == PYSDR_IQ) ? 1 : 0;
+    s.out_complex[r] = (x.mode == PYSDR_IQ || wfm) ? 1 : 0;
+    s.single_block[r] = wfm ? 1 : 0;
+    s.matrix[r] = (x.mode == PYSDR_WFM2) ? 1 : 0;
     s.bfo_fword[r] = x.bfo_fword;
-    c->last_complex[r] = s.out_complex[r];
+    c->last_complex[r] = (x.mode == PYSDR_IQ || x.mode == PYSDR_WFM2) ? 1 : 0;
     any_pll |= (s.det[r] == kDetPll);
   }
   s.blkpeak = c->d_blkpeak; s.gain = c->d_gain; s.state = c->d_state;
   if (any_pll && n_out > 0) { rc = launch_pll(s, c->stream); if (rc) return rc; }
   rc = launch_demod_fir(s, c->stream); if (rc) return rc;
   rc = launch_agc_scan(s, c->stream); if (rc) return rc;
+  // WFM (mono) emits the real part of the complex pipeline
+  for (int r = 0; r < c->nrx; ++r) if (c->rx[r].mode == PYSDR_WFM) s.out_complex[r] = 0;
   rc = launch_apply(s, c->stream); if (rc) return rc;
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[2], c->stream));
 
@@ -586,17 +781,13 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     e.ybase[r] = c->rx[r].d_y;
     e.ypllbase[r] = (s.det[r] == kDetPll) ? c->rx[r].d_ypll : nullptr;
   }
-  e.x = d_x; e.hist_old = c->d_hist[c->hist_cur]; e.hist_new = c->d_hist[c->hist_cur ^ 1];
-  e.hist_len = c->hist_len; e.n_total = (uint32_t)n;
   rc = launch_epilogue(e, c->stream); if (rc) return rc;
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[3], c->stream));
   c->ncalls++;
 
-  c->hist_cur ^= 1;
-  c->s_abs = s1;
   for (int r = 0; r < c->nrx; ++r) c->rx[r].phase += c->rx[r].fword * (uint32_t)n;
-  c->last_m0 = (long long)m0; c->last_nout = n_out; c->last_nchunks = nchunks;
-  c->last_chunk_len = chunk_len; c->last_s0 = s0;
+  c->last_nout = n_out; c->last_nchunks = nchunks;
+  c->last_chunk_len = chunk_len; c->last_s0 = s0; c->last_wfm = wfm ? 1 : 0;
   return PYSDR_OK;
 }
 
@@ -619,11 +810,18 @@ int pysdr_fetch(pysdr_ctx* c, int irx, float* am, float* iq, int cap, int* n_out
   if (n_out) *n_out = n;
   if (am_is_complex) *am_is_complex = cx;
   if (chunk_nout) {
-    const unsigned long long up = c->cfg.up, down = c->cfg.down;
+    // outputs whose newest input sample falls into chunk k (a two-level cascade for WFM)
+    auto first_out = [&](unsigned long long s) -> unsigned long long {
+      if (!c->last_wfm) {
+        const unsigned long long up = c->cfg.up, down = c->cfg.down;
+        return (s * up + down - 1) / down;
+      }
+      const unsigned long long m1 = (s + c->d1 - 1) / (unsigned long long)c->d1;
+      return (m1 * (unsigned long long)c->up2 + c->down2 - 1) / (unsigned long long)c->down2;
+    };
     for (int k = 0; k < c->last_nchunks; ++k) {
       const unsigned long long a0 = c->last_s0 + (unsigned long long)k * c->last_chunk_len;
-      const unsigned long long a1 = a0 + c->last_chunk_len;
-      chunk_nout[k] = (int)((a1 * up + down - 1) / down - (a0 * up + down - 1) / down);
+      chunk_nout[k] = (int)(first_out(a0 + c->last_chunk_len) - first_out(a0));
     }
   }
   return PYSDR_OK;

@@ -66,7 +66,9 @@ size_t mixdec_lds_bytes(const MixDecArgs& a);
 struct RxDevState {       // one per RX, lives in device memory
   float env, gain, maxbuf, err, ref;
   int agc_enable;
-  float pll_theta, pll_w;
+  float pll_theta, pll_w;   // AM-Synch carrier PLL
+  uint32_t wfm_phase;       // WFM2 pilot PLL: 32-bit phase accumulator
+  float wfm_w;              //                 loop integrator (rad/sample)
 };
 
 struct Stage2Args {
@@ -84,6 +86,8 @@ struct Stage2Args {
   int det[PYSDR_MAX_RX];
   int out_complex[PYSDR_MAX_RX];
   uint32_t bfo_fword[PYSDR_MAX_RX];
+  int single_block[PYSDR_MAX_RX];     // WFM: no AGC blocks, the whole call is block 0
+  int matrix[PYSDR_MAX_RX];           // WFM2: (S, D) -> (S+D) + j(S-D) = L + jR
   unsigned* blkpeak;                  // [nrx][nchunks] float bits
   float* gain;                        // [nrx][nchunks]
   RxDevState* state;                  // [nrx]
@@ -97,9 +101,25 @@ struct EpilogueArgs {
   int nrx, n_out, hy;
   float2* ybase[PYSDR_MAX_RX];        // buffer start (prefix at [0,hy))
   float2* ypllbase[PYSDR_MAX_RX];     // may be null
-  const float2* x; const float2* hist_old; float2* hist_new; int hist_len; uint32_t n_total;
 };
 int launch_epilogue(const EpilogueArgs& a, hipStream_t st);
+// new history = last hist_len samples of [old history | x[0..n)]
+int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len,
+                     uint32_t n_total, hipStream_t st);
+
+// ---- broadcast FM (WFM / WFM2) at the IF rate fs1 (stage2.hip) -------------------------
+struct WfmArgs {
+  int nrx, n1;                        // IF-rate samples of this call
+  float scale;                        // fs1 / (2*pi*75 kHz)
+  float kp, ki, norm, rad2word;       // pilot PLL constants
+  uint32_t fword0;                    // 19 kHz at fs1
+  const float2* y1[PYSDR_MAX_RX];     // IF IQ, element 0 = first new sample (1-sample prefix)
+  float2* y1base[PYSDR_MAX_RX];       // buffer start (for the prefix roll)
+  float2* w[PYSDR_MAX_RX];            // out: mpx*(1 + 2j*sin(2*theta)) (WFM: imag 0)
+  int stereo[PYSDR_MAX_RX];
+  RxDevState* state;
+};
+int launch_wfm(const WfmArgs& a, hipStream_t st);
 
 // ---- misc kernels (misc.hip) ---------------------------------------------------------
 int launch_quad_mixer(const float2* x, float2* y, size_t n, uint32_t phase0, uint32_t fword,

@@ -14,7 +14,8 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 }
 
 // chunk (AGC block) that output i belongs to: the chunk holding its newest input sample
-__device__ __forceinline__ uint32_t block_of(const Stage2Args& a, int i) {
+__device__ __forceinline__ uint32_t block_of(const Stage2Args& a, int r, int i) {
+  if (a.single_block[r]) return 0u;
   const uint32_t t = a.t0 + (uint32_t)i * (uint32_t)a.down;
   return (t / (uint32_t)a.up) / a.chunk_len;
 }
@@ -162,15 +163,15 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   uint32_t blk_lo = 0xFFFFFFFFu, blk_hi = 0xFFFFFFFFu;
   if (ib < a.n_out) {
     const int last = (ib + 3 < a.n_out) ? ib + 3 : a.n_out - 1;
-    blk_lo = block_of(a, ib);
-    blk_hi = block_of(a, last);
+    blk_lo = block_of(a, r, ib);
+    blk_hi = block_of(a, r, last);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (ib + j < a.n_out) {
         a.a[r][ib + j] = acc[j];
         const float m = a.out_complex[r] ? sqrtf(acc[j].x * acc[j].x + acc[j].y * acc[j].y) : fabsf(acc[j].x);
         if (blk_lo == blk_hi) mag = fmaxf(mag, m);
-        else atomicMax(a.blkpeak + (size_t)r * a.nchunks + block_of(a, ib + j), __float_as_uint(m));
+        else atomicMax(a.blkpeak + (size_t)r * a.nchunks + block_of(a, r, ib + j), __float_as_uint(m));
       }
   }
   // block peak: one atomic per wave when the whole wave sits inside one block
@@ -236,34 +237,77 @@ __global__ __launch_bounds__(256) void apply_kernel(const Stage2Args a) {
   const int r = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_out) return;
-  const float g = a.gain[(size_t)r * a.nchunks + block_of(a, i)];
+  const float g = a.gain[(size_t)r * a.nchunks + block_of(a, r, i)];
   const float2 v = a.a[r][i];
-  if (a.out_complex[r]) {
+  if (a.matrix[r]) {
+    reinterpret_cast<float2*>(a.am[r])[i] = make_float2((v.x + v.y) * g, (v.x - v.y) * g);
+  } else if (a.out_complex[r]) {
     reinterpret_cast<float2*>(a.am[r])[i] = make_float2(v.x * g, v.y * g);
   } else {
     a.am[r][i] = v.x * g;
   }
 }
 
-// ---- history roll: y prefix <- last hy outputs, x history <- last hist_len samples.
-// One workgroup per job so overlapping source/destination ranges are safe.
+// ---- history roll of the FS_OUT-rate buffers: prefix <- last hy outputs.  One workgroup
+// per buffer so overlapping source/destination ranges are safe.
 __global__ __launch_bounds__(256) void epilogue_kernel(const EpilogueArgs a) {
   const int job = blockIdx.x;
   const int tid = threadIdx.x;
-  if (job < 2 * a.nrx) {
-    float2* base = (job < a.nrx) ? a.ybase[job] : a.ypllbase[job - a.nrx];
-    if (base == nullptr) return;
-    // element j of the new prefix = old element n_out + j  (prefix occupies [0,hy))
-    __shared__ float2 sh[4096];
-    for (int j = tid; j < a.hy; j += 256) sh[j] = base[a.n_out + j];
-    __syncthreads();
-    for (int j = tid; j < a.hy; j += 256) base[j] = sh[j];
-  } else {
-    for (int j = tid; j < a.hist_len; j += 256) {
-      const long long rel = (long long)a.n_total - a.hist_len + j;
-      a.hist_new[j] = (rel >= 0) ? a.x[rel] : a.hist_old[a.hist_len + rel];
-    }
+  float2* base = (job < a.nrx) ? a.ybase[job] : a.ypllbase[job - a.nrx];
+  if (base == nullptr) return;
+  // element j of the new prefix = old element n_out + j  (prefix occupies [0,hy))
+  __shared__ float2 sh[4096];
+  for (int j = tid; j < a.hy; j += 256) sh[j] = base[a.n_out + j];
+  __syncthreads();
+  for (int j = tid; j < a.hy; j += 256) base[j] = sh[j];
+}
+
+// ---- raw-sample history of a decimator: new = last hist_len samples of [old | x]
+__global__ __launch_bounds__(256) void hist_roll_kernel(const float2* __restrict__ x,
+                                                        const float2* __restrict__ hist_old,
+                                                        float2* __restrict__ hist_new, int hist_len,
+                                                        uint32_t n_total) {
+  for (int j = threadIdx.x; j < hist_len; j += 256) {
+    const long long rel = (long long)n_total - hist_len + j;
+    hist_new[j] = (rel >= 0) ? x[rel] : hist_old[hist_len + rel];
   }
+}
+
+// ---- broadcast FM at the IF rate: polar discriminator (all lanes), then the 19 kHz pilot
+// PLL of WFM2 -- inherently serial, one lane per RX, on a 32-bit phase accumulator.
+__global__ __launch_bounds__(256) void wfm_disc_kernel(const WfmArgs a) {
+  const int r = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n1) return;
+  const float2 yb = a.y1[r][i], ya = a.y1[r][i - 1];
+  const float re = yb.x * ya.x + yb.y * ya.y;
+  const float im = yb.y * ya.x - yb.x * ya.y;
+  a.w[r][i] = make_float2(atan2f(im, re) * a.scale, 0.f);
+}
+
+__global__ void wfm_pll_kernel(const WfmArgs a) {
+  const int r = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  // roll the 1-sample IF history for the next call (disc kernel is done: same stream)
+  if (a.n1 > 0) a.y1base[r][1] = a.y1[r][a.n1 - 1];
+  if (!a.stereo[r]) return;
+  RxDevState* st = a.state + r;
+  uint32_t ph = st->wfm_phase;
+  float w = st->wfm_w;
+  float2* o = a.w[r];
+  for (int i = 0; i < a.n1; ++i) {
+    const float m = o[i].x;
+    const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+    const float c = cospif(2.f * rev);        // exact argument scaling: 2*rev, 4*rev are exact
+    const float s2 = sinpif(4.f * rev);
+    const float e = __fmul_rn(__fmul_rn(m, c), a.norm);
+    o[i] = make_float2(m, __fmul_rn(m, __fmul_rn(2.f, s2)));
+    w = __fadd_rn(w, __fmul_rn(a.ki, e));
+    const int corr = __float2int_rn(__fmul_rn(__fadd_rn(w, __fmul_rn(a.kp, e)), a.rad2word));
+    ph = ph + a.fword0 + (uint32_t)corr;
+  }
+  st->wfm_phase = ph;
+  st->wfm_w = w;
 }
 
 }  // namespace
@@ -303,7 +347,24 @@ int launch_epilogue(const EpilogueArgs& a, hipStream_t st) {
     set_last_error("epilogue: history %d too long", a.hy);
     return PYSDR_ERR_ARG;
   }
-  hipLaunchKernelGGL(epilogue_kernel, dim3(2 * a.nrx + 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(epilogue_kernel, dim3(2 * a.nrx), dim3(256), 0, st, a);
+  PYSDR_HIP_CHECK(hipGetLastError());
+  return PYSDR_OK;
+}
+
+int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len,
+                     uint32_t n_total, hipStream_t st) {
+  hipLaunchKernelGGL(hist_roll_kernel, dim3(1), dim3(256), 0, st, x, hist_old, hist_new, hist_len, n_total);
+  PYSDR_HIP_CHECK(hipGetLastError());
+  return PYSDR_OK;
+}
+
+int launch_wfm(const WfmArgs& a, hipStream_t st) {
+  if (a.n1 > 0) {
+    hipLaunchKernelGGL(wfm_disc_kernel, dim3((a.n1 + 255) / 256, a.nrx), dim3(256), 0, st, a);
+    PYSDR_HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(wfm_pll_kernel, dim3(a.nrx), dim3(64), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }

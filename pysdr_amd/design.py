@@ -75,3 +75,40 @@ def psd_window(n, beta=8.6):
     """Kaiser(8.6) as in ``rtty.py`` (pin P5), scaled to unit coherent gain."""
     w = np.kaiser(n, beta)
     return w / np.sum(w)
+
+
+# ---- broadcast FM (modes WFM / WFM2), DESIGN.md 3.10 ------------------------------------
+WFM_DEEMPH_TAU = 75e-6
+WFM_DEEMPH_TAPS = 96
+WFM_AUDIO_CUT = 15e3
+WFM_RESAMP_CUT = 19.5e3
+WFM_RESAMP_TAPS_PER_PHASE = 64
+
+
+def wfm_video_bank(srate, fs1, ntaps, video_bw_other=200e3, labels=VIDEO_BWs):
+    """``rx.demod.wfm_filter_bank`` (``gui.py:1704``): pre-detection low-pass at SRATE, one
+    per VIDEO_BWs label, clamped to 0.45*fs1 (the IF rate after the integer decimation)."""
+    widest = NYQ_FRACTION * fs1
+    rows = []
+    for lab in labels:
+        hz = label_hz(lab)
+        cut = widest if lab == 'Max' else (0.5 * video_bw_other if lab == 'Other' else 0.5 * hz)
+        rows.append(firwin(ntaps, min(cut, widest), window='hamming', fs=float(srate)))
+    return np.asarray(rows, np.float64)
+
+
+def wfm_resampler_taps(fs1, up2):
+    """Prototype of the fs1 -> FS_OUT rational resampler (designed at fs1*up2, gain up2)."""
+    return up2 * firwin(up2 * WFM_RESAMP_TAPS_PER_PHASE, WFM_RESAMP_CUT, window='hamming',
+                        fs=float(fs1) * up2)
+
+
+def wfm_af_taps(fs_out, ntaps, af_bw=0.0):
+    """15 kHz audio low-pass convolved with the 75 us de-emphasis: the one-pole IIR
+    y = (1-b)*x + b*y[-1], b = exp(-1/(fs*tau)), as its impulse response truncated after 96
+    taps (b^96 = 2.5e-12, below float32 resolution)."""
+    cut = af_bw if 0 < af_bw <= WFM_AUDIO_CUT else WFM_AUDIO_CUT
+    b = np.exp(-1.0 / (fs_out * WFM_DEEMPH_TAU))
+    de = (1.0 - b) * b ** np.arange(WFM_DEEMPH_TAPS)
+    lp = firwin(ntaps - WFM_DEEMPH_TAPS + 1, cut, window='hamming', fs=float(fs_out))
+    return np.convolve(lp, de)

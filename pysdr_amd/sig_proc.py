@@ -29,7 +29,7 @@ from .tables import index_of_bw, label_hz
 
 bpf = design.bpf
 
-_UNSUPPORTED_ON_DEVICE = ("WFM", "WFM2")
+_WFM_MODES = ("WFM", "WFM2")
 
 
 def _device_of(P):
@@ -223,13 +223,44 @@ class _PLLHandle:
         check(self._rx._ctx.L.pysdr_reset(self._rx._ctx.h, self._rx.irx, 2), "pysdr_reset")
 
 
+class _WfmVideo:
+    """``rx.demod.wfm_video``: the pre-detection filter of the broadcast-FM path;
+    ``wfm_video.h = wfm_filter_bank[idx]`` (``gui.py:1704``) swaps it live."""
+
+    def __init__(self, rx, h):
+        self._rx = rx
+        self._h = np.ascontiguousarray(h, np.float64)
+
+    @property
+    def h(self):
+        return self._h
+
+    @h.setter
+    def h(self, taps):
+        self._h = np.ascontiguousarray(taps, np.float64)
+        self._rx._push_wfm_taps()
+
+
 class _Demod:
-    """``rx.demod``: AF filter banks (``receiver.py:873-874``) and the AM-Synch PLL."""
+    """``rx.demod``: AF filter banks (``receiver.py:873-874``), the AM-Synch PLL and the
+    broadcast-FM video filter bank (``gui.py:1704``)."""
 
     def __init__(self, rx, fs_out, ntaps):
         self.filter_bank_real = design.af_bank_real(fs_out, ntaps)
         self.filter_bank_cmpx = design.af_bank_cmpx(fs_out, ntaps)
         self.am_pll = _PLLHandle(rx)
+        ctx = rx._ctx
+        d1, up2, down2 = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(ctx.L.pysdr_wfm_params(float(ctx.cfg.srate), float(fs_out), C.byref(d1), C.byref(up2),
+                                     C.byref(down2)), "pysdr_wfm_params")
+        self.wfm_d1, self.wfm_up2, self.wfm_down2 = d1.value, up2.value, down2.value
+        self.wfm_fs1 = ctx.cfg.srate / d1.value
+        vbw = float(getattr(rx.P, 'VIDEO_BW', 200e3) or 200e3)
+        self.wfm_filter_bank = design.wfm_video_bank(ctx.cfg.srate, self.wfm_fs1, ctx.ntaps_dec, vbw,
+                                                     rx._video_labels)
+        vidx = index_of_bw(vbw, rx._video_labels, len(rx._video_labels) - 1)
+        self.wfm_video = _WfmVideo(rx, self.wfm_filter_bank[vidx])
+        self.wfm_resamp = design.wfm_resampler_taps(self.wfm_fs1, self.wfm_up2)
 
 
 class _AGC:
@@ -315,8 +346,8 @@ class Receiver:
         return (mode, int(idx), af_bw, bfo, lsb)
 
     def _af_taps(self, mode, idx, af_bw, bfo, lsb):
-        if mode in _UNSUPPORTED_ON_DEVICE:
-            raise NotImplementedError(f"mode {mode} is not implemented on the device yet")
+        if mode in _WFM_MODES:
+            return design.wfm_af_taps(self._ctx.fs_out, self._ctx.ntaps_af, af_bw).astype(np.complex128)
         if mode not in MODE_INDEX:
             raise ValueError(f"unknown mode {mode}")
         if mode == 'CW':
@@ -327,8 +358,17 @@ class Receiver:
         c = self.demod.filter_bank_cmpx[idx]
         return np.conj(c) if (mode == 'LSB' or lsb) else c
 
+    def _push_wfm_taps(self):
+        v = np.ascontiguousarray(self.demod.wfm_video.h, np.float64)
+        rs = np.ascontiguousarray(self.demod.wfm_resamp, np.float64)
+        check(self._ctx.L.pysdr_set_wfm_taps(self._ctx.h, self.irx, _lib.as_pd(v), len(v),
+                                             _lib.as_pd(rs), len(rs)), "pysdr_set_wfm_taps")
+        self._wfm_pushed = True
+
     def _sync_controls(self):
         want = self._want()
+        if want[0] in _WFM_MODES and not getattr(self, '_wfm_pushed', False):
+            self._push_wfm_taps()
         if want != self._applied:
             af = np.ascontiguousarray(self._af_taps(*want), np.complex128).view(np.float64)
             check(self._ctx.L.pysdr_set_mode(self._ctx.h, self.irx, MODE_INDEX[want[0]],

@@ -256,3 +256,44 @@ def test_convolver_streaming_fir_matches_scipy():
     z = (x[:2048] + 1j * x[2048:4096]).astype(np.complex64)
     cz = sig_proc.convolver(h, np.float32).convolve_fast(z)
     assert np.max(np.abs(cz - signal.lfilter(h, [1.0], z.astype(np.complex128)))) <= TOL * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("stereo", [True, False])
+def test_c4_wbfm_10msps(stereo):
+    """config #4: WBFM path, 10 MS/s IQ, 1 RX, pilot-PLL stereo demod + 75 us de-emphasis."""
+    from oracle import wfm_oracle as wo
+    from pysdr_amd import sig_proc
+    from pysdr_amd.params import RunTimeParams
+    fs, L, n = 10e6, 213333, 6
+    x = wo.synth_wfm(fs, n * L, 4)
+    mode = 'WFM2' if stereo else 'WFM'
+    P = RunTimeParams(fs=fs, fc=[98.1e6], mode=mode, nfilt=255, foffset=300e3, vid_bw=200e3)
+    assert (P.UP, P.DOWN, P.IN_CHUNK_SIZE, P.VIDEO_BW) == (3, 625, L, 200e3)
+    g = sig_proc.Receiver(P, 300e3, 0, '1')
+    o = wo.WfmReceiver(fs, 48e3, 300e3, stereo=stereo, ntaps_dec=255, dtype=np.float32)
+    assert (g.demod.wfm_d1, g.demod.wfm_up2, g.demod.wfm_down2) == (o.d1, o.up2, o.down2) == (40, 24, 125)
+    assert np.allclose(g.demod.wfm_filter_bank, o.front.filter_bank)
+    for k in range(n):
+        xc = x[k * L:(k + 1) * L]
+        ag, ao = g.demod_data(xc), o.demod_data(xc)
+        assert ag.dtype == ao.dtype and len(ag) in (1023, 1024, 1025)
+        if k == 0:
+            continue                        # discriminator start-up on an empty FIR (|y| ~ 0)
+        assert relerr(g.iq, o.iq) <= TOL, (k, 'iq')
+        assert relerr(ag, ao) <= TOL, (k, 'am')
+    if stereo:                              # the decoder really separates L (1 kHz) from R (2.5 kHz)
+        t = np.arange(len(ag)) / 48000.0
+        amp = lambda s, f: 2 * abs(np.mean(s * np.exp(-2j * np.pi * f * t)))
+        assert amp(ag.real, 1000.0) > 10 * amp(ag.real, 2500.0)
+        assert amp(ag.imag, 2500.0) > 5 * amp(ag.imag, 1000.0)
+
+
+def test_wfm_cannot_mix_with_narrowband_in_one_context():
+    from pysdr_amd import sig_proc, _lib
+    from pysdr_amd.params import RunTimeParams
+    P = RunTimeParams(fs=2.048e6, fc=[7e6, 7e6], mode='AM', nfilt=255)
+    a = sig_proc.Receiver(P, 100e3, 0, '1')
+    b = sig_proc.Receiver(P, 200e3, 1, '2')
+    b.mode = 'WFM'
+    with pytest.raises(_lib.PysdrError):
+        a.demod_data(np.zeros(P.IN_CHUNK_SIZE, np.complex64))
