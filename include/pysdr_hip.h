@@ -113,6 +113,11 @@ int pysdr_set_wfm_taps(pysdr_ctx* ctx, int irx, const double* video, int nv, con
 /* rx.agc.reset() / rx.demod.am_pll.reset() (receiver.py:648-649): what = 1 AGC, 2 PLL, 3 both */
 int pysdr_reset(pysdr_ctx* ctx, int irx, unsigned what);
 int pysdr_agc_get(pysdr_ctx* ctx, int irx, pysdr_agc_state* st);
+/* NFM noise squelch (north_star "AGC/squelch"; design notes sigs/squelch.m:92-145): per chunk the
+ * mean |2nd difference| of the discriminator output is smoothed (one pole) and the chunk is
+ * muted while it exceeds `thresh`; thresh <= 0 disables (default). */
+int pysdr_set_squelch(pysdr_ctx* ctx, int irx, float thresh);
+int pysdr_squelch_get(pysdr_ctx* ctx, int irx, float* level, int* open);
 /* AGC on/off and reference level */
 int pysdr_set_agc(pysdr_ctx* ctx, int irx, int enable, float ref);
 

@@ -40,6 +40,7 @@ PSD_FLOOR = 1.0e-30
 AUTO_MUTE_THRESH = 0.7         # |x| peak of the raw chunk that trips auto-mute
 PLL_ZETA = 0.7071
 PLL_BW_HZ = 50.0
+SQUELCH_ALPHA = 0.64           # per-block smoothing = 1-(1-0.001)^1024 (sigs/squelch.m alpha=0.001/sample)
 
 
 # ------------------------------------------------------------------ rates / sizes
@@ -401,6 +402,10 @@ class Demodulator:
         else:                       # SSB/USB/LSB/IQ/RTTY: the AF filter does the work
             d = ybuf[2:]
         a = np.convolve(d, self.taps, mode='valid') if n else d[:0]
+        # out-of-band noise of the detector output (2nd difference = crude high-pass), for
+        # the NFM noise squelch (sigs/squelch.m:92-145: HP envelope, one-pole smoothing)
+        dr = d.real.astype(self.rd)
+        self.last_hp = np.abs(dr[hl:] - self.rd(2) * dr[hl - 1:-1] + dr[hl - 2:-2]).astype(self.rd) if n else dr[:0]
         self.yhist = ybuf[len(ybuf) - (hl + 2):]
         self.m_abs += n
         return a.astype(self.cd)
@@ -437,6 +442,9 @@ class Receiver:
         self.iq = np.zeros(0, self.cd)
         self.peak_in = dtype(0)
         self.mute_count = 0
+        self.squelch = dtype(0)        # NFM noise-squelch threshold, 0 = off
+        self.sq_level = dtype(0)
+        self.sq_open = True
         self.xhist = np.zeros(0, self.cd)
 
     @staticmethod
@@ -491,6 +499,12 @@ class Receiver:
             a = a.real.astype(self.rd)
             peak = np.max(np.abs(a)) if len(a) else 0.0
         g = self.agc.update(peak, self.mode in AGC_MODES)
+        if self.mode == 'NFM' and self.squelch > 0 and len(a):
+            noise = self.rd(np.sum(self.demod.last_hp.astype(np.float64)) / len(a))
+            self.sq_level = self.rd(self.sq_level + self.rd(SQUELCH_ALPHA) * self.rd(noise - self.sq_level))
+            self.sq_open = bool(self.sq_level <= self.rd(self.squelch))
+            if not self.sq_open:
+                g = self.rd(0)
         am = (a * g).astype(a.dtype)
         self.iq = y
         self.am = am

@@ -71,6 +71,7 @@ struct RxHost {
   unsigned reset_pending = 3;
   int agc_enable = 1;
   float agc_ref = 0.5f;
+  float sq_thresh = 0.f;
   float2* d_y = nullptr;        // [hy + mmax]
   float2* d_ypll = nullptr;     // [hy + mmax], allocated on first AM-Synch use
   float2* d_a = nullptr;        // [mmax]
@@ -106,6 +107,8 @@ struct pysdr_ctx {
   unsigned* d_peak_scratch = nullptr;  // [1] sink for decimators whose raw peak is not wanted
   unsigned* d_blkpeak = nullptr; // [MAX_RX][max_chunks]
   float* d_gain = nullptr;       // [MAX_RX][max_chunks]
+  float* d_blknoise = nullptr;   // [MAX_RX][max_chunks]
+  unsigned* d_blkcnt = nullptr;  // [MAX_RX][max_chunks]
   RxDevState* d_state = nullptr; // [MAX_RX]
   // last call
   int last_nout = 0, last_nchunks = 0;
@@ -335,7 +338,7 @@ int apply_pending(pysdr_ctx* c) {
       RxDevState st;
       PYSDR_HIP_CHECK(hipMemcpyAsync(&st, c->d_state + r, sizeof(st), hipMemcpyDeviceToHost, c->stream));
       PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
-      if (x.reset_pending & 1u) { st.env = 0.f; st.gain = 1.f; st.maxbuf = 0.f; st.err = 0.f; }
+      if (x.reset_pending & 1u) { st.env = 0.f; st.gain = 1.f; st.maxbuf = 0.f; st.err = 0.f; st.sq_level = 0.f; st.sq_open = 1; }
       if (x.reset_pending & 2u) { st.pll_theta = 0.f; st.pll_w = 0.f; st.wfm_phase = 0u; st.wfm_w = 0.f; }
       st.ref = x.agc_ref; st.agc_enable = x.agc_enable;
       PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_state + r, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
@@ -432,6 +435,10 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   CK(hipMalloc(&c->d_blkpeak, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
   CK(hipMemset(c->d_blkpeak, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
   CK(hipMalloc(&c->d_gain, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
+  CK(hipMalloc(&c->d_blknoise, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
+  CK(hipMemset(c->d_blknoise, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
+  CK(hipMalloc(&c->d_blkcnt, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
+  CK(hipMemset(c->d_blkcnt, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
   CK(hipMalloc(&c->d_state, PYSDR_MAX_RX * sizeof(RxDevState)));
   CK(hipMemset(c->d_state, 0, PYSDR_MAX_RX * sizeof(RxDevState)));
   for (int k = 0; k < pysdr_ctx::kSlots; ++k)
@@ -464,6 +471,8 @@ void pysdr_destroy(pysdr_ctx* c) {
   if (c->d_peak_scratch) (void)hipFree(c->d_peak_scratch);
   if (c->d_blkpeak) (void)hipFree(c->d_blkpeak);
   if (c->d_gain) (void)hipFree(c->d_gain);
+  if (c->d_blknoise) (void)hipFree(c->d_blknoise);
+  if (c->d_blkcnt) (void)hipFree(c->d_blkcnt);
   if (c->d_state) (void)hipFree(c->d_state);
   for (int k = 0; k < pysdr_ctx::kSlots; ++k)
     for (int i = 0; i < 4; ++i) if (c->ev[k][i]) (void)hipEventDestroy(c->ev[k][i]);
@@ -560,6 +569,25 @@ int pysdr_set_agc(pysdr_ctx* c, int irx, int enable, float ref) {
   c->rx[irx].agc_enable = enable ? 1 : 0;
   c->rx[irx].agc_ref = ref;
   c->rx[irx].agc_dirty = true;
+  return PYSDR_OK;
+}
+
+int pysdr_set_squelch(pysdr_ctx* c, int irx, float thresh) {
+  if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->rx[irx].sq_thresh = thresh > 0.f ? thresh : 0.f;
+  return PYSDR_OK;
+}
+
+int pysdr_squelch_get(pysdr_ctx* c, int irx, float* level, int* open) {
+  if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  RxDevState d;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (level) *level = d.sq_level;
+  if (open) *open = d.sq_open;
   return PYSDR_OK;
 }
 
@@ -762,10 +790,12 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     s.single_block[r] = wfm ? 1 : 0;
     s.matrix[r] = (x.mode == PYSDR_WFM2) ? 1 : 0;
     s.bfo_fword[r] = x.bfo_fword;
+    s.sq_thresh[r] = x.sq_thresh;
     c->last_complex[r] = (x.mode == PYSDR_IQ || x.mode == PYSDR_WFM2) ? 1 : 0;
     any_pll |= (s.det[r] == kDetPll);
   }
   s.blkpeak = c->d_blkpeak; s.gain = c->d_gain; s.state = c->d_state;
+  s.blknoise = c->d_blknoise; s.blkcnt = c->d_blkcnt;
   if (any_pll && n_out > 0) { rc = launch_pll(s, c->stream); if (rc) return rc; }
   rc = launch_demod_fir(s, c->stream); if (rc) return rc;
   rc = launch_agc_scan(s, c->stream); if (rc) return rc;

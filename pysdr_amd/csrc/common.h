@@ -69,6 +69,8 @@ struct RxDevState {       // one per RX, lives in device memory
   float pll_theta, pll_w;   // AM-Synch carrier PLL
   uint32_t wfm_phase;       // WFM2 pilot PLL: 32-bit phase accumulator
   float wfm_w;              //                 loop integrator (rad/sample)
+  float sq_level;           // NFM noise squelch: smoothed out-of-band noise
+  int sq_open;
 };
 
 struct Stage2Args {
@@ -88,6 +90,9 @@ struct Stage2Args {
   uint32_t bfo_fword[PYSDR_MAX_RX];
   int single_block[PYSDR_MAX_RX];     // WFM: no AGC blocks, the whole call is block 0
   int matrix[PYSDR_MAX_RX];           // WFM2: (S, D) -> (S+D) + j(S-D) = L + jR
+  float sq_thresh[PYSDR_MAX_RX];      // NFM noise squelch threshold, <= 0 disabled
+  float* blknoise;                    // [nrx][nchunks] sum |2nd difference of the detector output|
+  unsigned* blkcnt;                   // [nrx][nchunks] outputs per block
   unsigned* blkpeak;                  // [nrx][nchunks] float bits
   float* gain;                        // [nrx][nchunks]
   RxDevState* state;                  // [nrx]

@@ -174,6 +174,28 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
         else atomicMax(a.blkpeak + (size_t)r * a.nchunks + block_of(a, r, ib + j), __float_as_uint(m));
       }
   }
+  // NFM noise squelch (sigs/squelch.m:92-145): block sum of |2nd difference| of the
+  // detector output -- out-of-band noise rises when the carrier goes away
+  const bool squelch = (a.sq_thresh[r] > 0.f) && (det == kDetFm);
+  float nz = 0.f;
+  unsigned cnt = 0u;
+  if (squelch && ib < a.n_out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ib + j < a.n_out) {
+        const int e = 4 * (hq + tid) + j;                 // element of output ib+j
+        const float d0 = dre[(e & 3) * sub + (e >> 2)];
+        const float d1 = dre[((e - 1) & 3) * sub + ((e - 1) >> 2)];
+        const float d2 = dre[((e - 2) & 3) * sub + ((e - 2) >> 2)];
+        const float hp = fabsf(d0 - 2.f * d1 + d2);
+        if (blk_lo == blk_hi) { nz += hp; cnt += 1u; }
+        else {
+          const uint32_t bj = block_of(a, r, ib + j);
+          atomicAdd(a.blknoise + (size_t)r * a.nchunks + bj, hp);
+          atomicAdd(a.blkcnt + (size_t)r * a.nchunks + bj, 1u);
+        }
+      }
+  }
   // block peak: one atomic per wave when the whole wave sits inside one block
   const uint32_t b0 = __shfl(blk_lo, 0);
   const bool uniform = __all((blk_lo == b0 && blk_hi == b0) || blk_lo == 0xFFFFFFFFu);
@@ -183,8 +205,22 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((tid & 63) == 0 && b0 != 0xFFFFFFFFu)
       atomicMax(a.blkpeak + (size_t)r * a.nchunks + b0, __float_as_uint(m));
+    if (squelch) {
+      float sn = nz;
+      unsigned sc = cnt;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { sn += __shfl_xor(sn, o); sc += __shfl_xor(sc, o); }
+      if ((tid & 63) == 0 && b0 != 0xFFFFFFFFu) {
+        atomicAdd(a.blknoise + (size_t)r * a.nchunks + b0, sn);
+        atomicAdd(a.blkcnt + (size_t)r * a.nchunks + b0, sc);
+      }
+    }
   } else if (blk_lo != 0xFFFFFFFFu && blk_lo == blk_hi) {
     atomicMax(a.blkpeak + (size_t)r * a.nchunks + blk_lo, __float_as_uint(mag));
+    if (squelch) {
+      atomicAdd(a.blknoise + (size_t)r * a.nchunks + blk_lo, nz);
+      atomicAdd(a.blkcnt + (size_t)r * a.nchunks + blk_lo, cnt);
+    }
   }
 }
 
@@ -220,15 +256,36 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
     // the raw block peaks are consumed: leave them zeroed for the next call
     a.blkpeak[(size_t)r * a.nchunks + c] = 0u;
   }
+  if (a.sq_thresh[r] > 0.f) {
+    __syncthreads();
+    if (tid == 0) {
+      // serial one-pole smoothing of the block noise, gate the gain (0 = squelched)
+      float lvl = st.sq_level;
+      int open = st.sq_open;
+      for (int c = 0; c < a.nchunks; ++c) {
+        const size_t k = (size_t)r * a.nchunks + c;
+        const unsigned n = a.blkcnt[k];
+        if (n > 0u) {
+          const float noise = __fdiv_rn(a.blknoise[k], (float)n);
+          lvl = __fadd_rn(lvl, __fmul_rn(0.64f, __fsub_rn(noise, lvl)));
+          open = (lvl <= a.sq_thresh[r]) ? 1 : 0;
+          if (!open) a.gain[k] = 0.f;
+        }
+        a.blknoise[k] = 0.f;
+        a.blkcnt[k] = 0u;
+      }
+      a.state[r].sq_level = lvl;
+      a.state[r].sq_open = open;
+    }
+  }
   if (tid == 0 && a.nchunks > 0) {
     const float env = pk[a.nchunks - 1];
     const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(env, 1e-12f)), 1.0e4f) : 1.f;
-    RxDevState o = st;
-    o.env = env;
-    o.gain = g;
-    o.maxbuf = last_peak;
-    o.err = __fsub_rn(st.ref, __fmul_rn(g, last_peak));
-    a.state[r] = o;
+    // field-wise: the squelch block above owns sq_level / sq_open
+    a.state[r].env = env;
+    a.state[r].gain = g;
+    a.state[r].maxbuf = last_peak;
+    a.state[r].err = __fsub_rn(st.ref, __fmul_rn(g, last_peak));
   }
 }
 

@@ -327,6 +327,7 @@ class Receiver:
         self.peak_in = 0.0
         self._seen = ctx.seq
         self._mute_left = 0
+        self._squelch = 0.0
 
     # -- what the controls currently ask for: (mode, af_idx, af_bw, bfo, lsb)
     def _want(self):
@@ -388,6 +389,24 @@ class Receiver:
             self._seen = ctx.seq
         self.am, self.iq, self.peak_in = am, iq, pk
         return am
+
+    # -- NFM noise squelch (not a call site of the reference: north_star lists it; the idea
+    # is sigs/squelch.m:92-145).  ``rx.squelch = thresh`` arms it, 0 disables.
+    @property
+    def squelch(self):
+        return self._squelch
+
+    @squelch.setter
+    def squelch(self, thresh):
+        self._squelch = float(thresh)
+        check(self._ctx.L.pysdr_set_squelch(self._ctx.h, self.irx, self._squelch), "pysdr_set_squelch")
+
+    @property
+    def squelch_state(self):
+        lvl, op = C.c_float(0), C.c_int(1)
+        check(self._ctx.L.pysdr_squelch_get(self._ctx.h, self.irx, C.byref(lvl), C.byref(op)),
+              "pysdr_squelch_get")
+        return lvl.value, bool(op.value)
 
     def auto_mute(self, x=None):
         """``rx.auto_mute(x)`` (``receiver.py:238-245``): big-signal detector on the raw

@@ -297,3 +297,26 @@ def test_wfm_cannot_mix_with_narrowband_in_one_context():
     b.mode = 'WFM'
     with pytest.raises(_lib.PysdrError):
         a.demod_data(np.zeros(P.IN_CHUNK_SIZE, np.complex64))
+
+
+def test_nfm_noise_squelch_mutes_when_the_carrier_drops():
+    cfg = so.CONFIGS['C2']
+    L, n = 170666, 15
+    x = so.synth_iq(cfg, n * L, 14)
+    noise_only = so.synth_iq(dict(cfg, carriers=[]), n * L, 15)
+    x[4 * L:8 * L] = noise_only[4 * L:8 * L]           # the station goes off the air for 4 chunks
+    P, g = make_gpu_receivers(cfg)
+    o = so.make_receivers(cfg, np.float32)
+    g[0].squelch = 0.05
+    o[0].squelch = np.float32(0.05)
+    opened = []
+    for k in range(n):
+        xc = x[k * L:(k + 1) * L]
+        ag, ao = g[0].demod_data(xc), o[0].demod_data(xc)
+        lvl, op = g[0].squelch_state
+        opened.append(op)
+        assert op == o[0].sq_open, k
+        assert abs(lvl - float(o[0].sq_level)) <= 1e-4 * max(float(o[0].sq_level), 1e-3), k
+        if k > 0:
+            assert relerr(ag, ao) <= TOL or (not op and not np.any(ag)), k
+    assert opened[2] and opened[3] and not opened[5] and not opened[6] and opened[14]
