@@ -170,6 +170,20 @@ int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size
 int pysdr_spectrum_sync(pysdr_spectrum* sp);
 int pysdr_spectrum_elapsed_ms(pysdr_spectrum* sp, float* ms);
 
+/* ---- waterfall numeric back-end (three_box_plot.plot, Plotting.py:536-626; shift_waterfall
+ * :689-695): device history ring [nfft][ncols]; push = shift-in of one PSD line (shorter lines
+ * padded with -1e38); roll = np.roll(wf, -nbins, axis=0); image = max(wf - median(mean(wf[:,
+ * -cnt:], 1)), nanmax(wf - bkgnd) - pan_dr), returned column-major: image_out[c][i], c = 0 the
+ * oldest column (numpy: image_out.reshape(ncols, nfft).T).  mean_out[nfft] is the PSD2 vector the
+ * reference feeds to find_peaks (Plotting.py:583,595). */
+typedef struct pysdr_waterfall pysdr_waterfall;
+int  pysdr_waterfall_create(int device, int nfft, int ncols, pysdr_waterfall** out);
+void pysdr_waterfall_destroy(pysdr_waterfall* wf);
+int  pysdr_waterfall_push(pysdr_waterfall* wf, const float* line_db, int n, int on_device);
+int  pysdr_waterfall_roll(pysdr_waterfall* wf, int nbins);
+int  pysdr_waterfall_image(pysdr_waterfall* wf, float pan_dr, float* image_out, float* mean_out,
+                           float* bkgnd_out);
+
 /* ---- device memory for resident streams --------------------------------------- */
 int pysdr_dev_alloc(int device, size_t bytes, void** out);
 int pysdr_dev_free(int device, void* p);

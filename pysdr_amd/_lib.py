@@ -73,6 +73,11 @@ PROTOTYPES = {
     "pysdr_spectrum_batch": (_i, [_vp, _vp, _i, _sz, _vp]),
     "pysdr_spectrum_sync": (_i, [_vp]),
     "pysdr_spectrum_elapsed_ms": (_i, [_vp, _pf]),
+    "pysdr_waterfall_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
+    "pysdr_waterfall_destroy": (None, [_vp]),
+    "pysdr_waterfall_push": (_i, [_vp, _vp, _i, _i]),
+    "pysdr_waterfall_roll": (_i, [_vp, _i]),
+    "pysdr_waterfall_image": (_i, [_vp, _f, _pf, _pf, _pf]),
     "pysdr_dev_alloc": (_i, [_i, _sz, C.POINTER(_vp)]),
     "pysdr_dev_free": (_i, [_i, _vp]),
     "pysdr_dev_upload": (_i, [_i, _vp, _vp, _sz]),

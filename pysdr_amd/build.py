@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpysdr_hip.so")
-SOURCES = ["api.hip", "mixdec.hip", "stage2.hip", "misc.hip", "psdfft.hip"]
+SOURCES = ["api.hip", "mixdec.hip", "stage2.hip", "misc.hip", "psdfft.hip", "waterfall.hip"]
 # per-file extra flags (none needed today; -fno-slp-vectorize on mixdec.hip folds the DPP
 # reduction into v_add_f32_dpp but measured the same 96-99 us, so the default stays)
 EXTRA_FLAGS = {"mixdec.hip": os.environ.get("PYSDR_MIXDEC_FLAGS", "").split()}

@@ -14,6 +14,7 @@ chunk is uploaded and read once for every RX (the reference loops
 from __future__ import annotations
 
 import ctypes as C
+import sys
 import multiprocessing as mp
 import queue
 import threading
@@ -66,6 +67,10 @@ class _StreamContext:
             self.h = None
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be torn down: leave the device
+        # memory to process exit rather than call into a dead runtime
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -448,6 +453,10 @@ class spectrum:
         self._h = h
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be torn down: leave the device
+        # memory to process exit rather than call into a dead runtime
+        if sys.is_finalizing():
+            return
         try:
             if self._h:
                 _lib.lib().pysdr_spectrum_destroy(self._h)

@@ -1,0 +1,69 @@
+"""Numeric part of the reference's waterfall display (``three_box_plot.plot``,
+``Plotting.py:536-626``; ``shift_waterfall`` :689-695) with the history kept on the GPU
+(SURVEY.md 8(f) N1).  The Qt drawing stays with the caller; this returns what it blits."""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+
+import numpy as np
+from scipy import signal
+
+from . import _lib
+from ._lib import check
+
+
+class Waterfall:
+    def __init__(self, nfft, ncols=100, device=0):
+        _lib.require_gpu()
+        self.nfft, self.ncols, self.device = int(nfft), int(ncols), device
+        self.wf_cnt = 0                  # Plotting.py:386
+        self.wf_fc = 0                   # Plotting.py:387
+        h = C.c_void_p()
+        check(_lib.lib().pysdr_waterfall_create(device, self.nfft, self.ncols, C.byref(h)),
+              "pysdr_waterfall_create")
+        self._h = h
+
+    def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be torn down: leave the device
+        # memory to process exit rather than call into a dead runtime
+        if sys.is_finalizing():
+            return
+        try:
+            if self._h:
+                _lib.lib().pysdr_waterfall_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def push(self, PSD, flip=False):
+        """``wf = concatenate((wf[:,1:], line), axis=1)`` (``Plotting.py:536-547``); ``flip`` is
+        the ``RIG_IF<0`` ``np.flipud`` of :538-539."""
+        line = np.ascontiguousarray(PSD[::-1] if flip else PSD, np.float32)
+        check(_lib.lib().pysdr_waterfall_push(self._h, C.c_void_p(line.ctypes.data), len(line), 0),
+              "pysdr_waterfall_push")
+        if self.wf_cnt < self.ncols:
+            self.wf_cnt += 1
+
+    def shift_waterfall(self, frq, df):
+        """``Plotting.py:689-695``: roll the history when the centre frequency moved."""
+        nbins = int(float(frq - self.wf_fc) / df + 0.5)
+        if nbins != 0:
+            check(_lib.lib().pysdr_waterfall_roll(self._h, nbins), "pysdr_waterfall_roll")
+            self.wf_fc = frq
+        return nbins
+
+    def image(self, pan_dr):
+        """-> (image[nfft, ncols], bkgnd, PSD2): ``Plotting.py:583-587,618-626``."""
+        img = np.empty((self.ncols, self.nfft), np.float32)
+        mean = np.empty(self.nfft, np.float32)
+        bk = C.c_float(0)
+        check(_lib.lib().pysdr_waterfall_image(self._h, float(pan_dr), _lib.as_pf(img), _lib.as_pf(mean),
+                                               C.byref(bk)), "pysdr_waterfall_image")
+        return img.T, bk.value, mean
+
+    @staticmethod
+    def peaks(psd2, bkgnd, peak_dist, df):
+        """``Plotting.py:594-602``: peak pick on the averaged PSD (host, SciPy)."""
+        pk, _ = signal.find_peaks(psd2, distance=peak_dist / df, height=bkgnd + 10)
+        return pk

@@ -320,3 +320,34 @@ def test_nfm_noise_squelch_mutes_when_the_carrier_drops():
         if k > 0:
             assert relerr(ag, ao) <= TOL or (not op and not np.any(ag)), k
     assert opened[2] and opened[3] and not opened[5] and not opened[6] and opened[14]
+
+
+def test_waterfall_backend_matches_plotting_py_numerics():
+    """Plotting.py:536-626,689-695 with the history on the device."""
+    from pysdr_amd.waterfall import Waterfall
+    rng = np.random.default_rng(16)
+    nfft, ncols = 4096, 100
+    w = Waterfall(nfft, ncols)
+    ref = -1e38 * np.ones((nfft, ncols))
+    cnt, fc = 0, 0.0
+    df = 0.125
+    for k in range(130):                      # more than ncols: the ring wraps
+        line = (rng.standard_normal(nfft) * 3 - 90).astype(np.float32)
+        line[1000 + k] += 40                  # a drifting carrier
+        n = nfft if k % 7 else nfft // 2      # real-input PSDs are half length (Plotting.py:540-541)
+        if k in (40, 90):                     # retune: roll by a few bins
+            newfc = fc + (3 if k == 40 else -5) * df
+            ref, fc = so.waterfall_roll(ref, fc, newfc, df)
+            assert w.shift_waterfall(newfc, df) != 0
+        ref = so.waterfall_push(ref, line[:n].astype(np.float64))
+        cnt = min(cnt + 1, ncols)
+        w.push(line[:n])
+        if k in (0, 5, 99, 129):
+            img, bk, psd2 = w.image(60.0)
+            rimg, rbk, rpsd2 = so.waterfall_image(ref, cnt, 60.0)
+            assert img.shape == rimg.shape == (nfft, ncols) and w.wf_cnt == cnt
+            assert abs(bk - rbk) <= 1e-5 * abs(rbk)
+            assert np.allclose(psd2, rpsd2, rtol=1e-5)
+            assert np.allclose(img, rimg, rtol=1e-5, atol=1e-3)
+            assert np.array_equal(Waterfall.peaks(psd2.astype(np.float64), bk, 10.0, df),
+                                  so.find_peaks_db(rpsd2, rbk, 10.0 / df)) or k != 129
