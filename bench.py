@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
-    ap.add_argument("--chunks", type=int, default=512, help="chunks per step (batch resident in HBM)")
+    ap.add_argument("--chunks", type=int, default=2048, help="chunks per step (batch resident in HBM)")
     ap.add_argument("--no-psd", action="store_true")
     ap.add_argument("--no-demod", action="store_true", help="diagnostic: PSD only")
     ap.add_argument("--tile-bytes", type=int, default=0)
@@ -100,7 +100,7 @@ def cpu_baseline(cfg, nchunks, with_psd, seed):
 def measured_traffic(args, nrx, B):
     """HBM bytes per mix+decimate launch from the committed PMC passes (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE), valid only for the configuration that was profiled."""
-    if args.workload != "c3" or B != 512 or nrx != 4:
+    if args.workload != "c3" or B != 2048 or nrx != 4:
         return None
     try:
         rows = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))

@@ -323,7 +323,7 @@ int apply_pending(pysdr_ctx* c) {
       x.wfm_dirty = false;
     }
     if (x.af_dirty) {
-      std::vector<float2> t((c->cfg.ntaps_af + 3) & ~3, make_float2(0.f, 0.f));
+      std::vector<float2> t((c->cfg.ntaps_af + 7) & ~7, make_float2(0.f, 0.f));
       x.taps_real = 1;
       for (int k = 0; k < c->cfg.ntaps_af; ++k) {
         t[k] = make_float2((float)x.af[2 * k], (float)x.af[2 * k + 1]);
@@ -413,7 +413,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   if (rc) return rc;
   pysdr_ctx* c = new pysdr_ctx();
   c->cfg = *cfg;
-  c->hy = (((cfg->ntaps_af + 3) & ~3) + 4 + 1) & ~1;   // FIR history (padded taps) + discriminator
+  c->hy = (((cfg->ntaps_af + 7) & ~7) + 4 + 1) & ~1;   // FIR history (taps padded to 8) + discriminator
   c->cap_samples = (size_t)cfg->max_chunks * (size_t)cfg->in_chunk;
   c->mmax = (int)((c->cap_samples * (size_t)cfg->up) / (size_t)cfg->down) + 4;
   {
@@ -510,7 +510,7 @@ int pysdr_rx_add(pysdr_ctx* c, int mode, double lo_freq, const double* h, const 
   PYSDR_HIP_CHECK(hipMemset(x.d_y, 0, ny * sizeof(float2)));
   PYSDR_HIP_CHECK(hipMalloc(&x.d_a, (size_t)c->mmax * sizeof(float2)));
   PYSDR_HIP_CHECK(hipMalloc(&x.d_am, (size_t)c->mmax * 2 * sizeof(float)));
-  PYSDR_HIP_CHECK(hipMalloc(&x.d_aftaps, (size_t)((c->cfg.ntaps_af + 3) & ~3) * sizeof(float2)));
+  PYSDR_HIP_CHECK(hipMalloc(&x.d_aftaps, (size_t)((c->cfg.ntaps_af + 7) & ~7) * sizeof(float2)));
   c->nrx = r + 1;
   if (irx) *irx = r;
   return PYSDR_OK;

@@ -170,7 +170,8 @@ __device__ __forceinline__ void stage_tile(const MixDecArgs& a, const Tile& t, f
   }
 }
 
-template <int R>
+// NJ = kpad/16 known at compile time (fully unrolled tap loop) or 0 for a runtime loop
+template <int R, int NJ>
 __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   float2* const buf0 = lds;                    // [tile_cap]
@@ -279,8 +280,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
       float2 A[R], B[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) { A[r] = make_float2(0.f, 0.f); B[r] = make_float2(0.f, 0.f); }
-#pragma unroll 3
-      for (int j = 0; j < a.kpad; j += 16) {
+      auto tap_step = [&](int j) {
         const float2 xv = xp[-j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -290,6 +290,13 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
           B[r].x = fmaf(gg.x, xv.y, B[r].x);
           B[r].y = fmaf(gg.y, xv.y, B[r].y);
         }
+      };
+      if (NJ > 0) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) tap_step(16 * jj);
+      } else {
+#pragma unroll 2
+        for (int j = 0; j < a.kpad; j += 16) tap_step(j);
       }
       // fold the 16 lanes of each row: all 2R partial sums advance one DPP step at a time,
       // so consecutive instructions are independent (no DPP hazard stalls)
@@ -326,21 +333,28 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
 }
 
-template <int R>
-int launch_r(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
+template <int R, int NJ>
+int launch_rj(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mixdec_kernel<R>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mixdec_kernel<R, NJ>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
-      set_last_error("hipFuncSetAttribute(mixdec<%d>): %s", R, hipGetErrorString(e));
+      set_last_error("hipFuncSetAttribute(mixdec<%d,%d>): %s", R, NJ, hipGetErrorString(e));
       return PYSDR_ERR_HIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(mixdec_kernel<R>, dim3(grid), dim3(threads), lds, st, a);
+  hipLaunchKernelGGL((mixdec_kernel<R, NJ>), dim3(grid), dim3(threads), lds, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
+}
+
+template <int R>
+int launch_r(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
+  // 255-tap prototypes at UP = 3 (the BASELINE configurations) have 96 taps per branch
+  if (a.kpad == 96) return launch_rj<R, 6>(a, threads, grid, lds, st);
+  return launch_rj<R, 0>(a, threads, grid, lds, st);
 }
 
 }  // namespace

@@ -48,16 +48,17 @@ __global__ void pll_kernel(const Stage2Args a) {
   st->pll_w = w;
 }
 
-// ---- detector + AF FIR + block peak.  grid = (tiles, nrx), 1024 outputs per workgroup,
-// four consecutive outputs per thread.  The detector output d is staged in LDS as four
-// de-interleaved sub-arrays D_m[q] = d[4q+m]: thread t owns outputs 4t..4t+3, and at tap k
-// needs d[4t+j-k] -- a window that slides by ONE element per tap, so each tap costs one
-// conflict-free LDS read (lanes read consecutive q of one sub-array) for four outputs.
-// The taps are wave-uniform and come through the scalar cache (s_load), not LDS.
+// ---- detector + AF FIR + block peak.  grid = (tiles, nrx), 2048 outputs per workgroup,
+// EIGHT consecutive outputs per thread.  The detector output d is staged in LDS as eight
+// de-interleaved sub-arrays D_m[q] = d[8q+m]: thread t owns outputs 8t..8t+7, and at tap k
+// needs d[8t+j-k] -- a window that slides by ONE element per tap, so each tap costs one
+// conflict-free LDS read (lanes read consecutive q of one sub-array) for eight outputs.
+// The (<= 256) taps live in VGPRs, one per lane, and are broadcast with v_readlane.
 // Arithmetic is specialised by what the mode needs (kFir* below): AM/NFM/AM-Synch have a
 // real detector and real taps (1 FMA per tap), the SSB family needs only Re(c*d) (2 FMA).
-constexpr int kFirOut = 1024;          // outputs per workgroup
+constexpr int kW = 8;                  // outputs per thread = window length
 constexpr int kFirThreads = 256;
+constexpr int kFirOut = kW * kFirThreads;   // outputs per workgroup
 constexpr int kFirRealReal = 0;        // d real, c real    -> real
 constexpr int kFirRePart = 1;          // d cplx, c cplx    -> Re(c*d)
 constexpr int kFirCplx = 2;            // d cplx, c cplx    -> cplx (IQ)
@@ -87,44 +88,79 @@ __device__ __forceinline__ float2 detect(const Stage2Args& a, int r, int det, co
   return d;
 }
 
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// One tap for the kW outputs of a lane (window slots rotate instead of moving registers).
 template <int KIND>
-__device__ __forceinline__ void fir4(const Stage2Args& a, int r, int hq, const float2* __restrict__ taps,
-                                     int ntaps4, const float* dre, const float* dim, int sub, int tid,
-                                     float2 (&acc)[4]) {
-  // window w[j] = d[e0 + j - k], e0 = 4*(hq + tid); element e lives at D[e&3][e>>2]
-  float wr[4], wi[4];
+__device__ __forceinline__ void fir_tap(float2 c, int u, const float (&wr)[kW], const float (&wi)[kW],
+                                        float2 (&acc)[kW]) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < kW; ++j) {
+    const int sl = (j - u) & (kW - 1);
+    acc[j].x = fmaf(c.x, wr[sl], acc[j].x);
+    if (KIND != kFirRealReal) {
+      acc[j].x = fmaf(-c.y, wi[sl], acc[j].x);
+      if (KIND == kFirCplx) {
+        acc[j].y = fmaf(c.x, wi[sl], acc[j].y);
+        acc[j].y = fmaf(c.y, wr[sl], acc[j].y);
+      }
+    }
+  }
+}
+
+// TAPS_IN_LANES: the (<= 256) taps sit in four VGPR pairs, lane l holding taps l, 64+l, ...;
+// each tap is broadcast with v_readlane -- no scalar-cache load (an s_load in flight forces
+// every LDS wait to drain lgkmcnt completely) and no extra LDS read.
+template <int KIND, bool TAPS_IN_LANES>
+__device__ __forceinline__ void fir_window(int hq, const float2* __restrict__ taps, int ngroups,
+                                           const float* dre, const float* dim, int sub, int tid,
+                                           float2 (&acc)[kW]) {
+  // window w[j] = d[e0 + j - k], e0 = kW*(hq + tid); element e lives at D[e % kW][e / kW]
+  float wr[kW], wi[kW];
+#pragma unroll
+  for (int j = 0; j < kW; ++j) {
     wr[j] = dre[j * sub + hq + tid];
     wi[j] = (KIND == kFirRealReal) ? 0.f : dim[j * sub + hq + tid];
     acc[j] = make_float2(0.f, 0.f);
   }
-  for (int g = 0; g < ntaps4; ++g) {
-    const int q = hq + tid - g - 1;
+  // after tap k = kW*g+u the window moves down one element: the slot that held d[e0+kW-1-k]
+  // is refilled with d[e0-k-1] = D[kW-1-u][hq + tid - g - 1]
+  if (TAPS_IN_LANES) {
+    const int lane = tid & 63;
+    constexpr int kGroupsPerReg = 64 / kW;
+    float2 tc[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float2 c = taps[4 * g + u];                    // wave-uniform: scalar load
-      // outputs j use window slot (j - u) mod 4 ... slots rotate instead of moving registers
+    for (int jb = 0; jb < 4; ++jb)
+      tc[jb] = (64 * jb + lane < kW * ngroups) ? taps[64 * jb + lane] : make_float2(0.f, 0.f);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int sl = (j - u) & 3;
-        if (KIND == kFirRealReal) {
-          acc[j].x = fmaf(c.x, wr[sl], acc[j].x);
-        } else {
-          acc[j].x = fmaf(c.x, wr[sl], acc[j].x);
-          acc[j].x = fmaf(-c.y, wi[sl], acc[j].x);
-          if (KIND == kFirCplx) {
-            acc[j].y = fmaf(c.x, wi[sl], acc[j].y);
-            acc[j].y = fmaf(c.y, wr[sl], acc[j].y);
-          }
+    for (int jb = 0; jb < 4; ++jb) {
+      const int left = ngroups - kGroupsPerReg * jb;
+      const int g_end = left < kGroupsPerReg ? left : kGroupsPerReg;
+      for (int gg = 0; gg < g_end; ++gg) {
+        const int q = hq + tid - (kGroupsPerReg * jb + gg) - 1;
+#pragma unroll
+        for (int u = 0; u < kW; ++u) {
+          const float2 c = make_float2(lane_bcast(tc[jb].x, kW * gg + u),
+                                       KIND == kFirRealReal ? 0.f : lane_bcast(tc[jb].y, kW * gg + u));
+          fir_tap<KIND>(c, u, wr, wi, acc);
+          const int m = (kW - 1 - u) & (kW - 1);
+          wr[m] = dre[m * sub + q];
+          if (KIND != kFirRealReal) wi[m] = dim[m * sub + q];
         }
       }
-      // next tap: the window moves down by one element; the slot that held the newest
-      // element d[e0+3-k] is refilled with d[e0-k-1] = D[(3-u)][q + (u==3 ? ... )]
-      const int sl_new = (3 - u) & 3;                      // slot of j=3 at this u
-      const int m = (3 - u) & 3;                           // (e0 - k - 1) mod 4 with k = 4g+u
-      wr[sl_new] = dre[m * sub + q];
-      if (KIND != kFirRealReal) wi[sl_new] = dim[m * sub + q];
+    }
+  } else {
+    for (int g = 0; g < ngroups; ++g) {
+      const int q = hq + tid - g - 1;
+#pragma unroll
+      for (int u = 0; u < kW; ++u) {
+        fir_tap<KIND>(taps[kW * g + u], u, wr, wi, acc);      // wave-uniform: scalar load
+        const int m = (kW - 1 - u) & (kW - 1);
+        wr[m] = dre[m * sub + q];
+        if (KIND != kFirRealReal) wi[m] = dim[m * sub + q];
+      }
     }
   }
 }
@@ -136,37 +172,43 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   const int i0 = blockIdx.x * kFirOut;
   const int det = a.det[r];
   const float2* y = (det == kDetPll) ? a.ypll[r] : a.y[r];
-  const int ntaps4 = (a.ntaps + 3) >> 2;                 // taps are zero padded to 4*ntaps4
-  const int hq = ntaps4;                                 // history quads in front of the tile
-  const int sub = kFirOut / 4 + hq;                      // length of one sub-array
-  float* dre = lds_f;                                    // [4][sub]
-  float* dim = lds_f + 4 * sub;                          // [4][sub]
+  const int ngroups = (a.ntaps + kW - 1) / kW;           // taps are zero padded to kW*ngroups
+  const int hq = ngroups;                                // history groups in front of the tile
+  const int sub = kFirOut / kW + hq;                     // length of one sub-array
+  float* dre = lds_f;                                    // [kW][sub]
+  float* dim = lds_f + kW * sub;                         // [kW][sub]
   const bool real_det = (det == kDetAbs || det == kDetFm || det == kDetPll);
 
   const float2* taps = a.aftaps[r];
   const int kind = a.out_complex[r] ? kFirCplx : (real_det && a.taps_real[r] ? kFirRealReal : kFirRePart);
-  // stage d[i0 - 4 hq + e], e = 0 .. 4*sub-1
-  for (int e = tid; e < 4 * sub; e += kFirThreads) {
-    const float2 d = detect(a, r, det, y, i0 - 4 * hq + e);
-    dre[(e & 3) * sub + (e >> 2)] = d.x;
-    if (kind != kFirRealReal) dim[(e & 3) * sub + (e >> 2)] = d.y;
+  // stage d[i0 - kW hq + e], e = 0 .. kW*sub-1
+  for (int e = tid; e < kW * sub; e += kFirThreads) {
+    const float2 d = detect(a, r, det, y, i0 - kW * hq + e);
+    dre[(e & (kW - 1)) * sub + (e / kW)] = d.x;
+    if (kind != kFirRealReal) dim[(e & (kW - 1)) * sub + (e / kW)] = d.y;
   }
   __syncthreads();
 
-  float2 acc[4];
-  if (kind == kFirRealReal) fir4<kFirRealReal>(a, r, hq, taps, ntaps4, dre, dim, sub, tid, acc);
-  else if (kind == kFirRePart) fir4<kFirRePart>(a, r, hq, taps, ntaps4, dre, dim, sub, tid, acc);
-  else fir4<kFirCplx>(a, r, hq, taps, ntaps4, dre, dim, sub, tid, acc);
+  float2 acc[kW];
+  if (ngroups * kW <= 256) {
+    if (kind == kFirRealReal) fir_window<kFirRealReal, true>(hq, taps, ngroups, dre, dim, sub, tid, acc);
+    else if (kind == kFirRePart) fir_window<kFirRePart, true>(hq, taps, ngroups, dre, dim, sub, tid, acc);
+    else fir_window<kFirCplx, true>(hq, taps, ngroups, dre, dim, sub, tid, acc);
+  } else {
+    if (kind == kFirRealReal) fir_window<kFirRealReal, false>(hq, taps, ngroups, dre, dim, sub, tid, acc);
+    else if (kind == kFirRePart) fir_window<kFirRePart, false>(hq, taps, ngroups, dre, dim, sub, tid, acc);
+    else fir_window<kFirCplx, false>(hq, taps, ngroups, dre, dim, sub, tid, acc);
+  }
 
-  const int ib = i0 + 4 * tid;
+  const int ib = i0 + kW * tid;
   float mag = 0.f;
   uint32_t blk_lo = 0xFFFFFFFFu, blk_hi = 0xFFFFFFFFu;
   if (ib < a.n_out) {
-    const int last = (ib + 3 < a.n_out) ? ib + 3 : a.n_out - 1;
+    const int last = (ib + kW - 1 < a.n_out) ? ib + kW - 1 : a.n_out - 1;
     blk_lo = block_of(a, r, ib);
     blk_hi = block_of(a, r, last);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < kW; ++j)
       if (ib + j < a.n_out) {
         a.a[r][ib + j] = acc[j];
         const float m = a.out_complex[r] ? sqrtf(acc[j].x * acc[j].x + acc[j].y * acc[j].y) : fabsf(acc[j].x);
@@ -181,12 +223,12 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   unsigned cnt = 0u;
   if (squelch && ib < a.n_out) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < kW; ++j)
       if (ib + j < a.n_out) {
-        const int e = 4 * (hq + tid) + j;                 // element of output ib+j
-        const float d0 = dre[(e & 3) * sub + (e >> 2)];
-        const float d1 = dre[((e - 1) & 3) * sub + ((e - 1) >> 2)];
-        const float d2 = dre[((e - 2) & 3) * sub + ((e - 2) >> 2)];
+        const int e = kW * (hq + tid) + j;                // element of output ib+j
+        const float d0 = dre[(e & (kW - 1)) * sub + (e / kW)];
+        const float d1 = dre[((e - 1) & (kW - 1)) * sub + ((e - 1) / kW)];
+        const float d2 = dre[((e - 2) & (kW - 1)) * sub + ((e - 2) / kW)];
         const float hp = fabsf(d0 - 2.f * d1 + d2);
         if (blk_lo == blk_hi) { nz += hp; cnt += 1u; }
         else {
@@ -377,8 +419,8 @@ int launch_pll(const Stage2Args& a, hipStream_t st) {
 
 int launch_demod_fir(const Stage2Args& a, hipStream_t st) {
   if (a.n_out <= 0) return PYSDR_OK;
-  const int ntaps4 = (a.ntaps + 3) >> 2;
-  const size_t lds = (size_t)8 * (kFirOut / 4 + ntaps4) * sizeof(float);
+  const int ngroups = (a.ntaps + kW - 1) / kW;
+  const size_t lds = (size_t)2 * kW * (kFirOut / kW + ngroups) * sizeof(float);
   dim3 grid((a.n_out + kFirOut - 1) / kFirOut, a.nrx);
   hipLaunchKernelGGL(demod_fir_kernel, grid, dim3(kFirThreads), lds, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
