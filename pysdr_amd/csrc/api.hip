@@ -993,10 +993,11 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
                         int db, float* d_out) {
   int rc;
   if (is_complex && sp->chunk == 32768 && sp->nfft == 65536 && !getenv("PYSDR_PSD_ROCFFT")) {
-    // the RF-waterfall size: fused four-step transform.  Frames go through in groups so the
-    // 512 KB/frame intermediate is re-read while it is still in L2 / Infinity Cache.
+    // the RF-waterfall size: fused four-step transform, in groups of frames (grid.y limit).
+    // Small groups would keep the 512 KB/frame intermediate in the Infinity Cache, but that
+    // measured no faster than HBM (scripts/mall_test.hip), so the groups are large.
     const char* ge = getenv("PYSDR_PSD_GROUP");
-    int group = ge ? atoi(ge) : 128;
+    int group = ge ? atoi(ge) : 4096;
     if (group < 1) group = 1;
     PYSDR_HIP_CHECK(hipEventRecord(sp->ev[0], sp->stream));
     for (int f0 = 0; f0 < nframes; f0 += group) {
