@@ -137,7 +137,7 @@ def main():
     L = P.IN_CHUNK_SIZE
     nsamp = B * L
     if args.tile_bytes or args.threads:
-        _lib.check(lib.pysdr_set_tile(ctx.h, args.tile_bytes or 64 * 1024, args.threads or 1024), "set_tile")
+        _lib.check(lib.pysdr_set_tile(ctx.h, args.tile_bytes, args.threads or 1024), "set_tile")
 
     # synthetic stream: 8 unique chunks (seed per rank = its own stream), repeated to fill the batch
     uniq = 8

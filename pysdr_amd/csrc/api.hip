@@ -116,7 +116,7 @@ struct pysdr_ctx {
   unsigned long long last_s0 = 0;
   int last_complex[PYSDR_MAX_RX] = {0};
   // tuning / profiling
-  int tile_bytes = 64 * 1024, threads = 1024;  // per LDS buffer (two buffers per workgroup)
+  int tile_bytes = 0, threads = 1024;  // per LDS buffer (two per workgroup); 0 = as large as fits
   int wgs_per_cu = 1, num_cus = 256;
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
@@ -226,7 +226,7 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   const unsigned long long m0 = (s0 * up + down - 1) / down, m1 = (s1 * up + down - 1) / down;
   const int n_out = (int)(m1 - m0);
   if (n_out > y_cap) { set_last_error("decimator: n_out %d > capacity %d", n_out, y_cap); return PYSDR_ERR_STATE; }
-  if ((double)n * up + down >= 4294967295.0) { set_last_error("decimator: call too long for 32-bit indices"); return PYSDR_ERR_ARG; }
+  if ((double)n * up + down >= 2147483647.0) { set_last_error("decimator: call too long for 31-bit indices"); return PYSDR_ERR_ARG; }
   MixDecArgs a;
   memset(&a, 0, sizeof(a));
   a.x = d_x;
@@ -246,22 +246,34 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   int wgs = c->wgs_per_cu;
   { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) wgs = atoi(e); }
   const long lds_share = (160L * 1024) / wgs - 512;
-  long cap = c->tile_bytes / (long)sizeof(float2);
+  // tile_bytes == 0: the largest tile the LDS share allows (fewer tiles = less per-tile
+  // scalar work, the kernel's scarcest resource)
+  long cap = c->tile_bytes > 0 ? c->tile_bytes / (long)sizeof(float2) : (1L << 30);
   if (2 * cap * (long)sizeof(float2) + (long)taps_bytes > lds_share)
     cap = (lds_share - (long)taps_bytes) / (2 * (long)sizeof(float2));
-  long tile_out = ((cap - d.kpad - 2L * ratio - 8) * up) / down;
+  const long slack = d.kpad + 2L * ratio + 8 + 128;   // halo, ownership overhang, whole 64-pair DMA pieces
+  long tile_out = ((cap - slack) * up) / down;
   if (tile_out >= 4L * up) tile_out -= tile_out % (4L * up);   // whole quads of every polyphase branch
   tile_out &= ~1L;
   if (tile_out < 2) {
     tile_out = 2;
-    cap = d.kpad + 2L * ratio + 8 + (2L * down + up - 1) / up + 2;
+    cap = slack + (2L * down + up - 1) / up + 2;
     if (2 * (size_t)cap * sizeof(float2) + taps_bytes > 160 * 1024) {
       set_last_error("decimator: filter (%d taps, %d rx, up %d) does not fit LDS", d.ntaps, nrx, up);
       return PYSDR_ERR_ARG;
     }
+  } else {
+    cap = std::min(cap, slack + (tile_out * down + up - 1) / up + 2);   // no more LDS than the tile needs
   }
   a.tile_out = (int)tile_out;
   a.tile_cap = (int)((cap + 1) & ~1L);
+  a.tpc = (int)((((tile_out + up - 1) / up) + 3) >> 2);
+  a.ntasks = up * a.tpc;
+  a.magic_tpc = (a.tpc == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned)a.tpc) + 1u;
+  a.dq_tile = (int)((tile_out * down) / up);
+  a.dr_tile = (int)((tile_out * down) % up);
+  a.dq_last = (int)(((tile_out - 1) * down) / up);
+  a.dr_last = (int)(((tile_out - 1) * down) % up);
   a.ntiles = n_out > 0 ? (n_out + a.tile_out - 1) / a.tile_out : 1;
   a.taps = d.d_taps;
   for (int r = 0; r < nrx; ++r) { a.y[r] = y[r]; a.phase0[r] = phase0[r]; a.fword[r] = fword[r]; }
@@ -609,7 +621,7 @@ int pysdr_set_profile(pysdr_ctx* c, int enable) {
 }
 
 int pysdr_set_tile(pysdr_ctx* c, int tile_bytes, int threads) {
-  if (!c || tile_bytes < 4096 || tile_bytes > 150 * 1024 || threads < 64 || threads > 1024 ||
+  if (!c || (tile_bytes != 0 && (tile_bytes < 4096 || tile_bytes > 150 * 1024)) || threads < 64 || threads > 1024 ||
       (threads & 63))
     return PYSDR_ERR_ARG;
   c->tile_bytes = tile_bytes;

@@ -58,6 +58,11 @@ struct MixDecArgs {
   uint32_t chunk_len;
   uint32_t magic_chunk;   // floor(2^32/chunk_len)+1
   int dbg;                // diagnostic build switches (PYSDR_DEBUG_FLAGS); 0 in production
+  // host-precomputed loop constants (the kernel's scalar unit is its scarcest resource)
+  int tpc, ntasks;        // tasks (quads of outputs) per polyphase branch; up*tpc
+  uint32_t magic_tpc;     // floor(2^32/tpc)+1
+  int dq_tile, dr_tile;   // divmod(tile_out*down, up)
+  int dq_last, dr_last;   // divmod((tile_out-1)*down, up)
 };
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st);
 size_t mixdec_lds_bytes(const MixDecArgs& a);

@@ -95,13 +95,28 @@ __device__ __forceinline__ void glds16(const void* gsrc, const void* lds_wave_ba
       : "v"(gsrc), "s"(dst)
       : "memory");
 }
+// Same copy with M0 handled by the caller (m0_save / m0_restore around a run of pieces):
+// the scalar unit is shared by all waves of a CU, so every s_* instruction saved here is
+// saved 16 times per tile.
+__device__ __forceinline__ unsigned m0_save() {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0" : "=s"(keep)::"memory");
+  return keep;
+}
+__device__ __forceinline__ void m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep) : "memory"); }
+__device__ __forceinline__ void glds16_m0(const void* gsrc, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Geometry of tile b: outputs [i_first, i_last], LDS image = samples [lo, hi] (relative to
-// the first sample of the call; negative = history), samples [own_lo, own_hi] are the ones
-// this tile contributes to the raw-chunk peak.
+// Geometry of tile b: outputs [i_first, i_first + tile_n), LDS image = samples [lo, hi]
+// (relative to the first sample of the call; negative = history), samples [own_lo, own_hi]
+// are the ones this tile contributes to the raw-chunk peak.  (rel_f, p_f) = divmod(t0 +
+// i_first*DOWN, UP) and rel_l = floor((t0 + i_last*DOWN)/UP) seed the per-task index
+// arithmetic and the incremental step to the next tile.
 struct Tile {
-  int i_first, i_last, tile_n;
+  int i_first, tile_n;
+  int rel_f, p_f, rel_l;
   int lo, hi, own_lo, own_hi, npairs;
 };
 
@@ -112,15 +127,19 @@ __device__ __forceinline__ Tile tile_geometry(const MixDecArgs& a, int b) {
   if (n > a.tile_out) n = a.tile_out;
   if (n < 0) n = 0;
   t.tile_n = n;
-  t.i_last = t.i_first + n - 1;
   int need_lo, need_hi;
+  uint32_t q, r;
+  divmod_magic(a.t0 + (uint32_t)t.i_first * (uint32_t)a.down, (uint32_t)a.up, a.magic, q, r);
+  t.rel_f = (int)q;
+  t.p_f = (int)r;
   if (n > 0) {
-    need_hi = (int)div_magic(a.t0 + (uint32_t)t.i_last * (uint32_t)a.down, (uint32_t)a.up, a.magic);
-    need_lo = (int)div_magic(a.t0 + (uint32_t)t.i_first * (uint32_t)a.down, (uint32_t)a.up, a.magic) - (a.kpad - 1);
+    need_hi = (int)div_magic(a.t0 + (uint32_t)(t.i_first + n - 1) * (uint32_t)a.down, (uint32_t)a.up, a.magic);
+    need_lo = t.rel_f - (a.kpad - 1);
     t.own_hi = need_hi;
   } else {
     need_hi = -1; need_lo = 0; t.own_hi = -1;
   }
+  t.rel_l = need_hi;
   t.own_lo = (b == 0) ? 0
                       : (int)div_magic(a.t0 + (uint32_t)(t.i_first - 1) * (uint32_t)a.down, (uint32_t)a.up, a.magic) + 1;
   if (b == a.ntiles - 1) t.own_hi = (int)a.n_total - 1;
@@ -132,10 +151,47 @@ __device__ __forceinline__ Tile tile_geometry(const MixDecArgs& a, int b) {
   return t;
 }
 
+// The same for the tile after the FULL tile `c` when that next tile is full and not the
+// last one: additions only (dq/dr = divmod(tile_out*DOWN, UP) and divmod((tile_out-1)*DOWN,
+// UP) come from the host), about 20 scalar instructions instead of three divisions.
+__device__ __forceinline__ Tile tile_advance(const MixDecArgs& a, const Tile& c) {
+  Tile t;
+  t.i_first = c.i_first + a.tile_out;
+  t.tile_n = a.tile_out;
+  int p = c.p_f + a.dr_tile, q = c.rel_f + a.dq_tile;
+  if (p >= a.up) { p -= a.up; q += 1; }
+  t.rel_f = q;
+  t.p_f = p;
+  t.rel_l = q + a.dq_last + ((p + a.dr_last >= a.up) ? 1 : 0);
+  t.own_lo = c.rel_l + 1;
+  t.own_hi = t.rel_l;
+  const int need_lo = q - (a.kpad - 1);
+  t.lo = (need_lo < t.own_lo ? need_lo : t.own_lo) & ~1;
+  t.hi = t.rel_l;
+  t.npairs = (t.hi - t.lo + 2) >> 1;
+  return t;
+}
+
 // Start the copy of tile `t` into `xs` (does not wait).
 __device__ __forceinline__ void stage_tile(const MixDecArgs& a, const Tile& t, float2* xs, int tid,
                                            int nthr) {
-  if (a.aligned16) {
+  const int npieces = (t.npairs + 63) >> 6;          // 1 KiB (64 pairs) per wave-instruction
+  if (a.aligned16 && t.lo >= 0 && (uint32_t)(t.lo + 128 * npieces) <= a.n_total) {
+    // interior tile: whole pieces, every pair exists (reads up to 63 pairs past `hi`, still
+    // inside the call; tile_cap leaves room for them)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6, lane = tid & 63;
+    const char* src = reinterpret_cast<const char*>(a.x + t.lo) + (size_t)(wave * 1024 + lane * 16);
+    unsigned dst = __builtin_amdgcn_readfirstlane(
+                       (unsigned)(size_t)(const __attribute__((address_space(3))) void*)xs) + (unsigned)wave * 1024u;
+    const unsigned step = (unsigned)nwaves * 1024u;
+    const unsigned keep = m0_save();
+    for (int q = wave; q < npieces; q += nwaves) {
+      glds16_m0(src, dst);
+      src += step;
+      dst += step;
+    }
+    m0_restore(keep);
+  } else if (a.aligned16) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6, lane = tid & 63;
     float4* dst = reinterpret_cast<float4*>(xs);
     for (int q = wave; q * 64 < t.npairs; q += nwaves) {
@@ -205,9 +261,20 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
     const int nt = R * a.up * a.kpad;
     for (int i = tid; i < nt; i += nthr) tl[i] = a.taps[i];
   }
+  // per-lane constants of the epilogue: lane s < R of every row finishes RX s
+  uint32_t my_p0 = 0u, my_fw = 0u;
+  float2* my_y = nullptr;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (s == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; my_y = a.y[r]; }
+  int v_gup = g * a.up, v_gdown = g * a.down - s;
+  asm volatile("" : "+v"(my_p0), "+v"(my_fw), "+v"(my_y), "+v"(v_gup), "+v"(v_gdown));
+
   Tile cur = tile_geometry(a, t_begin);
   float pk_run = 0.f;            // running raw-chunk peak of chunk pk_chunk (per lane)
   uint32_t pk_chunk = 0u;
+  int pk_lo = 0;                 // samples [pk_lo, pk_hi] of chunk pk_chunk exist in this call
+  int pk_hi = (int)(a.chunk_len < a.n_total ? a.chunk_len : a.n_total) - 1;
   if (!(a.dbg & 2)) stage_tile(a, cur, buf0, tid, nthr);
 
   for (int tb = t_begin; tb < t_end; ++tb) {
@@ -219,62 +286,84 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
     __syncthreads();
     Tile nxt = cur;
     if (tb + 1 < t_end) {
-      nxt = tile_geometry(a, tb + 1);
+      nxt = (tb + 2 < a.ntiles) ? tile_advance(a, cur) : tile_geometry(a, tb + 1);
       if (!(a.dbg & 2)) stage_tile(a, nxt, xn, tid, nthr);
     }
 
     // ---- raw-chunk peak |x|^2 over the samples this tile owns (rx.auto_mute input).
-    // A tile may straddle chunk boundaries: one wave-reduced scan + one atomic per wave
-    // for every chunk it touches (same-address atomics are slow: never one per sample).
+    // The running maximum of a chunk stays in a register across tiles; the atomic is only
+    // issued when the run moves on to another chunk (and once at the end): same-address
+    // atomics are slow, and one per tile would sit in vmcnt and stall the next dma_wait.
     if (cur.own_hi >= cur.own_lo && !(a.dbg & 4)) {
-      const uint32_t c_lo = div_magic((uint32_t)cur.own_lo, a.chunk_len, a.magic_chunk);
-      const uint32_t c_hi = div_magic((uint32_t)cur.own_hi, a.chunk_len, a.magic_chunk);
-      for (uint32_t c = c_lo; c <= c_hi; ++c) {
-        const long long cb = (long long)c * a.chunk_len;
-        const int s_lo = cur.own_lo > cb ? cur.own_lo : (int)cb;
-        const long long ce = cb + a.chunk_len - 1;
-        const int s_hi = cur.own_hi < ce ? cur.own_hi : (int)ce;
-        const int p_lo = (s_lo - cur.lo) >> 1, p_hi = (s_hi - cur.lo) >> 1;
-        const float4* xv = reinterpret_cast<const float4*>(xs);
-        // The running maximum of a chunk stays in a register across tiles; the atomic is
-        // only issued when the run moves on to another chunk (and once at the end): an
-        // atomic per tile would sit in vmcnt and stall the next tile's dma_wait.
-        if (c != pk_chunk) {
-          pk_run = wave_max63(pk_run);
-          if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
-          pk_run = 0.f;
-          pk_chunk = c;
-        }
-        // interior pairs need no masking; the two edge pairs are handled by one lane
-        for (int pi = p_lo + 1 + tid; pi < p_hi; pi += nthr) {
+      const float4* xv = reinterpret_cast<const float4*>(xs);
+      const int e_lo = cur.own_lo & ~1, e_hi = cur.own_hi | 1;
+      if (e_lo >= pk_lo && e_hi <= pk_hi) {
+        // whole pairs inside the current chunk: a maximum does not mind the neighbour
+        // sample being counted by two tiles
+        const int p_hi = (e_hi - cur.lo) >> 1;
+        for (int pi = ((e_lo - cur.lo) >> 1) + tid; pi <= p_hi; pi += nthr) {
           const float4 v = xv[pi];
           pk_run = fmaxf(pk_run, fmaxf(fmaf(v.x, v.x, v.y * v.y), fmaf(v.z, v.z, v.w * v.w)));
         }
-        if (tid == 0) {
-          const float4 v0 = xv[p_lo], v1 = xv[p_hi];
-          const int r0 = cur.lo + 2 * p_lo, r1 = cur.lo + 2 * p_hi;
-          if (r0 >= s_lo) pk_run = fmaxf(pk_run, fmaf(v0.x, v0.x, v0.y * v0.y));
-          if (r0 + 1 <= s_hi) pk_run = fmaxf(pk_run, fmaf(v0.z, v0.z, v0.w * v0.w));
-          if (r1 >= s_lo) pk_run = fmaxf(pk_run, fmaf(v1.x, v1.x, v1.y * v1.y));
-          if (r1 + 1 <= s_hi) pk_run = fmaxf(pk_run, fmaf(v1.z, v1.z, v1.w * v1.w));
+      } else {
+        // the tile straddles chunk boundaries (or the odd end of the call): one masked scan
+        // per chunk it touches
+        const uint32_t c_lo = div_magic((uint32_t)cur.own_lo, a.chunk_len, a.magic_chunk);
+        const uint32_t c_hi = div_magic((uint32_t)cur.own_hi, a.chunk_len, a.magic_chunk);
+        for (uint32_t c = c_lo; c <= c_hi; ++c) {
+          const long long cb = (long long)c * a.chunk_len;
+          const int s_lo = cur.own_lo > cb ? cur.own_lo : (int)cb;
+          const long long ce = cb + a.chunk_len - 1;
+          const int s_hi = cur.own_hi < ce ? cur.own_hi : (int)ce;
+          const int p_lo = (s_lo - cur.lo) >> 1, p_hi = (s_hi - cur.lo) >> 1;
+          if (c != pk_chunk) {
+            pk_run = wave_max63(pk_run);
+            if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
+            pk_run = 0.f;
+            pk_chunk = c;
+          }
+          // interior pairs need no masking; the two edge pairs are handled by one lane
+          for (int pi = p_lo + 1 + tid; pi < p_hi; pi += nthr) {
+            const float4 v = xv[pi];
+            pk_run = fmaxf(pk_run, fmaxf(fmaf(v.x, v.x, v.y * v.y), fmaf(v.z, v.z, v.w * v.w)));
+          }
+          if (tid == 0) {
+            const float4 v0 = xv[p_lo], v1 = xv[p_hi];
+            const int r0 = cur.lo + 2 * p_lo, r1 = cur.lo + 2 * p_hi;
+            if (r0 >= s_lo) pk_run = fmaxf(pk_run, fmaf(v0.x, v0.x, v0.y * v0.y));
+            if (r0 + 1 <= s_hi) pk_run = fmaxf(pk_run, fmaf(v0.z, v0.z, v0.w * v0.w));
+            if (r1 >= s_lo) pk_run = fmaxf(pk_run, fmaf(v1.x, v1.x, v1.y * v1.y));
+            if (r1 + 1 <= s_hi) pk_run = fmaxf(pk_run, fmaf(v1.z, v1.z, v1.w * v1.w));
+          }
         }
+        const long long cb = (long long)pk_chunk * a.chunk_len;
+        const long long ce = cb + a.chunk_len < (long long)a.n_total ? cb + a.chunk_len : (long long)a.n_total;
+        pk_lo = (int)cb;
+        pk_hi = (int)ce - 1;
       }
     }
 
     // ---- polyphase dot products: one output per DPP row (16 lanes), four outputs of the
-    // same polyphase branch per wave
+    // same polyphase branch per wave.  Task = (branch c, quad qq): outputs
+    // i = i_first + c + UP*(4*qq + g), whose input index is rel_c + DOWN*(4*qq + g) with
+    // (rel_c, p_c) = divmod(t0 + (i_first + c)*DOWN, UP) = (rel_f, 0) + divmod(p_f + c*DOWN, UP):
+    // one small scalar division per task, one VALU add per lane.
     const int upc = a.up;
-    const int tpc = (((a.tile_out + upc - 1) / upc) + 3) >> 2;     // tasks per branch
-    const int ntasks = (cur.tile_n > 0 && !(a.dbg & 1)) ? upc * tpc : 0;
+    const int kp = (NJ > 0) ? 16 * NJ : a.kpad;
+    const int ntasks = (cur.tile_n > 0 && !(a.dbg & 1)) ? a.ntasks : 0;
+    const int i_last = cur.i_first + cur.tile_n - 1;
     for (int task = wave; task < ntasks; task += nwaves) {
-      const int c = task / tpc, qq = task - c * tpc;
-      int i = cur.i_first + c + upc * (4 * qq + g);
-      const bool valid = (i <= cur.i_last);
-      if (!valid) i = cur.i_last;
-      uint32_t rel, p;
-      divmod_magic(a.t0 + (uint32_t)i * (uint32_t)a.down, (uint32_t)upc, a.magic, rel, p);
-      const float2* xp = xs + ((int)rel - cur.lo - s);
-      const float2* tp = tl + p * a.kpad + s;
+      const int c = (a.tpc == 1) ? task : (int)__umulhi((uint32_t)task, a.magic_tpc);
+      const int qq = task - c * a.tpc;
+      uint32_t qc, pc;
+      divmod_magic((uint32_t)cur.p_f + (uint32_t)c * (uint32_t)a.down, (uint32_t)upc, a.magic, qc, pc);
+      const int i = cur.i_first + c + 4 * qq * upc + v_gup;
+      const bool valid = (i <= i_last);
+      const int sb = cur.rel_f + (int)qc + 4 * qq * a.down - cur.lo;      // scalar
+      const int xi = valid ? sb + v_gdown : (cur.rel_f - cur.lo) - s;      // x index of tap 0, minus s
+      const uint32_t rel = (uint32_t)(sb + cur.lo + v_gdown + s);
+      const float2* xp = xs + xi;
+      const float2* tp = tl + (int)pc * kp + s;
       // A += g*x.re, B += g*x.im per RX (two packed FMAs per tap, no operand shuffles);
       // y = (A.re - B.im, A.im + B.re)
       float2 A[R], B[R];
@@ -284,7 +373,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
         const float2 xv = xp[-j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const float2 gg = tp[r * upc * a.kpad + j];
+          const float2 gg = tp[r * upc * kp + j];
           A[r].x = fmaf(gg.x, xv.x, A[r].x);
           A[r].y = fmaf(gg.y, xv.x, A[r].y);
           B[r].x = fmaf(gg.x, xv.y, B[r].x);
@@ -296,7 +385,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
         for (int jj = 0; jj < NJ; ++jj) tap_step(16 * jj);
       } else {
 #pragma unroll 2
-        for (int j = 0; j < a.kpad; j += 16) tap_step(j);
+        for (int j = 0; j < kp; j += 16) tap_step(j);
       }
       // fold the 16 lanes of each row: all 2R partial sums advance one DPP step at a time,
       // so consecutive instructions are independent (no DPP hazard stalls)
@@ -312,19 +401,17 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
 #pragma unroll
       for (int q = 0; q < 2 * R; ++q) red[q] += dpp_mirror(red[q]);
       float sr = 0.f, si = 0.f;
-      uint32_t p0 = 0u, fw = 0u;
-      float2* yp = nullptr;
 #pragma unroll
       for (int r = 0; r < R; ++r)
-        if (s == r) { sr = red[2 * r]; si = red[2 * r + 1]; p0 = a.phase0[r]; fw = a.fword[r]; yp = a.y[r]; }
+        if (s == r) { sr = red[2 * r]; si = red[2 * r + 1]; }
       if (valid && s < R) {
-        const uint32_t ph = p0 + fw * rel;
+        const uint32_t ph = my_p0 + my_fw * rel;
         const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
         const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
         float2 o;
         o.x = sr * cs - si * sn;
         o.y = sr * sn + si * cs;
-        yp[i] = o;
+        my_y[i] = o;
       }
     }
     cur = nxt;
