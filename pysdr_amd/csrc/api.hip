@@ -247,26 +247,39 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) wgs = atoi(e); }
   const long lds_share = (160L * 1024) / wgs - 512;
   // tile_bytes == 0: the largest tile the LDS share allows (fewer tiles = less per-tile
-  // scalar work, the kernel's scarcest resource)
-  long cap = c->tile_bytes > 0 ? c->tile_bytes / (long)sizeof(float2) : (1L << 30);
-  if (2 * cap * (long)sizeof(float2) + (long)taps_bytes > lds_share)
-    cap = (lds_share - (long)taps_bytes) / (2 * (long)sizeof(float2));
+  // scalar work, the kernel's scarcest resource).  What is left over holds the output stage
+  // (yflush tiles of outputs per RX); if that is less than 4 tiles' worth the tile shrinks.
   const long slack = d.kpad + 2L * ratio + 8 + 128;   // halo, ownership overhang, whole 64-pair DMA pieces
-  long tile_out = ((cap - slack) * up) / down;
-  if (tile_out >= 4L * up) tile_out -= tile_out % (4L * up);   // whole quads of every polyphase branch
-  tile_out &= ~1L;
-  if (tile_out < 2) {
-    tile_out = 2;
-    cap = slack + (2L * down + up - 1) / up + 2;
-    if (2 * (size_t)cap * sizeof(float2) + taps_bytes > 160 * 1024) {
-      set_last_error("decimator: filter (%d taps, %d rx, up %d) does not fit LDS", d.ntaps, nrx, up);
-      return PYSDR_ERR_ARG;
+  long cap = 0, tile_out = 0, yflush = 0;
+  long reserve = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    cap = c->tile_bytes > 0 ? c->tile_bytes / (long)sizeof(float2) : (1L << 30);
+    if (2 * cap * (long)sizeof(float2) + (long)taps_bytes + reserve > lds_share)
+      cap = (lds_share - (long)taps_bytes - reserve) / (2 * (long)sizeof(float2));
+    tile_out = ((cap - slack) * up) / down;
+    if (tile_out >= 4L * up) tile_out -= tile_out % (4L * up);   // whole quads of every polyphase branch
+    tile_out &= ~1L;
+    if (tile_out < 2) {
+      tile_out = 2;
+      cap = slack + (2L * down + up - 1) / up + 2;
+    } else {
+      cap = std::min(cap, slack + (tile_out * down + up - 1) / up + 2);   // no more LDS than the tile needs
     }
-  } else {
-    cap = std::min(cap, slack + (tile_out * down + up - 1) / up + 2);   // no more LDS than the tile needs
+    cap = (cap + 1) & ~1L;
+    const long per_tile = (long)nrx * tile_out * (long)sizeof(float2);
+    const long left = lds_share - (long)taps_bytes - 2 * cap * (long)sizeof(float2);
+    yflush = left > 0 ? std::min(16L, left / per_tile) : 0;
+    if (yflush >= 4 || pass == 1) break;
+    reserve = 4 * per_tile;
+  }
+  if (yflush < 1) {
+    set_last_error("decimator: filter (%d taps, %d rx, up %d) does not fit LDS", d.ntaps, nrx, up);
+    return PYSDR_ERR_ARG;
   }
   a.tile_out = (int)tile_out;
-  a.tile_cap = (int)((cap + 1) & ~1L);
+  a.tile_cap = (int)cap;
+  a.yflush = (int)yflush;
+  a.ycap = (int)(yflush * tile_out);
   a.tpc = (int)((((tile_out + up - 1) / up) + 3) >> 2);
   a.ntasks = up * a.tpc;
   a.magic_tpc = (a.tpc == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned)a.tpc) + 1u;

@@ -63,6 +63,7 @@ struct MixDecArgs {
   uint32_t magic_tpc;     // floor(2^32/tpc)+1
   int dq_tile, dr_tile;   // divmod(tile_out*down, up)
   int dq_last, dr_last;   // divmod((tile_out-1)*down, up)
+  int yflush, ycap;       // LDS output stage: flushed every yflush tiles; ycap = yflush*tile_out per RX
 };
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st);
 size_t mixdec_lds_bytes(const MixDecArgs& a);

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   float2* const buf0 = lds;                    // [tile_cap]
   float2* const buf1 = lds + a.tile_cap;       // [tile_cap]
   float2* const tl = lds + 2 * a.tile_cap;     // [R][up][kpad]
+  float2* const ys = tl + R * a.up * a.kpad;   // [R][ycap] output stage
 
   const int tid = threadIdx.x;
   const int nthr = blockDim.x;
@@ -263,14 +264,14 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   }
   // per-lane constants of the epilogue: lane s < R of every row finishes RX s
   uint32_t my_p0 = 0u, my_fw = 0u;
-  float2* my_y = nullptr;
 #pragma unroll
   for (int r = 0; r < R; ++r)
-    if (s == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; my_y = a.y[r]; }
+    if (s == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; }
   int v_gup = g * a.up, v_gdown = g * a.down - s;
-  asm volatile("" : "+v"(my_p0), "+v"(my_fw), "+v"(my_y), "+v"(v_gup), "+v"(v_gdown));
+  asm volatile("" : "+v"(my_p0), "+v"(my_fw), "+v"(v_gup), "+v"(v_gdown));
 
   Tile cur = tile_geometry(a, t_begin);
+  int i_base = cur.i_first;      // first output held in the LDS output stage
   float pk_run = 0.f;            // running raw-chunk peak of chunk pk_chunk (per lane)
   uint32_t pk_chunk = 0u;
   int pk_lo = 0;                 // samples [pk_lo, pk_hi] of chunk pk_chunk exist in this call
@@ -404,6 +405,10 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
         if (s == r) { sr = red[2 * r]; si = red[2 * r + 1]; }
+      // The outputs go to an LDS stage, not to memory: stores share vmcnt with the tile
+      // copies and the wait in front of the barrier is vmcnt(0), so a store per tile holds
+      // the next tile hostage to its write acknowledge (measured 4.5 vs 5.1 TB/s).  The
+      // stage is flushed every `yflush` tiles with whole-line coalesced stores.
       if (valid && s < R) {
         const uint32_t ph = my_p0 + my_fw * rel;
         const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
@@ -411,8 +416,22 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
         float2 o;
         o.x = sr * cs - si * sn;
         o.y = sr * sn + si * cs;
-        my_y[i] = o;
+        ys[s * a.ycap + (i - i_base)] = o;
       }
+    }
+    // ---- flush the output stage: RX r, 64 outputs per wave-store (512 contiguous bytes)
+    if (tb + 1 == t_end || (tb - t_begin + 1) % a.yflush == 0) {
+      __syncthreads();
+      const int n_st = cur.i_first + cur.tile_n - i_base;
+      const int cpr = (n_st + 63) >> 6;
+      if (!(a.dbg & 8))
+        for (int ch = wave; ch < R * cpr; ch += nwaves) {
+          int r = 0, c2 = ch;
+          while (c2 >= cpr) { c2 -= cpr; ++r; }
+          const int j = c2 * 64 + lane;
+          if (j < n_st) a.y[r][i_base + j] = ys[r * a.ycap + j];
+        }
+      i_base = cur.i_first + cur.tile_n;
     }
     cur = nxt;
   }
@@ -447,7 +466,7 @@ int launch_r(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t
 }  // namespace
 
 size_t mixdec_lds_bytes(const MixDecArgs& a) {
-  return (2 * (size_t)a.tile_cap + (size_t)a.nrx * a.up * a.kpad) * sizeof(float2);
+  return (2 * (size_t)a.tile_cap + (size_t)a.nrx * a.up * a.kpad + (size_t)a.nrx * a.ycap) * sizeof(float2);
 }
 
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st) {
