@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
     ap.add_argument("--chunks", type=int, default=2048, help="chunks per step (batch resident in HBM)")
     ap.add_argument("--no-psd", action="store_true")
+    ap.add_argument("--overlap-psd", action="store_true", help="PSD on its own stream, unordered w.r.t. the demod")
     ap.add_argument("--no-demod", action="store_true", help="diagnostic: PSD only")
     ap.add_argument("--tile-bytes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
@@ -164,7 +165,14 @@ def main():
         if not args.no_demod:
             ctx.process_batch(d_x.value, B, L, on_device=True)
         if sp is not None:
+            # Same order as pySDR's RX thread (demod of the chunk, then its PSD): the two are
+            # both HBM-bound, so overlapping them on two streams buys nothing and only smears
+            # the per-kernel timings; --overlap-psd restores the two-stream form.
+            if not args.overlap_psd and not args.no_demod:
+                _lib.check(lib.pysdr_spectrum_order(sp, ctx.h, 0), "spectrum_order")
             _lib.check(lib.pysdr_spectrum_batch(sp, d_x, nframes, PSD_CHUNK, d_psd), "spectrum_batch")
+            if not args.overlap_psd and not args.no_demod:
+                _lib.check(lib.pysdr_spectrum_order(sp, ctx.h, 1), "spectrum_order")
 
     def sync():
         _lib.check(lib.pysdr_sync(ctx.h), "sync")
@@ -251,6 +259,18 @@ def main():
             "avg_launch_ms": k1_ms,
         },
         "kernel_ms": {"mixdec": k1_ms, "stage2": float(np.mean(k2)) if k2 else None, "psd_last": psd_ms},
+        # the spectral path, same accounting: one call = nframes frames, each reads chunk complex
+        # samples and writes nfft dB values (the 512 KB/frame four-step intermediate is traffic,
+        # not algorithmic bytes)
+        "roofline_psd": None if psd_ms is None else {
+            "kernel": "psd_cols_kernel + psd_rows_kernel (window, zero-pad, 64k FFT, |.|^2, dB, fftshift)",
+            "bound": "hbm",
+            "achieved": nframes * (PSD_CHUNK * 8 + PSD_NFFT * 4) / (psd_ms * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": nframes * (PSD_CHUNK * 8 + PSD_NFFT * 4) / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "algorithmic_bytes_per_call": nframes * (PSD_CHUNK * 8 + PSD_NFFT * 4),
+            "avg_call_ms": psd_ms,
+        },
         "job_bytes_per_sample": bytes_per_sample_job,
         "job_hbm_frac_per_gpu": (nsamp * args.steps / dt) * bytes_per_sample_job / 1e9 / HBM_PEAK_GBPS,
     }

@@ -169,6 +169,11 @@ int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size
                          void* d_out);
 int pysdr_spectrum_sync(pysdr_spectrum* sp);
 int pysdr_spectrum_elapsed_ms(pysdr_spectrum* sp, float* ms);
+/* Ordering between the spectrum's stream and a receiver context's stream (both read the same
+ * device-resident chunk; Plotting.py:462 runs the PSD after the chunk's demod in one thread):
+ * direction 0: spectrum work queued from now on starts after everything queued on ctx so far;
+ * direction 1: ctx work queued from now on starts after everything queued on sp so far. */
+int pysdr_spectrum_order(pysdr_spectrum* sp, pysdr_ctx* ctx, int direction);
 
 /* ---- waterfall numeric back-end (three_box_plot.plot, Plotting.py:536-626; shift_waterfall
  * :689-695): device history ring [nfft][ncols]; push = shift-in of one PSD line (shorter lines

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "pysdr_spectrum_batch": (_i, [_vp, _vp, _i, _sz, _vp]),
     "pysdr_spectrum_sync": (_i, [_vp]),
     "pysdr_spectrum_elapsed_ms": (_i, [_vp, _pf]),
+    "pysdr_spectrum_order": (_i, [_vp, _vp, _i]),
     "pysdr_waterfall_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "pysdr_waterfall_destroy": (None, [_vp]),
     "pysdr_waterfall_push": (_i, [_vp, _vp, _i, _i]),

@@ -14,7 +14,7 @@
 
 namespace pysdr {
 
-static thread_local char g_err[512] = "";
+static thread_local char g_err[2048] = "";
 
 void set_last_error(const char* fmt, ...) {
   va_list ap;
@@ -139,6 +139,7 @@ struct pysdr_spectrum {
   std::map<int, rocfft_plan> plans;
   rocfft_execution_info info = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
+  hipEvent_t ev_order = nullptr;
 };
 
 namespace {
@@ -1008,6 +1009,7 @@ void pysdr_spectrum_destroy(pysdr_spectrum* sp) {
   if (sp->d_out) (void)hipFree(sp->d_out);
   if (sp->d_fftwork) (void)hipFree(sp->d_fftwork);
   for (int i = 0; i < 2; ++i) if (sp->ev[i]) (void)hipEventDestroy(sp->ev[i]);
+  if (sp->ev_order) (void)hipEventDestroy(sp->ev_order);
   if (sp->stream) (void)hipStreamDestroy(sp->stream);
   delete sp;
   std::lock_guard<std::mutex> lk(g_rocfft_mu);
@@ -1087,6 +1089,18 @@ int pysdr_spectrum_elapsed_ms(pysdr_spectrum* sp, float* ms) {
   if (rc) return rc;
   PYSDR_HIP_CHECK(hipEventSynchronize(sp->ev[1]));
   PYSDR_HIP_CHECK(hipEventElapsedTime(ms, sp->ev[0], sp->ev[1]));
+  return PYSDR_OK;
+}
+
+int pysdr_spectrum_order(pysdr_spectrum* sp, pysdr_ctx* c, int direction) {
+  if (!sp || !c || (direction != 0 && direction != 1) || sp->device != c->cfg.device) return PYSDR_ERR_ARG;
+  int rc = use_device(sp->device);
+  if (rc) return rc;
+  if (!sp->ev_order) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&sp->ev_order, hipEventDisableTiming));
+  hipStream_t first = direction == 0 ? c->stream : sp->stream;
+  hipStream_t then = direction == 0 ? sp->stream : c->stream;
+  PYSDR_HIP_CHECK(hipEventRecord(sp->ev_order, first));
+  PYSDR_HIP_CHECK(hipStreamWaitEvent(then, sp->ev_order, 0));
   return PYSDR_OK;
 }
 

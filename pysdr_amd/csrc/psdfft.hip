@@ -103,17 +103,11 @@ __device__ __forceinline__ void twiddle_pow(float2 (&v)[16], float2 w) {
 constexpr int kColsPerWg = 16;
 constexpr int kColLds = 16 * 272;
 
-__global__ __launch_bounds__(256) void psd_cols_kernel(const float2* __restrict__ x, size_t hop,
-                                                       const float* __restrict__ win,
-                                                       float2* __restrict__ work) {
-  __shared__ __attribute__((aligned(16))) float2 lds[kColLds];
-  const int tid = threadIdx.x;
-  const int f = blockIdx.y, cb = blockIdx.x;
+// one unit = 16 columns [16 cb, 16 cb + 16) of frame xf, 256 threads (tid), LDS kColLds
+__device__ __forceinline__ void cols_unit(const float2* __restrict__ xf, const float* __restrict__ win,
+                                          float2* __restrict__ yf, int cb, int tid, float2* lds) {
   const int b = tid & 15, hi = tid >> 4;
   const int bb = cb * kColsPerWg + b;
-  const float2* xf = x + (size_t)f * hop;
-  float2* yf = work + (size_t)f * kN;
-
   {
     const int a0 = hi;
     float2 u[16];
@@ -149,6 +143,14 @@ __global__ __launch_bounds__(256) void psd_cols_kernel(const float2* __restrict_
   }
 }
 
+__global__ __launch_bounds__(256) void psd_cols_kernel(const float2* __restrict__ x, size_t hop,
+                                                       const float* __restrict__ win,
+                                                       float2* __restrict__ work) {
+  __shared__ __attribute__((aligned(16))) float2 lds[kColLds];
+  const int f = blockIdx.y;
+  cols_unit(x + (size_t)f * hop, win, work + (size_t)f * kN, blockIdx.x, threadIdx.x, lds);
+}
+
 // ---- step 2: 32 rows p of one frame per workgroup (grid = 8 x frames, 512 threads).
 //   b = c0 + 16 c1, q = q1 + 16 q0
 //   pass 1 thread (c0, pl): DFT16 over c1, * W_256^(c0 q1)     -> LDS[q1][pl][c0]
@@ -159,19 +161,29 @@ __global__ __launch_bounds__(256) void psd_cols_kernel(const float2* __restrict_
 constexpr int kRowsPerWg = 32;
 constexpr int kRowLds = 16 * 544;
 
-__global__ __launch_bounds__(512) void psd_rows_kernel(const float2* __restrict__ work,
-                                                       float* __restrict__ out, int db) {
-  __shared__ __attribute__((aligned(16))) float2 lds[kRowLds];
-  const int tid = threadIdx.x;
-  const int f = blockIdx.y, rb = blockIdx.x;
-  const float2* yf = work + (size_t)f * kN;
-  float* of = out + (size_t)f * kN;
+// how the rows pass reads the intermediate: plain loads (two-kernel path: the kernel boundary
+// made it visible) or agent-scope loads that miss the CU's L1 (fused path: written by other
+// CUs of the same XCD during this kernel, served by their common L2)
+template <bool kBypassL1>
+__device__ __forceinline__ float2 load_work(const float2* p) {
+  if (kBypassL1) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)(v & 0xffffffffull)), __uint_as_float((unsigned)(v >> 32)));
+  }
+  return *p;
+}
+
+// one unit = 32 rows [32 rb, 32 rb + 32) of frame yf, 512 threads, LDS kRowLds
+template <bool kBypassL1>
+__device__ __forceinline__ void rows_unit(const float2* yf, float* __restrict__ of, int rb, int db,
+                                          int tid, float2* lds) {
   {
     const int c0 = tid & 15, pl = tid >> 4;
     const float2* src = yf + (size_t)(rb * kRowsPerWg + pl) * 256 + c0;
     float2 u[16];
 #pragma unroll
-    for (int c1 = 0; c1 < 16; ++c1) u[c1] = src[16 * c1];
+    for (int c1 = 0; c1 < 16; ++c1) u[c1] = load_work<kBypassL1>(src + 16 * c1);
     dft16(u);
     twiddle_pow(u, expmpi((float)c0 * (1.0f / 128.0f)));              // W_256^(c0 q1)
     float2* p = lds + 17 * pl + c0;
@@ -195,6 +207,13 @@ __global__ __launch_bounds__(512) void psd_rows_kernel(const float2* __restrict_
       of[(k + kM) & (kN - 1)] = pw;
     }
   }
+}
+
+__global__ __launch_bounds__(512) void psd_rows_kernel(const float2* __restrict__ work,
+                                                       float* __restrict__ out, int db) {
+  __shared__ __attribute__((aligned(16))) float2 lds[kRowLds];
+  const int f = blockIdx.y;
+  rows_unit<false>(work + (size_t)f * kN, out + (size_t)f * kN, blockIdx.x, db, threadIdx.x, lds);
 }
 
 }  // namespace
