@@ -136,7 +136,9 @@ class SDR_EXECUTIVE:
     def Startup(self):
         P = self.P
         if P.REPLAY_MODE:
-            self.raw = P.sdr.read_data()
+            # the reference loads the whole recording (receiver.py:526); a fileio reader is
+            # streamed through its memory map instead, chunk by chunk
+            self.raw = None if hasattr(P.sdr, 'read_chunk') else P.sdr.read_data()
             self.praw = 0
         else:
             P.rxStream = P.sdr.setupStream(SOAPY_SDR_RX, SOAPY_SDR_CF32)
@@ -147,8 +149,9 @@ class SDR_EXECUTIVE:
         P = self.P
         n = P.IN_CHUNK_SIZE
         if P.REPLAY_MODE:
-            if self.praw + n < len(self.raw):
-                x1 = self.raw[self.praw:self.praw + n]
+            total = len(self.raw) if self.raw is not None else P.sdr.nsamples
+            if self.praw + n < total:                   # strict, as receiver.py:543
+                x1 = self.raw[self.praw:self.praw + n] if self.raw is not None else P.sdr.read_chunk(n)
                 self.praw += n
                 lo = getattr(P, 'lo', None)
                 self.x = lo.quad_mixer(x1) if (lo is not None and lo.fo != 0) else x1
@@ -232,3 +235,60 @@ class SDR_EXECUTIVE:
         if not P.REPLAY_MODE and P.sdr is not None:
             P.sdr.deactivateStream(P.rxStream)
             P.sdr.closeStream(P.rxStream)
+
+
+def replay_batched(P, batch_chunks=64, on_batch=None, dsp=None):
+    """Replay a recording (``P.sdr`` = ``fileio.sdr_fileio`` reader, see ``fileio.open_replay``)
+    through the batched device path: ``batch_chunks`` chunks per launch sequence instead of one
+    Python round trip per chunk, the results identical to ``SDR_EXECUTIVE.Run`` in REPLAY_MODE
+    chunk for chunk (a chunk is still one AGC block; ``receiver.py:541-557`` for the slicing and
+    the tuning-offset mixer, ``:250-252`` for the DC removal, ``:293-297`` for the save taps).
+
+    ``on_batch(first_chunk, am, iq, chunk_nout)`` gets, per batch, lists over the sub-receivers of
+    the audio / baseband IQ of the whole batch and the per-chunk output counts.  Returns the
+    number of chunks processed.  GPU only (``pysdr_amd.sig_proc``)."""
+    if dsp is None:
+        from . import sig_proc as dsp
+    P.MAX_BATCH_CHUNKS = int(batch_chunks)
+    ex = SDR_EXECUTIVE(P, dsp=dsp)
+    ctx = P._pysdr_stream
+    L = P.IN_CHUNK_SIZE
+    total = (P.sdr.nsamples - 1) // L                  # strict '<' of receiver.py:543
+    if getattr(P, 'DURATION', None):
+        total = min(total, int(np.ceil(P.DURATION * P.SRATE / L)))
+    lo = getattr(P, 'lo', None)
+    done = 0
+    P.sdr.rewind()
+    while done < total:
+        nb = min(batch_chunks, total - done)
+        x = P.sdr.read_chunk(nb * L)
+        if lo is not None and lo.fo != 0:
+            x = lo.quad_mixer(x)
+        ctx.process_batch(x, nb, L)
+        ams, iqs, cns = [], [], None
+        for irx in range(P.NUM_RX):
+            rx = P.rx[irx]
+            am, iq, cn, pk = ctx.fetch(rx.irx, nb)
+            mode = rx.mode if getattr(rx, 'mode', None) is not None else P.MODE
+            if mode == 'AM' or mode == 'USB':
+                am = am.copy()
+                pos = 0
+                for c in cn:
+                    am[pos:pos + c] -= np.mean(am[pos:pos + c])
+                    pos += c
+            ams.append(am)
+            iqs.append(iq)
+            cns = cn
+            if irx == 0:
+                if P.SAVE_BASEBAND:
+                    P.baseband_iq_io.save_data(iq)
+                if P.SAVE_DEMOD:
+                    P.demod_io.save_data(am)
+        if P.SAVE_IQ:
+            P.raw_iq_io.save_data(x)
+        if on_batch is not None:
+            on_batch(done, ams, iqs, cns)
+        done += nb
+        P.nchunks += nb
+    ex.quit_rx()
+    return done
