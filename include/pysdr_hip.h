@@ -204,6 +204,20 @@ int pysdr_comm_init(pysdr_ctx* ctx, const char id[128], int rank, int nranks);
 int pysdr_comm_bcast(pysdr_ctx* ctx, void* d_buf, size_t bytes, int root);
 int pysdr_comm_destroy(pysdr_ctx* ctx);
 
+/* ---- ingest ring (receiver.py:579-631, soapy.py:33-48) ------------------
+ * The step in front of pysdr_process for a live device: `nslots` pinned host chunk buffers
+ * that sdr.readStream() fills directly, an asynchronous H2D copy on its own stream, the
+ * chunk's kernels behind it and an asynchronous D2H of every sub-receiver's result into pinned
+ * per-slot buffers.  submit() returns at once, so the host assembles chunk k+1 (short reads,
+ * xold carry) while chunk k is copied and demodulated; collect() waits for one slot and hands
+ * out pointers into its result buffers (valid until the slot is submitted again). */
+typedef struct pysdr_ingest pysdr_ingest;
+int  pysdr_ingest_create(pysdr_ctx* ctx, int nslots, pysdr_ingest** out);
+void pysdr_ingest_destroy(pysdr_ingest* ing);
+int  pysdr_ingest_buffer(pysdr_ingest* ing, int slot, float** iq, size_t* cap_samples);
+int  pysdr_ingest_submit(pysdr_ingest* ing, int slot, size_t n);
+int  pysdr_ingest_collect(pysdr_ingest* ing, int slot, pysdr_out* outs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,11 @@ PROTOTYPES = {
     "pysdr_spectrum_sync": (_i, [_vp]),
     "pysdr_spectrum_elapsed_ms": (_i, [_vp, _pf]),
     "pysdr_spectrum_order": (_i, [_vp, _vp, _i]),
+    "pysdr_ingest_create": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "pysdr_ingest_destroy": (None, [_vp]),
+    "pysdr_ingest_buffer": (_i, [_vp, _i, C.POINTER(_pf), C.POINTER(C.c_size_t)]),
+    "pysdr_ingest_submit": (_i, [_vp, _i, C.c_size_t]),
+    "pysdr_ingest_collect": (_i, [_vp, _i, C.POINTER(Out)]),
     "pysdr_waterfall_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "pysdr_waterfall_destroy": (None, [_vp]),
     "pysdr_waterfall_push": (_i, [_vp, _vp, _i, _i]),

@@ -142,6 +142,26 @@ struct pysdr_spectrum {
   hipEvent_t ev_order = nullptr;
 };
 
+// N4: ingest ring.  Pinned host chunk buffers the device reads directly over PCIe (async H2D on
+// its own stream into two device staging buffers) and pinned per-slot result buffers.
+struct pysdr_ingest {
+  pysdr_ctx* c = nullptr;
+  int nslots = 0;
+  size_t cap = 0;                         // samples per chunk buffer
+  int ocap = 0;                           // outputs per RX per chunk
+  hipStream_t copy_stream = nullptr;
+  std::vector<float2*> h_in;              // [nslots] pinned
+  float2* d_in[2] = {nullptr, nullptr};
+  hipEvent_t ev_free[2] = {nullptr, nullptr};   // the kernels that read d_in[i] have finished
+  bool used[2] = {false, false};
+  std::vector<hipEvent_t> ev_copied, ev_done;   // [nslots]
+  std::vector<float*> h_am, h_iq;         // [nslots*MAX_RX] pinned
+  std::vector<float*> h_peak;             // [nslots] pinned
+  std::vector<int> n_out, in_flight;
+  std::vector<int> cx;                    // [nslots*MAX_RX]
+  unsigned long long seq = 0;
+};
+
 namespace {
 
 std::mutex g_rocfft_mu;
@@ -1138,6 +1158,126 @@ int pysdr_dev_copy(int device, void* dst, const void* src, size_t bytes) {
   int rc = use_device(device);
   if (rc) return rc;
   PYSDR_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+  return PYSDR_OK;
+}
+
+// ---------------------------------------------------------------- ingest ring (N4)
+void pysdr_ingest_destroy(pysdr_ingest* g) {
+  if (!g) return;
+  if (g->c) (void)hipSetDevice(g->c->cfg.device);
+  if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+  if (g->c && g->c->stream) (void)hipStreamSynchronize(g->c->stream);
+  for (auto p : g->h_in) if (p) (void)hipHostFree(p);
+  for (auto p : g->h_am) if (p) (void)hipHostFree(p);
+  for (auto p : g->h_iq) if (p) (void)hipHostFree(p);
+  for (auto p : g->h_peak) if (p) (void)hipHostFree(p);
+  for (int i = 0; i < 2; ++i) {
+    if (g->d_in[i]) (void)hipFree(g->d_in[i]);
+    if (g->ev_free[i]) (void)hipEventDestroy(g->ev_free[i]);
+  }
+  for (auto e : g->ev_copied) if (e) (void)hipEventDestroy(e);
+  for (auto e : g->ev_done) if (e) (void)hipEventDestroy(e);
+  if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
+  delete g;
+}
+
+int pysdr_ingest_create(pysdr_ctx* c, int nslots, pysdr_ingest** out) {
+  if (!c || !out || nslots < 2 || nslots > 64) return PYSDR_ERR_ARG;
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  pysdr_ingest* g = new pysdr_ingest();
+  g->c = c; g->nslots = nslots;
+  g->cap = (size_t)c->cfg.in_chunk;
+  g->ocap = (int)((g->cap * (size_t)c->cfg.up) / (size_t)c->cfg.down) + 8;
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_error("pysdr_ingest_create: %s -> %s", #e, hipGetErrorString(_e)); pysdr_ingest_destroy(g); return PYSDR_ERR_HIP; } } while (0)
+  CK(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+  g->h_in.assign(nslots, nullptr);
+  g->ev_copied.assign(nslots, nullptr);
+  g->ev_done.assign(nslots, nullptr);
+  g->h_am.assign((size_t)nslots * PYSDR_MAX_RX, nullptr);
+  g->h_iq.assign((size_t)nslots * PYSDR_MAX_RX, nullptr);
+  g->h_peak.assign(nslots, nullptr);
+  g->n_out.assign(nslots, 0);
+  g->in_flight.assign(nslots, 0);
+  g->cx.assign((size_t)nslots * PYSDR_MAX_RX, 0);
+  for (int s = 0; s < nslots; ++s) {
+    CK(hipHostMalloc(reinterpret_cast<void**>(&g->h_in[s]), g->cap * sizeof(float2), hipHostMallocDefault));
+    CK(hipHostMalloc(reinterpret_cast<void**>(&g->h_peak[s]), sizeof(float), hipHostMallocDefault));
+    CK(hipEventCreateWithFlags(&g->ev_copied[s], hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&g->ev_done[s], hipEventDisableTiming));
+    for (int r = 0; r < PYSDR_MAX_RX; ++r) {
+      CK(hipHostMalloc(reinterpret_cast<void**>(&g->h_am[(size_t)s * PYSDR_MAX_RX + r]), (size_t)g->ocap * sizeof(float2), hipHostMallocDefault));
+      CK(hipHostMalloc(reinterpret_cast<void**>(&g->h_iq[(size_t)s * PYSDR_MAX_RX + r]), (size_t)g->ocap * sizeof(float2), hipHostMallocDefault));
+    }
+  }
+  for (int i = 0; i < 2; ++i) {
+    CK(hipMalloc(&g->d_in[i], g->cap * sizeof(float2)));
+    CK(hipEventCreateWithFlags(&g->ev_free[i], hipEventDisableTiming));
+  }
+#undef CK
+  *out = g;
+  return PYSDR_OK;
+}
+
+int pysdr_ingest_buffer(pysdr_ingest* g, int slot, float** iq, size_t* cap_samples) {
+  if (!g || !iq || slot < 0 || slot >= g->nslots) return PYSDR_ERR_ARG;
+  if (g->in_flight[slot]) { set_last_error("pysdr_ingest_buffer: slot %d is in flight (collect it first)", slot); return PYSDR_ERR_STATE; }
+  *iq = reinterpret_cast<float*>(g->h_in[slot]);
+  if (cap_samples) *cap_samples = g->cap;
+  return PYSDR_OK;
+}
+
+int pysdr_ingest_submit(pysdr_ingest* g, int slot, size_t n) {
+  if (!g || slot < 0 || slot >= g->nslots || n < 1 || n > g->cap) return PYSDR_ERR_ARG;
+  if (g->in_flight[slot]) { set_last_error("pysdr_ingest_submit: slot %d is already in flight", slot); return PYSDR_ERR_STATE; }
+  pysdr_ctx* c = g->c;
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  const int b = (int)(g->seq & 1ull);
+  // the copy may not overwrite a staging buffer the kernels of two chunks ago still read
+  if (g->used[b]) PYSDR_HIP_CHECK(hipStreamWaitEvent(g->copy_stream, g->ev_free[b], 0));
+  PYSDR_HIP_CHECK(hipMemcpyAsync(g->d_in[b], g->h_in[slot], n * sizeof(float2), hipMemcpyHostToDevice, g->copy_stream));
+  PYSDR_HIP_CHECK(hipEventRecord(g->ev_copied[slot], g->copy_stream));
+  PYSDR_HIP_CHECK(hipStreamWaitEvent(c->stream, g->ev_copied[slot], 0));
+  rc = pysdr_process_batch(c, g->d_in[b], 1, n, 1);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipEventRecord(g->ev_free[b], c->stream));
+  g->used[b] = true;
+  const int nout = c->last_nout;
+  if (nout > g->ocap) { set_last_error("pysdr_ingest_submit: %d outputs > capacity %d", nout, g->ocap); return PYSDR_ERR_STATE; }
+  g->n_out[slot] = nout;
+  for (int r = 0; r < c->nrx; ++r) {
+    const int cx = c->last_complex[r];
+    g->cx[(size_t)slot * PYSDR_MAX_RX + r] = cx;
+    if (nout > 0) {
+      PYSDR_HIP_CHECK(hipMemcpyAsync(g->h_am[(size_t)slot * PYSDR_MAX_RX + r], c->rx[r].d_am,
+                                     (size_t)nout * (cx ? 2 : 1) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+      PYSDR_HIP_CHECK(hipMemcpyAsync(g->h_iq[(size_t)slot * PYSDR_MAX_RX + r], c->rx[r].d_y + c->hy,
+                                     (size_t)nout * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  PYSDR_HIP_CHECK(hipMemcpyAsync(g->h_peak[slot], c->d_peak, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipEventRecord(g->ev_done[slot], c->stream));
+  g->in_flight[slot] = 1;
+  g->seq += 1;
+  return PYSDR_OK;
+}
+
+int pysdr_ingest_collect(pysdr_ingest* g, int slot, pysdr_out* outs) {
+  if (!g || !outs || slot < 0 || slot >= g->nslots) return PYSDR_ERR_ARG;
+  if (!g->in_flight[slot]) { set_last_error("pysdr_ingest_collect: slot %d was not submitted", slot); return PYSDR_ERR_STATE; }
+  int rc = use_device(g->c->cfg.device);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipEventSynchronize(g->ev_done[slot]));
+  for (int r = 0; r < g->c->nrx; ++r) {
+    outs[r].am = g->h_am[(size_t)slot * PYSDR_MAX_RX + r];
+    outs[r].iq = g->h_iq[(size_t)slot * PYSDR_MAX_RX + r];
+    outs[r].cap = g->ocap;
+    outs[r].n_out = g->n_out[slot];
+    outs[r].am_is_complex = g->cx[(size_t)slot * PYSDR_MAX_RX + r];
+    outs[r].peak_in = *g->h_peak[slot];
+  }
+  g->in_flight[slot] = 0;
   return PYSDR_OK;
 }
 

@@ -46,7 +46,12 @@ def demodulate_data(P, x, irx):
     """One sub-receiver, one chunk (``receiver.py:231-297``)."""
     rx = P.rx[irx]
     am = rx.demod_data(x)
+    return post_demod(P, x, irx, am)
 
+
+def post_demod(P, x, irx, am):
+    """Everything ``demodulate_data`` does behind ``rx.demod_data(x)`` (``receiver.py:238-297``)."""
+    rx = P.rx[irx]
     if getattr(P, 'ENABLE_AUTO_MUTE', False):           # receiver.py:238-245
         P.AUTO_MUTED = bool(rx.auto_mute(x))
 
@@ -224,6 +229,60 @@ class SDR_EXECUTIVE:
             if on_chunk is not None:
                 on_chunk(self)
             P.RX_DONE = P.RX_DONE or t >= P.DURATION
+        self.quit_rx()
+
+    def Run_pipelined(self, on_chunk=None, nslots=3):
+        """``Run`` with the ingest ring (N4): ``self.x`` is a pinned ring slot, the chunk is
+        submitted asynchronously and its audio is post-processed one chunk later, while the
+        next chunk is being read.  Same chunks, same order, same results as ``Run``."""
+        from .ingest import IngestRing
+        P = self.P
+        ring = IngestRing(P._pysdr_stream, nslots)
+        dt = float(P.IN_CHUNK_SIZE) / P.SRATE
+        t = 0.0
+        self.Startup()
+        slot, pending = 0, None
+
+        def finish(ps):
+            res = ring.collect(ps)
+            xs = ring.buffer(ps)
+            for irx in range(P.NUM_RX):
+                rx = P.rx[irx]
+                rx.am, rx.iq, rx.peak_in = res[irx]
+                post_demod(P, xs, irx, rx.am)
+            audio_out(P)
+            if P.SHOW_RF_PSD:
+                P.rb_rf.push(xs.copy())
+            if P.SAVE_IQ:
+                P.raw_iq_io.save_data(xs)
+            if on_chunk is not None:
+                self.x = xs
+                on_chunk(self)
+
+        try:
+            while not P.RX_DONE:
+                t += dt
+                P.nchunks += 1
+                if P.Stopper and P.Stopper.is_set():
+                    P.RX_DONE = True
+                    break
+                self.x = ring.buffer(slot)
+                self.read_chunk()
+                if P.RX_DONE:
+                    break
+                if self.x is not ring.buffer(slot):         # replay hands back its own array
+                    ring.buffer(slot)[:] = self.x
+                self.mode_freq_change()
+                ring.submit(slot, P.IN_CHUNK_SIZE)
+                if pending is not None:
+                    finish(pending)
+                pending = slot
+                slot = (slot + 1) % nslots
+                P.RX_DONE = P.RX_DONE or t >= P.DURATION
+            if pending is not None:
+                finish(pending)
+        finally:
+            ring.close()
         self.quit_rx()
 
     # -- receiver.py:461-500
