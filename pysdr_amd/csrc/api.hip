@@ -1040,11 +1040,14 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
                         int db, float* d_out) {
   int rc;
   if (is_complex && sp->chunk == 32768 && sp->nfft == 65536 && !getenv("PYSDR_PSD_ROCFFT")) {
-    // the RF-waterfall size: fused four-step transform, in groups of frames (grid.y limit).
-    // Small groups would keep the 512 KB/frame intermediate in the Infinity Cache, but that
-    // measured no faster than HBM (scripts/mall_test.hip), so the groups are large.
+    // the RF-waterfall size: fused four-step transform, in groups of 256 frames: the 128 MB
+    // of intermediate of one group then stays in the 256 MB Infinity Cache between the two
+    // kernels (measured 3.04 ms per 10666 frames against 3.45 ms for groups of 4096 and
+    // 3.48 ms for 512, whose 256 MB no longer fit; below 128 frames launch gaps dominate).
+    // Running the rows of group g beside the columns of group g+1 on a second stream was
+    // tried and is slower (3.9 ms): the two working sets evict each other.
     const char* ge = getenv("PYSDR_PSD_GROUP");
-    int group = ge ? atoi(ge) : 4096;
+    int group = ge ? atoi(ge) : 256;
     if (group < 1) group = 1;
     PYSDR_HIP_CHECK(hipEventRecord(sp->ev[0], sp->stream));
     for (int f0 = 0; f0 < nframes; f0 += group) {
