@@ -131,7 +131,8 @@ struct pysdr_spectrum {
   int device = 0, chunk = 0, nfft = 0, max_frames = 0;
   hipStream_t stream = nullptr;
   float* d_win = nullptr;
-  float2* d_work = nullptr;   // [max_frames][nfft]
+  float2* d_work = nullptr;   // [work_frames][nfft], grown on demand
+  size_t work_frames = 0;
   float2* d_in = nullptr;     // [chunk] staging for host frames
   float* d_out = nullptr;     // [nfft] staging for host frames
   void* d_fftwork = nullptr;
@@ -1001,7 +1002,6 @@ int pysdr_spectrum_create(int device, int chunk_size, int nfft, int max_frames, 
   CK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
   CK(hipMalloc(&sp->d_win, (size_t)chunk_size * sizeof(float)));
   CK(hipMemcpy(sp->d_win, window, (size_t)chunk_size * sizeof(float), hipMemcpyHostToDevice));
-  CK(hipMalloc(&sp->d_work, (size_t)max_frames * nfft * sizeof(float2)));
   CK(hipMalloc(&sp->d_in, (size_t)chunk_size * sizeof(float2)));
   CK(hipMalloc(&sp->d_out, (size_t)nfft * sizeof(float)));
   CK(hipEventCreate(&sp->ev[0]));
@@ -1036,6 +1036,18 @@ void pysdr_spectrum_destroy(pysdr_spectrum* sp) {
   if (--g_rocfft_users == 0) rocfft_cleanup();
 }
 
+// the transform's work area: `frames` frames of nfft complex (the 64k path only ever needs one
+// group of frames, the rocFFT path the whole batch)
+static int ensure_work(pysdr_spectrum* sp, size_t frames) {
+  if (sp->work_frames >= frames) return PYSDR_OK;
+  PYSDR_HIP_CHECK(hipStreamSynchronize(sp->stream));
+  if (sp->d_work) PYSDR_HIP_CHECK(hipFree(sp->d_work));
+  sp->d_work = nullptr; sp->work_frames = 0;
+  PYSDR_HIP_CHECK(hipMalloc(&sp->d_work, frames * (size_t)sp->nfft * sizeof(float2)));
+  sp->work_frames = frames;
+  return PYSDR_OK;
+}
+
 static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int nframes, int is_complex,
                         int db, float* d_out) {
   int rc;
@@ -1049,6 +1061,8 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
     const char* ge = getenv("PYSDR_PSD_GROUP");
     int group = ge ? atoi(ge) : 256;
     if (group < 1) group = 1;
+    rc = ensure_work(sp, (size_t)std::min(group, nframes));
+    if (rc) return rc;
     PYSDR_HIP_CHECK(hipEventRecord(sp->ev[0], sp->stream));
     for (int f0 = 0; f0 < nframes; f0 += group) {
       const int nf = (nframes - f0 < group) ? nframes - f0 : group;
@@ -1061,6 +1075,8 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
   }
   rocfft_plan plan;
   rc = get_plan(sp, nframes, &plan);
+  if (rc) return rc;
+  rc = ensure_work(sp, (size_t)nframes);
   if (rc) return rc;
   PYSDR_HIP_CHECK(hipEventRecord(sp->ev[0], sp->stream));
   rc = launch_psd_pre(d_x, hop, nframes, sp->chunk, sp->nfft, sp->d_win, sp->d_work, is_complex, sp->stream);
