@@ -33,6 +33,26 @@ __device__ __forceinline__ float2 expmpi(float t) {
   return make_float2(__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev));
 }
 
+// Explicit global-address-space accesses: the unit bodies below are also compiled inside
+// non-kernel functions (scripts/experiments), where a generic pointer would turn into
+// flat_load / flat_store.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+#define PYSDR_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ float2 ldg2(const float2* p) {
+  const v2f_t v = *(const PYSDR_AS1 v2f_t*)p;
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void stg2(float2* p, float2 v) {
+  const v2f_t w = {v.x, v.y};
+  *(PYSDR_AS1 v2f_t*)p = w;
+}
+__device__ __forceinline__ float ldg1(const float* p) {
+  return *(const PYSDR_AS1 float*)p;
+}
+__device__ __forceinline__ void stg1(float* p, float v) {
+  *(PYSDR_AS1 float*)p = v;
+}
+
 // 4-point DFT in place (W4 = -j): (a,b,c,d) -> (X0,X1,X2,X3)
 __device__ __forceinline__ void dft4(float2& a, float2& b, float2& c, float2& d) {
   const float2 s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
@@ -114,8 +134,8 @@ __device__ __forceinline__ void cols_unit(const float2* __restrict__ xf, const f
 #pragma unroll
     for (int a1 = 0; a1 < 8; ++a1) {
       const int n = 256 * (a0 + 16 * a1) + bb;
-      const float2 s = xf[n];
-      const float g = win[n];
+      const float2 s = ldg2(xf + n);
+      const float g = ldg1(win + n);
       u[a1] = make_float2(s.x * g, s.y * g);
     }
 #pragma unroll
@@ -139,7 +159,7 @@ __device__ __forceinline__ void cols_unit(const float2* __restrict__ xf, const f
                  expmpi((float)(bb * p1) * (1.0f / 32768.0f)));
     float2* o = yf + (size_t)p1 * 256 + bb;
 #pragma unroll
-    for (int p0 = 0; p0 < 16; ++p0) o[(size_t)p0 * 16 * 256] = v[p0];
+    for (int p0 = 0; p0 < 16; ++p0) stg2(o + (size_t)p0 * 16 * 256, v[p0]);
   }
 }
 
@@ -167,11 +187,12 @@ constexpr int kRowLds = 16 * 544;
 template <bool kBypassL1>
 __device__ __forceinline__ float2 load_work(const float2* p) {
   if (kBypassL1) {
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long v = __hip_atomic_load(
+        (const PYSDR_AS1 unsigned long long*)p,
+        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_float2(__uint_as_float((unsigned)(v & 0xffffffffull)), __uint_as_float((unsigned)(v >> 32)));
   }
-  return *p;
+  return ldg2(p);
 }
 
 // one unit = 32 rows [32 rb, 32 rb + 32) of frame yf, 512 threads, LDS kRowLds
@@ -204,7 +225,7 @@ __device__ __forceinline__ void rows_unit(const float2* yf, float* __restrict__ 
       const int k = kb + 4096 * q0;
       float pw = v[q0].x * v[q0].x + v[q0].y * v[q0].y;
       if (db) pw = 10.f * log10f(pw + 1.0e-30f);
-      of[(k + kM) & (kN - 1)] = pw;
+      stg1(of + ((k + kM) & (kN - 1)), pw);
     }
   }
 }
