@@ -20,32 +20,54 @@ __device__ __forceinline__ uint32_t block_of(const Stage2Args& a, int r, int i) 
   return (t / (uint32_t)a.up) / a.chunk_len;
 }
 
-// ---- AM-Synch carrier PLL (rx.demod.am_pll, receiver.py:649): inherently serial,
-// one lane per RX; writes v = y*exp(-j*theta) for the detector stage.
-__global__ void pll_kernel(const Stage2Args a) {
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// ---- AM-Synch carrier PLL (rx.demod.am_pll, receiver.py:649): inherently serial (theta
+// feeds back through sin/cos and atan2).  One wave per RX, blocks of 64 samples loaded
+// coalesced and broadcast with v_readlane; every lane runs the same recursion, lane j keeps
+// v = y*exp(-j*theta) of sample j for the detector stage, stored coalesced.  Nothing but
+// arithmetic sits on the critical path (sin/cos by v_sin/v_cos on theta/2pi).
+__global__ __launch_bounds__(64) void pll_kernel(const Stage2Args a) {
   const int r = blockIdx.x;
-  if (threadIdx.x != 0 || a.det[r] != kDetPll) return;
+  const int lane = threadIdx.x;
+  if (a.det[r] != kDetPll) return;
   RxDevState* st = a.state + r;
   float th = st->pll_theta, w = st->pll_w;
   const float kp = a.pll_kp, ki = a.pll_ki;
   const float pi = 3.14159265358979323846f, twopi = 6.28318530717958647692f;
+  const float inv2pi = 0.15915494309189533577f;
   const float2* y = a.y[r];
   float2* o = a.ypll[r];
-  for (int i = 0; i < a.n_out; ++i) {
-    float s, c;
-    sincosf(th, &s, &c);
-    const float2 yy = y[i];
-    const float vr = yy.x * c + yy.y * s;
-    const float vi = yy.y * c - yy.x * s;
-    const float e = atan2f(vi, vr);
-    w = w + ki * e;
-    th = th + (w + kp * e);
-    if (th >= pi) th -= twopi;
-    else if (th < -pi) th += twopi;
-    o[i] = make_float2(vr, vi);
+  const int n = a.n_out;
+  float2 y_next = (lane < n) ? y[lane] : make_float2(0.f, 0.f);
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const float2 yv = y_next;
+    const int nidx = i0 + 64 + lane;
+    y_next = (nidx < n) ? y[nidx] : make_float2(0.f, 0.f);     // in flight during the steps below
+    float2 mine = make_float2(0.f, 0.f);
+    const int count = (n - i0 < 64) ? n - i0 : 64;
+#pragma unroll 4
+    for (int j = 0; j < count; ++j) {
+      const float yr = lane_bcast(yv.x, j), yi = lane_bcast(yv.y, j);
+      const float rev = th * inv2pi;
+      const float s = __builtin_amdgcn_sinf(rev), c = __builtin_amdgcn_cosf(rev);
+      const float vr = yr * c + yi * s;
+      const float vi = yi * c - yr * s;
+      const float e = atan2f(vi, vr);
+      w = w + ki * e;
+      th = th + (w + kp * e);
+      if (th >= pi) th -= twopi;
+      else if (th < -pi) th += twopi;
+      if (lane == j) mine = make_float2(vr, vi);
+    }
+    if (lane < count) o[i0 + lane] = mine;
   }
-  st->pll_theta = th;
-  st->pll_w = w;
+  if (lane == 0) {
+    st->pll_theta = th;
+    st->pll_w = w;
+  }
 }
 
 // ---- detector + AF FIR + block peak.  grid = (tiles, nrx), 2048 outputs per workgroup,
@@ -86,10 +108,6 @@ __device__ __forceinline__ float2 detect(const Stage2Args& a, int r, int det, co
     d = yc;
   }
   return d;
-}
-
-__device__ __forceinline__ float lane_bcast(float v, int lane) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
 // One tap for the kW outputs of a lane (window slots rotate instead of moving registers).
@@ -384,29 +402,64 @@ __global__ __launch_bounds__(256) void wfm_disc_kernel(const WfmArgs a) {
   a.w[r][i] = make_float2(atan2f(im, re) * a.scale, 0.f);
 }
 
-__global__ void wfm_pll_kernel(const WfmArgs a) {
+// 19 kHz pilot PLL of the stereo decoder: an inherently serial recursion (the phase feeds
+// back through cos).  One wave per RX walks the IF samples in blocks of 64: the block's mpx
+// values are loaded coalesced (lane i = sample i) and broadcast with v_readlane, every lane
+// runs the same recursion (ten dependent VALU operations per sample, cos by v_cos_f32 on the
+// exact 32-bit phase), lane i keeps the phase of sample i, and the 38 kHz carrier
+// sin(2*theta) and the output are then computed by all lanes at once.  No memory access sits
+// on the recursion's critical path (the first version loaded and stored per sample and called
+// cospif/sinpif: 250 ns per sample; now ~30 ns).
+__device__ __forceinline__ void wfm_pll_step(float mj, uint32_t& ph, float& w, const WfmArgs& a) {
+  const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+  const float c = __builtin_amdgcn_cosf(rev);
+  const float e = __fmul_rn(__fmul_rn(mj, c), a.norm);
+  w = __fadd_rn(w, __fmul_rn(a.ki, e));
+  const int corr = __float2int_rn(__fmul_rn(__fadd_rn(w, __fmul_rn(a.kp, e)), a.rad2word));
+  ph = ph + a.fword0 + (uint32_t)corr;
+}
+
+__global__ __launch_bounds__(64) void wfm_pll_kernel(const WfmArgs a) {
   const int r = blockIdx.x;
-  if (threadIdx.x != 0) return;
+  const int lane = threadIdx.x;
   // roll the 1-sample IF history for the next call (disc kernel is done: same stream)
-  if (a.n1 > 0) a.y1base[r][1] = a.y1[r][a.n1 - 1];
+  if (lane == 0 && a.n1 > 0) a.y1base[r][1] = a.y1[r][a.n1 - 1];
   if (!a.stereo[r]) return;
   RxDevState* st = a.state + r;
   uint32_t ph = st->wfm_phase;
   float w = st->wfm_w;
   float2* o = a.w[r];
-  for (int i = 0; i < a.n1; ++i) {
-    const float m = o[i].x;
-    const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
-    const float c = cospif(2.f * rev);        // exact argument scaling: 2*rev, 4*rev are exact
-    const float s2 = sinpif(4.f * rev);
-    const float e = __fmul_rn(__fmul_rn(m, c), a.norm);
-    o[i] = make_float2(m, __fmul_rn(m, __fmul_rn(2.f, s2)));
-    w = __fadd_rn(w, __fmul_rn(a.ki, e));
-    const int corr = __float2int_rn(__fmul_rn(__fadd_rn(w, __fmul_rn(a.kp, e)), a.rad2word));
-    ph = ph + a.fword0 + (uint32_t)corr;
+  float m_next = (lane < a.n1) ? o[lane].x : 0.f;
+  for (int i0 = 0; i0 < a.n1; i0 += 64) {
+    const float m = m_next;
+    const int nidx = i0 + 64 + lane;
+    m_next = (nidx < a.n1) ? o[nidx].x : 0.f;             // in flight during the 64 steps below
+    uint32_t myph = 0u;
+    const int count = (a.n1 - i0 < 64) ? a.n1 - i0 : 64;
+    if (count == 64) {
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        const float mj = lane_bcast(m, j);
+        myph = (lane == j) ? ph : myph;
+        wfm_pll_step(mj, ph, w, a);
+      }
+    } else {
+      for (int j = 0; j < count; ++j) {
+        const float mj = lane_bcast(m, j);
+        myph = (lane == j) ? ph : myph;
+        wfm_pll_step(mj, ph, w, a);
+      }
+    }
+    if (lane < count) {
+      const float rev = (float)(int)myph * (1.0f / 4294967296.0f);
+      const float s2 = __builtin_amdgcn_sinf(2.f * rev);
+      o[i0 + lane] = make_float2(m, __fmul_rn(m, __fmul_rn(2.f, s2)));
+    }
   }
-  st->wfm_phase = ph;
-  st->wfm_w = w;
+  if (lane == 0) {
+    st->wfm_phase = ph;
+    st->wfm_w = w;
+  }
 }
 
 }  // namespace
