@@ -200,6 +200,21 @@ def test_long_prototype_1001_taps_and_10msps():
     run_both(cfg, [L] * 3, seed=9)
 
 
+def test_eight_rx_long_prototype_fills_the_lds():
+    """8 sub-receivers x 1001 taps at UP = 3: 64 KB of LO-modulated taps share the 160 KB LDS with
+    the two tile buffers and the output stage (the tile shrinks; pysdr_create's worst case)."""
+    r0 = so.CONFIGS['C1']['rx'][0]
+    modes = ['AM', 'USB', 'CW', 'NFM', 'LSB', 'AM', 'IQ', 'AM-Synch']
+    cfg = dict(so.CONFIGS['C1'],
+               carriers=[dict(f=100e3 + 40e3 * i, kind='fm', amp=0.1, tone=1000.0, dev=3000.0) if m == 'NFM' else
+                         dict(f=100e3 + 40e3 * i, kind='am', amp=0.1, tone=500.0 + 100 * i, depth=0.5)
+                         for i, m in enumerate(modes)],
+               rx=[dict(r0, frq=100e3 + 40e3 * i, mode=m, af_bw=3e3, bfo=700.0 if m == 'CW' else 0.0)
+                   for i, m in enumerate(modes)])
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    run_both(cfg, [L, L - 7, L + 11, 3 * L], seed=19)
+
+
 def test_quad_mixer_matches_oracle_nco():
     from pysdr_amd import sig_proc
     rng = np.random.default_rng(10)
