@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
     ap.add_argument("--chunks", type=int, default=2048, help="chunks per step (batch resident in HBM)")
     ap.add_argument("--no-psd", action="store_true")
+    ap.add_argument("--no-cpu-mp", action="store_true", help="skip the one-process-per-RX CPU figure")
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seed", type=int, default=10, help=argparse.SUPPRESS)
     ap.add_argument("--overlap-psd", action="store_true", help="PSD on its own stream, unordered w.r.t. the demod")
     ap.add_argument("--no-demod", action="store_true", help="diagnostic: PSD only")
     ap.add_argument("--tile-bytes", type=int, default=0)
@@ -98,6 +101,69 @@ def cpu_baseline(cfg, nchunks, with_psd, seed):
                        f"{dt:.1f} s wall; host has {os.cpu_count()} cores")
 
 
+def _cpu_worker(job):
+    """One process of the NUM_RX-cores baseline: sub-receiver `irx` (or the PSD when irx < 0)
+    over the same chunks; returns its own wall time."""
+    cfg, nchunks, seed, irx = job
+    from oracle import sdr_oracle as so
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:
+        pass
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    uniq = 8
+    x = so.synth_iq(cfg, uniq * L, seed)
+    if irx >= 0:
+        rx = so.make_receivers(cfg, np.float32)[irx]
+        rx.demod_data(x[:L])
+        t0 = time.perf_counter()
+        for k in range(nchunks):
+            rx.demod_data(x[(k % uniq) * L:(k % uniq + 1) * L])
+        return time.perf_counter() - t0
+    sp = so.Spectrum(cfg['fs'] / 1e3, PSD_CHUNK, PSD_NFFT, 0.0, np.float32)
+    t0 = time.perf_counter()
+    for k in range(nchunks):
+        xc = x[(k % uniq) * L:(k % uniq + 1) * L]
+        for i in range(0, L - PSD_CHUNK + 1, PSD_CHUNK):
+            sp.periodogram(xc[i:i + PSD_CHUNK], True)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_per_rx(workload, cfg, nchunks, with_psd, seed):
+    """The analogue of the reference's MP_SCHEME 3 (one process per sub-receiver,
+    receiver.py:726-739): NUM_RX (+1 for the PSD) single-threaded child processes
+    (`bench.py --cpu-worker`, plain subprocesses with a deadline: the parent holds a HIP context
+    and must neither fork it nor ever wait forever) over the same sample; the job's rate is set
+    by the slowest of them.  Returns None if a child fails."""
+    import subprocess
+    from oracle import sdr_oracle as so
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    ids = list(range(len(cfg['rx']))) + ([-1] if with_psd else [])
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--workload", workload,
+                               "--cpu-chunks", str(nchunks), "--cpu-seed", str(seed)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT)
+             for i in ids]
+    times = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=240)
+            times.append(float(out.strip().splitlines()[-1]))
+    except Exception:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return None
+    wall = time.perf_counter() - t0
+    dt = max(times)
+    return dict(value=nchunks * L / dt / 1e6, unit="MS/s", cores=len(ids), kind="port",
+                sample=f"{nchunks} chunks x {L} samples, one process per sub-receiver"
+                       f"{' + one for the 64k PSD' if with_psd else ''}, slowest {dt:.1f} s "
+                       f"({', '.join('%.1f' % t for t in times)}), {wall:.1f} s wall incl. start-up")
+
+
 def measured_traffic(args, nrx, B):
     """HBM bytes per mix+decimate launch from the committed PMC passes (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE), valid only for the configuration that was profiled."""
@@ -112,6 +178,10 @@ def measured_traffic(args, nrx, B):
 
 def main():
     args = parse()
+    if args.cpu_worker is not None:      # child of cpu_baseline_per_rx: CPU only, never touches the GPU
+        from pysdr_amd.synth import CONFIGS
+        print(_cpu_worker((CONFIGS[args.workload.upper()], args.cpu_chunks, args.cpu_seed, args.cpu_worker)))
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -277,6 +347,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_chunks, with_psd, 10)
+        if not args.no_cpu_mp:
+            out["cpu_baseline_per_rx_process"] = cpu_baseline_per_rx(args.workload, cfg, args.cpu_chunks, with_psd, 10)
     elif rank == 0:
         out["cpu_baseline"] = None
 
