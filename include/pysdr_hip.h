@@ -210,7 +210,8 @@ int pysdr_comm_destroy(pysdr_ctx* ctx);
  * chunk's kernels behind it and an asynchronous D2H of every sub-receiver's result into pinned
  * per-slot buffers.  submit() returns at once, so the host assembles chunk k+1 (short reads,
  * xold carry) while chunk k is copied and demodulated; collect() waits for one slot and hands
- * out pointers into its result buffers (valid until the slot is submitted again). */
+ * out pointers into its result buffers (valid until the slot is submitted again).  Destroy the
+ * ring before the context it was created on. */
 typedef struct pysdr_ingest pysdr_ingest;
 int  pysdr_ingest_create(pysdr_ctx* ctx, int nslots, pysdr_ingest** out);
 void pysdr_ingest_destroy(pysdr_ingest* ing);

@@ -24,6 +24,9 @@ class IngestRing:
         h = C.c_void_p()
         check(self.L.pysdr_ingest_create(ctx.h, self.nslots, C.byref(h)), "pysdr_ingest_create")
         self.h = h
+        if not hasattr(ctx, '_rings'):
+            ctx._rings = []
+        ctx._rings.append(self)
         self._bufs = []
         for s in range(self.nslots):
             p = C.POINTER(C.c_float)()
@@ -63,6 +66,8 @@ class IngestRing:
         if self.h:
             self.L.pysdr_ingest_destroy(self.h)
             self.h = None
+            if self in getattr(self.ctx, '_rings', []):
+                self.ctx._rings.remove(self)
 
     def __del__(self):
         if sys is None or sys.is_finalizing():

@@ -63,6 +63,9 @@ class _StreamContext:
 
     def close(self):
         if self.h:
+            # dependants hold raw pointers into the context: they go first
+            for ring in list(getattr(self, '_rings', [])):
+                ring.close()
             self.L.pysdr_destroy(self.h)
             self.h = None
 
