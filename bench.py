@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seed", type=int, default=10, help=argparse.SUPPRESS)
     ap.add_argument("--overlap-psd", action="store_true", help="PSD on its own stream, unordered w.r.t. the demod")
+    ap.add_argument("--serial-psd", action="store_true", help="PSD strictly behind the whole demod (incl. stage 2)")
     ap.add_argument("--no-demod", action="store_true", help="diagnostic: PSD only")
     ap.add_argument("--tile-bytes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
@@ -239,7 +240,9 @@ def main():
             # both HBM-bound, so overlapping them on two streams buys nothing and only smears
             # the per-kernel timings; --overlap-psd restores the two-stream form.
             if not args.overlap_psd and not args.no_demod:
-                _lib.check(lib.pysdr_spectrum_order(sp, ctx.h, 0), "spectrum_order")
+                # behind the mix+decimate kernel only: the (VALU-bound) audio-rate stages run
+                # beside the (memory-bound) PSD kernels
+                _lib.check(lib.pysdr_spectrum_order(sp, ctx.h, 0 if args.serial_psd else 2), "spectrum_order")
             _lib.check(lib.pysdr_spectrum_batch(sp, d_x, nframes, PSD_CHUNK, d_psd), "spectrum_batch")
             if not args.overlap_psd and not args.no_demod:
                 _lib.check(lib.pysdr_spectrum_order(sp, ctx.h, 1), "spectrum_order")

@@ -172,7 +172,9 @@ int pysdr_spectrum_elapsed_ms(pysdr_spectrum* sp, float* ms);
 /* Ordering between the spectrum's stream and a receiver context's stream (both read the same
  * device-resident chunk; Plotting.py:462 runs the PSD after the chunk's demod in one thread):
  * direction 0: spectrum work queued from now on starts after everything queued on ctx so far;
- * direction 1: ctx work queued from now on starts after everything queued on sp so far. */
+ * direction 1: ctx work queued from now on starts after everything queued on sp so far;
+ * direction 2: like 0, but only behind the FRONT END (mix + decimate) of ctx's last process call --
+ *   the PSD reads the same input and may run beside the audio-rate stages. */
 int pysdr_spectrum_order(pysdr_spectrum* sp, pysdr_ctx* ctx, int direction);
 
 /* ---- waterfall numeric back-end (three_box_plot.plot, Plotting.py:536-626; shift_waterfall

@@ -121,6 +121,7 @@ struct pysdr_ctx {
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
   hipEvent_t ev[kSlots][4] = {};
+  hipEvent_t ev_front = nullptr;          // the input of the last call has been consumed (front end done)
   unsigned long long ncalls = 0;
   // RCCL
   void* rccl_lib = nullptr;
@@ -490,6 +491,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   CK(hipMemset(c->d_state, 0, PYSDR_MAX_RX * sizeof(RxDevState)));
   for (int k = 0; k < pysdr_ctx::kSlots; ++k)
     for (int i = 0; i < 4; ++i) CK(hipEventCreate(&c->ev[k][i]));
+  CK(hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming));
 #undef CK
   *out = c;
   return PYSDR_OK;
@@ -523,6 +525,7 @@ void pysdr_destroy(pysdr_ctx* c) {
   if (c->d_state) (void)hipFree(c->d_state);
   for (int k = 0; k < pysdr_ctx::kSlots; ++k)
     for (int i = 0; i < 4; ++i) if (c->ev[k][i]) (void)hipEventDestroy(c->ev[k][i]);
+  if (c->ev_front) (void)hipEventDestroy(c->ev_front);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -810,6 +813,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   }
   const int n_out = res.n_out;
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[1], c->stream));
+  PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream));
 
   Stage2Args s;
   memset(&s, 0, sizeof(s));
@@ -1132,9 +1136,13 @@ int pysdr_spectrum_elapsed_ms(pysdr_spectrum* sp, float* ms) {
 }
 
 int pysdr_spectrum_order(pysdr_spectrum* sp, pysdr_ctx* c, int direction) {
-  if (!sp || !c || (direction != 0 && direction != 1) || sp->device != c->cfg.device) return PYSDR_ERR_ARG;
+  if (!sp || !c || direction < 0 || direction > 2 || sp->device != c->cfg.device) return PYSDR_ERR_ARG;
   int rc = use_device(sp->device);
   if (rc) return rc;
+  if (direction == 2) {
+    PYSDR_HIP_CHECK(hipStreamWaitEvent(sp->stream, c->ev_front, 0));
+    return PYSDR_OK;
+  }
   if (!sp->ev_order) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&sp->ev_order, hipEventDisableTiming));
   hipStream_t first = direction == 0 ? c->stream : sp->stream;
   hipStream_t then = direction == 0 ? sp->stream : c->stream;
