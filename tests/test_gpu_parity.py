@@ -108,6 +108,35 @@ def test_ragged_and_tiny_chunks(chunks):
     run_both(cfg, chunks, seed=4)
 
 
+@pytest.mark.parametrize("fs,ntaps", [(2.4e6, 255), (1.8e6, 127), (2.048e6, 1001), (10e6, 255), (6.144e6, 63)])
+def test_random_call_lengths_across_rates(fs, ntaps):
+    """Tile geometry (incremental steps, whole-piece copies, chunk straddling, odd tails) under
+    call lengths drawn at random, for UP/DOWN = 1/50, 2/75, 3/128, 3/625, 1/128: the baseband IQ
+    and the raw-chunk peak must not depend on how the stream is cut."""
+    rng = np.random.default_rng(int(fs) % 9973)
+    L = so.chunk_sizes(fs, 48e3)[3]
+    cfg = dict(so.CONFIGS['C2'], fs=fs, ntaps_dec=ntaps,
+               carriers=[dict(f=0.11 * fs, kind='fm', amp=0.3, tone=1000.0, dev=3000.0),
+                         dict(f=-0.21 * fs, kind='am', amp=0.2, tone=700.0, depth=0.5)],
+               rx=[dict(frq=0.11 * fs, mode='NFM', video_bw=20e3, af_bw=4e3),
+                   dict(frq=-0.21 * fs, mode='AM', video_bw=10e3, af_bw=5e3)])
+    lens = [int(v) for v in rng.integers(1, 3 * L, 5)] + [1, 2, 3 * L + 1, 17]
+    x = so.synth_iq(cfg, sum(lens), 77)
+    P, g = make_gpu_receivers(cfg, max_batch_chunks=4)
+    o = so.make_receivers(cfg, np.float32)
+    pos = 0
+    for n in lens:
+        xc = x[pos:pos + n]
+        pos += n
+        for rg, ro in zip(g, o):
+            rg.demod_data(xc)
+            ro.demod_data(xc)
+            assert rg.iq.shape == ro.iq.shape, (n, pos)
+            if len(ro.iq):
+                assert relerr(rg.iq, ro.iq) <= TOL, (n, pos, relerr(rg.iq, ro.iq))
+        assert g[0].peak_in == pytest.approx(float(np.max(np.abs(xc) ** 2)), rel=1e-6)
+
+
 def test_other_modes_lsb_iq_amsynch():
     base = so.CONFIGS['C1']
     for mode, af in (('LSB', 3e3), ('IQ', 10e3), ('AM-Synch', 5e3), ('RTTY', 3e3), ('SSB', 2e3)):
