@@ -12,6 +12,8 @@ small_*.npz   reduced-rate cases with the INPUT stored (256 kS/s -> 48 kHz, 3/16
 c{1,2,3}.npz  the SURVEY 8(d) configurations: input regenerated from the seed (a checksum
               of it is stored), expected .am / .iq of every sub-receiver for the first chunks
 psd_*.npz     spectrum.periodogram lines
+c4.npz        config C4 (10 MS/s, WFM2 stereo): .am (L + jR) and .iq (S + jD) of chunks 1..2
+rtty.npz      RTTY filterbank lines (rtty.py:822-846) of a stored 48 kHz FSK signal
 """
 import os
 import sys
@@ -22,6 +24,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle import sdr_oracle as so  # noqa: E402
+from oracle import rtty_oracle as ro  # noqa: E402
+from oracle import wfm_oracle as wo  # noqa: E402
 
 SMALL = dict(fs=256e3, fs_out=48e3, ntaps_dec=255, noise=2e-3,
              carriers=[dict(f=20e3, kind='am', amp=0.25, tone=800.0, depth=0.5),
@@ -69,6 +73,23 @@ def main():
     sp = so.Spectrum(48.0, 4096, 8192, 0.5, np.float32)
     lines = np.stack([sp.periodogram(x[i:i + 2048], True) for i in range(0, 3 * 2048, 2048)])
     np.savez_compressed(os.path.join(HERE, 'psd_af8k.npz'), x=x, psd=lines)
+    # C4: 3 chunks of 213333 samples at 10 MS/s, stereo; chunk 0 (start-up on an empty FIR) is not stored
+    fs, L4 = 10e6, 213333
+    x = wo.synth_wfm(fs, 3 * L4, 4)
+    rx = wo.WfmReceiver(fs, 48e3, 300e3, stereo=True, ntaps_dec=255, dtype=np.float32)
+    am, iq = [], []
+    for k in range(3):
+        am.append(rx.demod_data(x[k * L4:(k + 1) * L4]))
+        iq.append(rx.iq)
+    chk = np.array([np.sum(x.real.astype(np.float64)), np.sum(x.imag.astype(np.float64)),
+                    float(x[12345].real), float(x[-1].imag)])
+    np.savez_compressed(os.path.join(HERE, 'c4.npz'), seed=4, L=L4, nchunks=3, input_checksum=chk,
+                        am=np.concatenate(am[1:]), iq=np.concatenate(iq[1:]),
+                        n=np.array([len(a) for a in am], np.int32))
+    # RTTY filterbank: 12 symbols of FSK at 48 kHz, input stored, lines as float32
+    xr, bits = ro.synth_rtty(48000, 12, 1500.0, seed=6, noise=2e-3)
+    lines = ro.RttyFilterbank(48000).push(xr).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, 'rtty.npz'), x=xr, bits=bits, lines=lines)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))
