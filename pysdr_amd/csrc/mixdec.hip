@@ -270,6 +270,15 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   int v_gup = g * a.up, v_gdown = g * a.down - s;
   asm volatile("" : "+v"(my_p0), "+v"(my_fw), "+v"(v_gup), "+v"(v_gdown));
 
+  // Taps in registers: when every tile has at most one task per wave (C3: 12 tasks, 16 waves)
+  // and tile_out is a multiple of UP, wave w always works on the same polyphase branch, so its
+  // R*NJ taps are read from LDS once and stay in VGPRs for the whole launch (24 of the 30 LDS
+  // reads of a task disappear).
+  constexpr bool kCanHold = (NJ > 0) && (R * NJ <= 24);
+  const bool hold = kCanHold && a.ntasks <= nwaves && (a.tile_out % a.up) == 0;
+  float2 greg[kCanHold ? R : 1][kCanHold ? NJ : 1];
+  bool have_greg = false;
+
   Tile cur = tile_geometry(a, t_begin);
   int i_base = cur.i_first;      // first output held in the LDS output stage
   float pk_run = 0.f;            // running raw-chunk peak of chunk pk_chunk (per lane)
@@ -381,7 +390,27 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
           B[r].y = fmaf(gg.y, xv.y, B[r].y);
         }
       };
-      if (NJ > 0) {
+      if (kCanHold && hold) {
+        if (!have_greg) {
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj) greg[r][jj] = tp[r * upc * kp + 16 * jj];
+          have_greg = true;
+        }
+#pragma unroll
+        for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj) {
+          const float2 xv = xp[-16 * jj];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float2 gg = greg[r][jj];
+            A[r].x = fmaf(gg.x, xv.x, A[r].x);
+            A[r].y = fmaf(gg.y, xv.x, A[r].y);
+            B[r].x = fmaf(gg.x, xv.y, B[r].x);
+            B[r].y = fmaf(gg.y, xv.y, B[r].y);
+          }
+        }
+      } else if (NJ > 0) {
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) tap_step(16 * jj);
       } else {
