@@ -181,16 +181,4 @@ class WfmReceiver:
         return am
 
 
-def synth_wfm(fs, nsamp, seed, f_carrier=300e3, tone_l=1000.0, tone_r=2500.0, amp=0.3, noise=2e-3):
-    """Synthetic stereo FM broadcast: composite = 0.9*((L+R)/2 +
-    (L-R)/2*sin(2 wp t)) + 0.1*sin(wp t), +-75 kHz deviation."""
-    rng = np.random.default_rng(seed)
-    t = np.arange(nsamp, dtype=np.float64) / fs
-    left = 0.8 * np.sin(2 * np.pi * tone_l * t)
-    right = 0.6 * np.sin(2 * np.pi * tone_r * t)
-    wp = 2 * np.pi * WFM_PILOT_HZ
-    mpx = 0.9 * (0.5 * (left + right) + 0.5 * (left - right) * np.sin(2 * wp * t)) + WFM_PILOT_LEVEL * np.sin(wp * t)
-    phase = 2 * np.pi * f_carrier * t + 2 * np.pi * WFM_FULL_SCALE_DEV * np.cumsum(mpx) / fs
-    x = amp * np.exp(1j * phase)
-    x += noise * (rng.standard_normal(nsamp) + 1j * rng.standard_normal(nsamp)) / math.sqrt(2)
-    return x.astype(np.complex64)
+from pysdr_amd.synth import synth_wfm  # noqa: E402,F401  (synthetic input generator, shared with the product's probes)

@@ -60,3 +60,18 @@ CONFIGS = {
                    dict(frq=455e3, mode='NFM', video_bw=20e3, af_bw=4e3),
                    dict(frq=-1.2e6, mode='AM', video_bw=10e3, af_bw=5e3)]),
 }
+
+
+def synth_wfm(fs, nsamp, seed, f_carrier=300e3, tone_l=1000.0, tone_r=2500.0, amp=0.3, noise=2e-3):
+    """Synthetic stereo FM broadcast: composite = 0.9*((L+R)/2 +
+    (L-R)/2*sin(2 wp t)) + 0.1*sin(wp t), +-75 kHz deviation."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(nsamp, dtype=np.float64) / fs
+    left = 0.8 * np.sin(2 * np.pi * tone_l * t)
+    right = 0.6 * np.sin(2 * np.pi * tone_r * t)
+    wp = 2 * np.pi * 19000.0
+    mpx = 0.9 * (0.5 * (left + right) + 0.5 * (left - right) * np.sin(2 * wp * t)) + 0.1 * np.sin(wp * t)
+    phase = 2 * np.pi * f_carrier * t + 2 * np.pi * 75e3 * np.cumsum(mpx) / fs
+    x = amp * np.exp(1j * phase)
+    x += noise * (rng.standard_normal(nsamp) + 1j * rng.standard_normal(nsamp)) / math.sqrt(2)
+    return x.astype(np.complex64)

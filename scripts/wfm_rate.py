@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pysdr_amd import _lib, sig_proc
 from pysdr_amd.params import RunTimeParams
-from oracle import wfm_oracle as wo   # synthetic signal only (test infrastructure)
+from pysdr_amd.synth import synth_wfm
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 lib = _lib.lib()
@@ -14,7 +14,7 @@ for mode in ('WFM', 'WFM2'):
     P = RunTimeParams(fs=fs, fc=[98.1e6], mode=mode, nfilt=255, foffset=300e3, vid_bw=200e3, max_batch_chunks=B)
     g = sig_proc.Receiver(P, 300e3, 0, '1')
     ctx = P._pysdr_stream
-    xu = wo.synth_wfm(fs, 4 * L, 4)
+    xu = synth_wfm(fs, 4 * L, 4)
     d_x = C.c_void_p()
     _lib.check(lib.pysdr_dev_alloc(0, B * L * 8, C.byref(d_x)), "alloc")
     for k in range(0, B, 4):
