@@ -301,6 +301,7 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   }
   a.tile_out = (int)tile_out;
   a.tile_cap = (int)cap;
+  { const char* e = getenv("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0 && atoi(e) < yflush) yflush = atoi(e); }
   a.yflush = (int)yflush;
   a.ycap = (int)(yflush * tile_out);
   a.tpc = (int)((((tile_out + up - 1) / up) + 3) >> 2);
@@ -461,7 +462,10 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   if (rc) return rc;
   pysdr_ctx* c = new pysdr_ctx();
   c->cfg = *cfg;
-  c->hy = (((cfg->ntaps_af + 7) & ~7) + 4 + 1) & ~1;   // FIR history (taps padded to 8) + discriminator
+  // FIR history (taps padded to 8) + discriminator, rounded up to 16 outputs so that output 0 of a
+  // call sits on a 128-byte line: the mix+decimate kernel's 512-byte wave stores then cover whole
+  // lines (partial lines are written through as masked writes = read-modify-write at the DRAM)
+  c->hy = ((((cfg->ntaps_af + 7) & ~7) + 4 + 1) + 15) & ~15;
   c->cap_samples = (size_t)cfg->max_chunks * (size_t)cfg->in_chunk;
   c->mmax = (int)((c->cap_samples * (size_t)cfg->up) / (size_t)cfg->down) + 4;
   {
