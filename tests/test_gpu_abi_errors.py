@@ -1,0 +1,134 @@
+"""Error behaviour of the C ABI on a live device: every misuse returns a negative pysdr_status
+with a message in pysdr_last_error(), nothing aborts, and the context keeps working afterwards
+(the reference's convention is "print + carry on", receiver.py:603-605)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import sdr_oracle as so
+from pysdr_amd import _lib, design
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(max_chunks=1, in_chunk=170666, ntaps=255):
+    lib = _lib.lib()
+    cfg = _lib.Cfg(8e6, 3, 500, in_chunk, max_chunks, ntaps, 255, 0, 0)
+    h = C.c_void_p()
+    _lib.check(lib.pysdr_create(C.byref(cfg), C.byref(h)), "create")
+    return lib, h
+
+
+def _taps():
+    hdec = np.ascontiguousarray(design.decimator_bank(8e6, 3, 48000, 255)[0], np.float64)
+    af = np.ascontiguousarray(design.af_bank_real(48000, 255)[3].astype(np.complex128)).view(np.float64)
+    return hdec, af
+
+
+def test_misuse_returns_status_and_context_survives():
+    lib, h = _ctx()
+    hdec, af = _taps()
+    irx = C.c_int(-1)
+    x = so.synth_iq(so.CONFIGS['C2'], 170666, 1)
+    outs = (_lib.Out * 1)()
+    # no receivers yet
+    assert lib.pysdr_process(h, _lib.as_pf(x.view(np.float32)), len(x), outs) < 0
+    assert b"no receivers" in lib.pysdr_last_error()
+    # bad mode / null taps
+    assert lib.pysdr_rx_add(h, 99, -455e3, _lib.as_pd(hdec), _lib.as_pd(af), 0.0, C.byref(irx)) < 0
+    assert lib.pysdr_rx_add(h, 9, -455e3, None, _lib.as_pd(af), 0.0, C.byref(irx)) < 0
+    for k in range(8):
+        assert lib.pysdr_rx_add(h, 9, -455e3 + 1e3 * k, _lib.as_pd(hdec), _lib.as_pd(af), 0.0, C.byref(irx)) == 0
+    assert irx.value == 7
+    assert lib.pysdr_rx_add(h, 9, 0.0, _lib.as_pd(hdec), _lib.as_pd(af), 0.0, C.byref(irx)) < 0      # PYSDR_MAX_RX
+    # setters on a sub-receiver that does not exist, wrong tap counts
+    fa = C.c_double()
+    assert lib.pysdr_set_lo(h, 8, 1.0, C.byref(fa)) < 0 and lib.pysdr_set_lo(h, -1, 1.0, C.byref(fa)) < 0
+    assert lib.pysdr_set_dec_taps(h, 0, _lib.as_pd(hdec), 254) < 0
+    assert lib.pysdr_set_mode(h, 0, 9, _lib.as_pd(af), 17, 0.0) < 0
+    # more samples than the context was created for
+    big = np.zeros(2 * 170666 + 5, np.complex64)
+    outs8 = (_lib.Out * 8)()
+    assert lib.pysdr_process(h, _lib.as_pf(big.view(np.float32)), len(big), outs8) < 0
+    assert b"capacity" in lib.pysdr_last_error()
+    assert lib.pysdr_process_batch(h, C.c_void_p(big.ctypes.data), 2, 170666, 0) < 0
+    # output buffers too small
+    am = np.empty(16, np.float32)
+    outs8[0].am = _lib.as_pf(am)
+    outs8[0].cap = 16
+    assert lib.pysdr_process(h, _lib.as_pf(x.view(np.float32)), len(x), outs8) < 0
+    # ... and after all that a proper call works
+    for r in range(8):
+        outs8[r].am, outs8[r].iq, outs8[r].cap = None, None, 0
+    assert lib.pysdr_process(h, _lib.as_pf(x.view(np.float32)), len(x), outs8) == 0
+    assert outs8[0].n_out in (1023, 1024, 1025) and outs8[0].peak_in > 0
+    lib.pysdr_destroy(h)
+
+
+def test_spectrum_waterfall_ingest_misuse():
+    lib, h = _ctx()
+    sp = C.c_void_p()
+    win = np.ones(1024, np.float32)
+    assert lib.pysdr_spectrum_create(0, 1024, 512, 1, _lib.as_pf(win), C.byref(sp)) < 0       # nfft < chunk
+    assert lib.pysdr_spectrum_create(0, 1024, 2048, 0, _lib.as_pf(win), C.byref(sp)) < 0      # no frames
+    _lib.check(lib.pysdr_spectrum_create(0, 1024, 2048, 4, _lib.as_pf(win), C.byref(sp)), "spectrum_create")
+    d = C.c_void_p()
+    _lib.check(lib.pysdr_dev_alloc(0, 1 << 20, C.byref(d)), "alloc")
+    assert lib.pysdr_spectrum_batch(sp, d, 5, 1024, d) < 0                                    # > max_frames
+    assert lib.pysdr_spectrum_order(sp, h, 3) < 0
+    assert lib.pysdr_spectrum_order(sp, h, 0) == 0 and lib.pysdr_spectrum_order(sp, h, 2) == 0
+    ing = C.c_void_p()
+    assert lib.pysdr_ingest_create(h, 1, C.byref(ing)) < 0                                    # needs >= 2 slots
+    _lib.check(lib.pysdr_ingest_create(h, 2, C.byref(ing)), "ingest_create")
+    outs = (_lib.Out * 1)()
+    assert lib.pysdr_ingest_collect(ing, 0, outs) < 0                                         # never submitted
+    assert lib.pysdr_ingest_submit(ing, 0, 170666) < 0                                        # no receivers
+    assert lib.pysdr_ingest_submit(ing, 5, 10) < 0 and lib.pysdr_ingest_submit(ing, 0, 10 ** 9) < 0
+    lib.pysdr_ingest_destroy(ing)
+    lib.pysdr_dev_free(0, d)
+    lib.pysdr_spectrum_destroy(sp)
+    lib.pysdr_destroy(h)
+    assert lib.pysdr_strerror(-5) and lib.pysdr_strerror(-99)
+
+
+def test_setters_from_a_second_thread_while_processing():
+    """The GUI thread retunes / swaps filters / changes mode while the RX thread demodulates
+    (gui.py:1713,1938 vs receiver.py:684-725): setters take effect at a chunk boundary, nothing
+    crashes or returns garbage."""
+    import threading
+    from tests.test_gpu_parity import make_gpu_receivers
+    cfg = so.CONFIGS['C3']
+    P, g = make_gpu_receivers(cfg)
+    L = P.IN_CHUNK_SIZE
+    x = so.synth_iq(cfg, 4 * L, 3)
+    stop = threading.Event()
+    errors = []
+
+    def gui():
+        k = 0
+        try:
+            while not stop.is_set():
+                g[2].lo.change_freq(-455e3 - 50.0 * (k % 7))
+                g[0].dec.h = g[0].dec.filter_bank[3 + (k % 4)]
+                g[1].bfo = 650.0 + 10.0 * (k % 5)
+                g[3].af_bw = (3e3, 5e3)[k % 2]
+                if k % 11 == 0:
+                    g[0].agc.reset()
+                k += 1
+        except Exception as e:          # pragma: no cover
+            errors.append(e)
+
+    t = threading.Thread(target=gui)
+    t.start()
+    try:
+        for k in range(40):
+            xc = x[(k % 4) * L:(k % 4 + 1) * L]
+            for rx in g:
+                am = rx.demod_data(xc)
+                assert len(am) in (1023, 1024, 1025) and np.all(np.isfinite(am)) and np.all(np.isfinite(rx.iq))
+    finally:
+        stop.set()
+        t.join()
+    assert not errors
+    assert abs(g[2].lo.fo) > 0
