@@ -1060,14 +1060,15 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
                         int db, float* d_out) {
   int rc;
   if (is_complex && sp->chunk == 32768 && sp->nfft == 65536 && !getenv("PYSDR_PSD_ROCFFT")) {
-    // the RF-waterfall size: fused four-step transform, in groups of 256 frames: the 128 MB
+    // the RF-waterfall size: fused four-step transform, in groups of 320 frames: the 160 MB
     // of intermediate of one group then stays in the 256 MB Infinity Cache between the two
-    // kernels (measured 3.04 ms per 10666 frames against 3.45 ms for groups of 4096 and
-    // 3.48 ms for 512, whose 256 MB no longer fit; below 128 frames launch gaps dominate).
+    // kernels (measured 3.04 ms per 10666 frames at 256, 3.02 at 320, against 3.45 ms for
+    // groups of 4096 and 3.48 ms for 512, whose 256 MB no longer fit; below 128 frames launch
+    // gaps dominate).
     // Running the rows of group g beside the columns of group g+1 on a second stream was
     // tried and is slower (3.9 ms): the two working sets evict each other.
     const char* ge = getenv("PYSDR_PSD_GROUP");
-    int group = ge ? atoi(ge) : 256;
+    int group = ge ? atoi(ge) : 320;
     if (group < 1) group = 1;
     rc = ensure_work(sp, (size_t)std::min(group, nframes));
     if (rc) return rc;
