@@ -1060,15 +1060,15 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
                         int db, float* d_out) {
   int rc;
   if (is_complex && sp->chunk == 32768 && sp->nfft == 65536 && !getenv("PYSDR_PSD_ROCFFT")) {
-    // the RF-waterfall size: fused four-step transform, in groups of 320 frames: the 160 MB
+    // the RF-waterfall size: fused four-step transform, in groups of 448 frames: the 224 MB
     // of intermediate of one group then stays in the 256 MB Infinity Cache between the two
-    // kernels (measured 3.04 ms per 10666 frames at 256, 3.02 at 320, against 3.45 ms for
-    // groups of 4096 and 3.48 ms for 512, whose 256 MB no longer fit; below 128 frames launch
-    // gaps dominate).
+    // kernels (the input and the PSD stream past it with non-temporal accesses).  Measured per
+    // 10666 frames: 3.45 ms for groups of 4096, 3.02 ms at 320 and 2.96 ms at 448-512 with the
+    // streaming hints, 3.6 ms at 576 (no longer fits); below 128 frames launch gaps dominate.
     // Running the rows of group g beside the columns of group g+1 on a second stream was
     // tried and is slower (3.9 ms): the two working sets evict each other.
     const char* ge = getenv("PYSDR_PSD_GROUP");
-    int group = ge ? atoi(ge) : 320;
+    int group = ge ? atoi(ge) : 448;
     if (group < 1) group = 1;
     rc = ensure_work(sp, (size_t)std::min(group, nframes));
     if (rc) return rc;
