@@ -275,7 +275,8 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   // R*NJ taps are read from LDS once and stay in VGPRs for the whole launch (24 of the 30 LDS
   // reads of a task disappear).
   constexpr bool kCanHold = (NJ > 0) && (R * NJ <= 24);
-  const bool hold = kCanHold && a.ntasks <= nwaves && (a.tile_out % a.up) == 0;
+  // (UP = 1, e.g. the broadcast-FM front end: there is only one branch, every task uses it)
+  const bool hold = kCanHold && (a.up == 1 || (a.ntasks <= nwaves && (a.tile_out % a.up) == 0));
   float2 greg[kCanHold ? R : 1][kCanHold ? NJ : 1];
   bool have_greg = false;
 
@@ -489,6 +490,10 @@ template <int R>
 int launch_r(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
   // 255-tap prototypes at UP = 3 (the BASELINE configurations) have 96 taps per branch
   if (a.kpad == 96) return launch_rj<R, 6>(a, threads, grid, lds, st);
+  // 255-tap video filter of the broadcast-FM front end (UP = 1): 256 taps in one branch
+  if constexpr (R == 1) {
+    if (a.kpad == 256) return launch_rj<R, 16>(a, threads, grid, lds, st);
+  }
   return launch_rj<R, 0>(a, threads, grid, lds, st);
 }
 
