@@ -270,13 +270,17 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   int v_gup = g * a.up, v_gdown = g * a.down - s;
   asm volatile("" : "+v"(my_p0), "+v"(my_fw), "+v"(v_gup), "+v"(v_gdown));
 
-  // Taps in registers: when every tile has at most one task per wave (C3: 12 tasks, 16 waves)
-  // and tile_out is a multiple of UP, wave w always works on the same polyphase branch, so its
-  // R*NJ taps are read from LDS once and stay in VGPRs for the whole launch (24 of the 30 LDS
-  // reads of a task disappear).
+  // Taps in registers: when tile_out is a multiple of UP, output i of every tile is on branch
+  // (p_f + i*DOWN) mod UP with the same p_f, so a wave that only ever works on one branch can
+  // read its R*NJ taps from LDS once and keep them in VGPRs for the whole launch (24 of the 30
+  // LDS reads of a C3 task disappear).
   constexpr bool kCanHold = (NJ > 0) && (R * NJ <= 24);
-  // (UP = 1, e.g. the broadcast-FM front end: there is only one branch, every task uses it)
-  const bool hold = kCanHold && (a.up == 1 || (a.ntasks <= nwaves && (a.tile_out % a.up) == 0));
+  // For that the tasks are dealt out by branch: wave w works on branch w % UP only and walks
+  // that branch's quads with stride nwaves / UP (UP = 1: every wave, one branch).
+  const bool hold = kCanHold && a.up <= nwaves && (a.tile_out % a.up) == 0;
+  const int hold_c = wave % a.up;                       // this wave's branch
+  const int hold_step = nwaves / a.up;                  // waves per branch
+  const int hold_q0 = (wave < a.up * hold_step) ? wave / a.up : (1 << 29);
   float2 greg[kCanHold ? R : 1][kCanHold ? NJ : 1];
   bool have_greg = false;
 
@@ -363,9 +367,12 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
     const int kp = (NJ > 0) ? 16 * NJ : a.kpad;
     const int ntasks = (cur.tile_n > 0 && !(a.dbg & 1)) ? a.ntasks : 0;
     const int i_last = cur.i_first + cur.tile_n - 1;
-    for (int task = wave; task < ntasks; task += nwaves) {
-      const int c = (a.tpc == 1) ? task : (int)__umulhi((uint32_t)task, a.magic_tpc);
-      const int qq = task - c * a.tpc;
+    // generic order: task = (branch, quad) round robin over the waves; hold order: see above
+    const int t_lim = hold ? (ntasks > 0 ? a.tpc : 0) : ntasks;
+    const int t_step = hold ? hold_step : nwaves;
+    for (int task = hold ? hold_q0 : wave; task < t_lim; task += t_step) {
+      const int c = hold ? hold_c : ((a.tpc == 1) ? task : (int)__umulhi((uint32_t)task, a.magic_tpc));
+      const int qq = hold ? task : task - c * a.tpc;
       uint32_t qc, pc;
       divmod_magic((uint32_t)cur.p_f + (uint32_t)c * (uint32_t)a.down, (uint32_t)upc, a.magic, qc, pc);
       const int i = cur.i_first + c + 4 * qq * upc + v_gup;
@@ -490,9 +497,11 @@ template <int R>
 int launch_r(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
   // 255-tap prototypes at UP = 3 (the BASELINE configurations) have 96 taps per branch
   if (a.kpad == 96) return launch_rj<R, 6>(a, threads, grid, lds, st);
-  // 255-tap video filter of the broadcast-FM front end (UP = 1): 256 taps in one branch
+  // single-RX long filters: the 255-tap video filter of the broadcast-FM front end (UP = 1, 256
+  // taps in one branch) and the reference's default 1001-tap prototype at UP = 3 (336 per branch)
   if constexpr (R == 1) {
     if (a.kpad == 256) return launch_rj<R, 16>(a, threads, grid, lds, st);
+    if (a.kpad == 336) return launch_rj<R, 21>(a, threads, grid, lds, st);
   }
   return launch_rj<R, 0>(a, threads, grid, lds, st);
 }
