@@ -395,3 +395,89 @@ def test_waterfall_backend_matches_plotting_py_numerics():
             assert np.allclose(img, rimg, rtol=1e-5, atol=1e-3)
             assert np.array_equal(Waterfall.peaks(psd2.astype(np.float64), bk, 10.0, df),
                                   so.find_peaks_db(rpsd2, rbk, 10.0 / df)) or k != 129
+
+
+def test_full_size_batch_is_independent_of_how_it_is_cut():
+    """BASELINE full size (the bench's 2048 chunks x 170666 samples = 2.8 GB resident in HBM, 4 RX):
+    one launch sequence over the whole batch = two over its halves, bit for bit (audio, baseband
+    IQ, per-chunk output counts and raw peaks), and the first chunks equal the oracle."""
+    from pysdr_amd import _lib
+    cfg = so.CONFIGS['C3']
+    L, B, uniq = 170666, 2048, 8
+    xu = so.synth_iq(cfg, uniq * L, 10)
+    lib = _lib.lib()
+    d_x = C.c_void_p()
+    _lib.check(lib.pysdr_dev_alloc(0, B * L * 8, C.byref(d_x)), "alloc")
+    try:
+        for k in range(0, B, uniq):
+            _lib.check(lib.pysdr_dev_upload(0, C.c_void_p(d_x.value + k * L * 8), C.c_void_p(xu.ctypes.data),
+                                            uniq * L * 8), "upload")
+        Pa, ga = make_gpu_receivers(cfg, max_batch_chunks=B)
+        ca = Pa._pysdr_stream
+        ca.process_batch(d_x.value, B, L, on_device=True)
+        whole = [ca.fetch(i, B) for i in range(len(ga))]
+        ca.close()
+        Pb, gb = make_gpu_receivers(cfg, max_batch_chunks=B // 2)
+        cb = Pb._pysdr_stream
+        halves = []
+        for h in range(2):
+            cb.process_batch(d_x.value + h * (B // 2) * L * 8, B // 2, L, on_device=True)
+            halves.append([cb.fetch(i, B // 2) for i in range(len(gb))])
+        cb.close()
+    finally:
+        lib.pysdr_dev_free(0, d_x)
+    for i in range(len(ga)):
+        am, iq, cn, pk = whole[i]
+        assert len(am) == B * L * 3 // 500 or len(am) == B * L * 3 // 500 + 1
+        assert np.array_equal(am, np.concatenate([halves[0][i][0], halves[1][i][0]]))
+        assert np.array_equal(iq, np.concatenate([halves[0][i][1], halves[1][i][1]]))
+        assert np.array_equal(cn, np.concatenate([halves[0][i][2], halves[1][i][2]])) and cn.sum() == len(am)
+        assert np.array_equal(pk, np.concatenate([halves[0][i][3], halves[1][i][3]]))
+        assert np.array_equal(pk[:uniq], pk[uniq:2 * uniq])            # the input repeats every 8 chunks
+    o = so.make_receivers(cfg, np.float32)
+    for i, ro in enumerate(o):
+        ref = np.concatenate([ro.demod_data(xu[k * L:(k + 1) * L]) for k in range(2)])
+        skip = NFM_STARTUP_SKIP if ro.mode == 'NFM' else 0
+        assert relerr(whole[i][0][skip:len(ref)], ref[skip:]) <= TOL, ro.mode
+
+
+def test_full_size_psd_frames_do_not_depend_on_the_batch():
+    """The bench's 10666 frames of the 64k PSD in one call: every frame equals the same frame
+    computed alone (bit for bit; first / last frame of a cache-resident group, last frame of the
+    batch), and frame 0 equals the oracle."""
+    from pysdr_amd import _lib, design
+    cfg = so.CONFIGS['C3']
+    CH, NF = 32768, 65536
+    uniq = 8 * 170666
+    nframes = (2048 * 170666) // CH
+    xu = so.synth_iq(cfg, uniq, 10)
+    lib = _lib.lib()
+    d_x, d_o, d_1 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(lib.pysdr_dev_alloc(0, 2048 * 170666 * 8, C.byref(d_x)), "alloc")
+    _lib.check(lib.pysdr_dev_alloc(0, nframes * NF * 4, C.byref(d_o)), "alloc")
+    _lib.check(lib.pysdr_dev_alloc(0, NF * 4, C.byref(d_1)), "alloc")
+    win = np.ascontiguousarray(design.psd_window(CH), np.float32)
+    sp = C.c_void_p()
+    _lib.check(lib.pysdr_spectrum_create(0, CH, NF, nframes, _lib.as_pf(win), C.byref(sp)), "create")
+    try:
+        for k in range(0, 2048, 8):
+            _lib.check(lib.pysdr_dev_upload(0, C.c_void_p(d_x.value + k * 170666 * 8), C.c_void_p(xu.ctypes.data),
+                                            uniq * 8), "upload")
+        _lib.check(lib.pysdr_spectrum_batch(sp, d_x, nframes, CH, d_o), "batch")
+        _lib.check(lib.pysdr_spectrum_sync(sp), "sync")
+        big, one = np.empty(NF, np.float32), np.empty(NF, np.float32)
+        for f in (0, 447, 448, 5000, nframes - 1):
+            _lib.check(lib.pysdr_dev_download(0, C.c_void_p(big.ctypes.data), C.c_void_p(d_o.value + f * NF * 4), NF * 4), "dl")
+            _lib.check(lib.pysdr_spectrum_batch(sp, C.c_void_p(d_x.value + f * CH * 8), 1, CH, d_1), "batch1")
+            _lib.check(lib.pysdr_spectrum_sync(sp), "sync")
+            _lib.check(lib.pysdr_dev_download(0, C.c_void_p(one.ctypes.data), d_1, NF * 4), "dl")
+            assert np.array_equal(big, one), f
+            if f == 0:
+                ref = so.Spectrum(8000.0, CH, NF, 0.0, np.float64).periodogram(xu[:CH], True)
+                strong = ref > ref.max() - 60.0
+                assert np.max(np.abs(big[strong] - ref[strong])) < 0.01
+                assert np.max(np.abs(10 ** (big / 10.0) - 10 ** (ref / 10.0))) <= 2e-5 * np.max(10 ** (ref / 10.0))
+    finally:
+        lib.pysdr_spectrum_destroy(sp)
+        for d in (d_x, d_o, d_1):
+            lib.pysdr_dev_free(0, d)
