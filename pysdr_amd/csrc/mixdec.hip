@@ -226,6 +226,43 @@ __device__ __forceinline__ void stage_tile(const MixDecArgs& a, const Tile& t, f
   }
 }
 
+// Fold the 16 lanes of each row for N sub-receivers (all 2N partial sums advance one DPP step
+// at a time, so consecutive instructions are independent: no DPP hazard stalls), then lane
+// s < ncount of every row rotates RX rbase + s by its LO phase and puts the sample into the LDS
+// output stage.  The outputs go to that stage, not to memory: stores share vmcnt with the tile
+// copies and the wait in front of the barrier is vmcnt(0), so a store per tile holds the next
+// tile hostage to its write acknowledge (measured 4.5 vs 5.1 TB/s); the stage is flushed every
+// `yflush` tiles with whole-line coalesced stores.
+template <int N>
+__device__ __forceinline__ void fold_rotate_stage(const float2 (&A)[N], const float2 (&B)[N], int ncount,
+                                                  int rbase, int s, bool valid, uint32_t rel, uint32_t p0,
+                                                  uint32_t fw, float2* ys, int ycap, int io) {
+  float red[2 * N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) { red[2 * r] = A[r].x - B[r].y; red[2 * r + 1] = A[r].y + B[r].x; }
+#pragma unroll
+  for (int q = 0; q < 2 * N; ++q) red[q] += dpp_quad_xor1(red[q]);
+#pragma unroll
+  for (int q = 0; q < 2 * N; ++q) red[q] += dpp_quad_xor2(red[q]);
+#pragma unroll
+  for (int q = 0; q < 2 * N; ++q) red[q] += dpp_half_mirror(red[q]);
+#pragma unroll
+  for (int q = 0; q < 2 * N; ++q) red[q] += dpp_mirror(red[q]);
+  float sr = 0.f, si = 0.f;
+#pragma unroll
+  for (int r = 0; r < N; ++r)
+    if (s == r) { sr = red[2 * r]; si = red[2 * r + 1]; }
+  if (valid && s < ncount) {
+    const uint32_t ph = p0 + fw * rel;
+    const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+    const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+    float2 o;
+    o.x = sr * cs - si * sn;
+    o.y = sr * sn + si * cs;
+    ys[(rbase + s) * ycap + io] = o;
+  }
+}
+
 // NJ = kpad/16 known at compile time (fully unrolled tap loop) or 0 for a runtime loop
 template <int R, int NJ>
 __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
@@ -262,27 +299,32 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
     const int nt = R * a.up * a.kpad;
     for (int i = tid; i < nt; i += nthr) tl[i] = a.taps[i];
   }
-  // per-lane constants of the epilogue: lane s < R of every row finishes RX s
+  // Taps in registers: when tile_out is a multiple of UP, output i of every tile is on branch
+  // (p_f + i*DOWN) mod UP with the same p_f, so a wave that only ever works on one branch can
+  // read its taps from LDS once and keep them in VGPRs for the whole launch (24 of the 30 LDS
+  // reads of a C3 task disappear).  For that the tasks are dealt out by (branch, RX half): wave w
+  // belongs to group w % (UP*NH), works on that group's branch and -- above 4 RX -- on one half
+  // of the sub-receivers only, and walks the quads with stride nwaves / (UP*NH).
+  constexpr int NH = (R > 4) ? 2 : 1;                   // RX halves
+  constexpr int RH = (R + NH - 1) / NH;                 // RX per task in hold mode
+  constexpr bool kCanHold = (NJ > 0) && (RH * NJ <= 24);
+  const int ngrp = a.up * NH;
+  const bool hold = kCanHold && ngrp <= nwaves && (a.tile_out % a.up) == 0;
+  const int hold_grp = wave % ngrp;
+  const int hold_c = hold_grp % a.up;                   // this wave's branch
+  const int hold_rbase = hold ? (hold_grp / a.up) * RH : 0;   // first RX of this wave's tasks
+  const int hold_rcount = hold ? ((R - hold_rbase < RH) ? R - hold_rbase : RH) : R;
+  const int hold_step = nwaves / ngrp;                  // waves per group
+  const int hold_q0 = (wave < ngrp * hold_step) ? wave / ngrp : (1 << 29);
+  float2 greg[kCanHold ? RH : 1][kCanHold ? NJ : 1];
+  bool have_greg = false;
+  // per-lane constants of the epilogue: lane s of every row finishes RX hold_rbase + s
   uint32_t my_p0 = 0u, my_fw = 0u;
 #pragma unroll
   for (int r = 0; r < R; ++r)
-    if (s == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; }
+    if (hold_rbase + s == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; }
   int v_gup = g * a.up, v_gdown = g * a.down - s;
   asm volatile("" : "+v"(my_p0), "+v"(my_fw), "+v"(v_gup), "+v"(v_gdown));
-
-  // Taps in registers: when tile_out is a multiple of UP, output i of every tile is on branch
-  // (p_f + i*DOWN) mod UP with the same p_f, so a wave that only ever works on one branch can
-  // read its R*NJ taps from LDS once and keep them in VGPRs for the whole launch (24 of the 30
-  // LDS reads of a C3 task disappear).
-  constexpr bool kCanHold = (NJ > 0) && (R * NJ <= 24);
-  // For that the tasks are dealt out by branch: wave w works on branch w % UP only and walks
-  // that branch's quads with stride nwaves / UP (UP = 1: every wave, one branch).
-  const bool hold = kCanHold && a.up <= nwaves && (a.tile_out % a.up) == 0;
-  const int hold_c = wave % a.up;                       // this wave's branch
-  const int hold_step = nwaves / a.up;                  // waves per branch
-  const int hold_q0 = (wave < a.up * hold_step) ? wave / a.up : (1 << 29);
-  float2 greg[kCanHold ? R : 1][kCanHold ? NJ : 1];
-  bool have_greg = false;
 
   Tile cur = tile_geometry(a, t_begin);
   int i_base = cur.i_first;      // first output held in the LDS output stage
@@ -384,33 +426,24 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
       const float2* tp = tl + (int)pc * kp + s;
       // A += g*x.re, B += g*x.im per RX (two packed FMAs per tap, no operand shuffles);
       // y = (A.re - B.im, A.im + B.re)
-      float2 A[R], B[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) { A[r] = make_float2(0.f, 0.f); B[r] = make_float2(0.f, 0.f); }
-      auto tap_step = [&](int j) {
-        const float2 xv = xp[-j];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const float2 gg = tp[r * upc * kp + j];
-          A[r].x = fmaf(gg.x, xv.x, A[r].x);
-          A[r].y = fmaf(gg.y, xv.x, A[r].y);
-          B[r].x = fmaf(gg.x, xv.y, B[r].x);
-          B[r].y = fmaf(gg.y, xv.y, B[r].y);
-        }
-      };
       if (kCanHold && hold) {
+        const float2* th = tp + hold_rbase * upc * kp;
         if (!have_greg) {
 #pragma unroll
-          for (int r = 0; r < R; ++r)
+          for (int r = 0; r < RH; ++r)
 #pragma unroll
-            for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj) greg[r][jj] = tp[r * upc * kp + 16 * jj];
+            for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj)
+              greg[r][jj] = (r < hold_rcount) ? th[r * upc * kp + 16 * jj] : make_float2(0.f, 0.f);
           have_greg = true;
         }
+        float2 A[RH], B[RH];
+#pragma unroll
+        for (int r = 0; r < RH; ++r) { A[r] = make_float2(0.f, 0.f); B[r] = make_float2(0.f, 0.f); }
 #pragma unroll
         for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj) {
           const float2 xv = xp[-16 * jj];
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
+          for (int r = 0; r < RH; ++r) {
             const float2 gg = greg[r][jj];
             A[r].x = fmaf(gg.x, xv.x, A[r].x);
             A[r].y = fmaf(gg.y, xv.x, A[r].y);
@@ -418,42 +451,30 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
             B[r].y = fmaf(gg.y, xv.y, B[r].y);
           }
         }
-      } else if (NJ > 0) {
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) tap_step(16 * jj);
+        fold_rotate_stage<RH>(A, B, hold_rcount, hold_rbase, s, valid, rel, my_p0, my_fw, ys, a.ycap, i - i_base);
       } else {
+        float2 A[R], B[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { A[r] = make_float2(0.f, 0.f); B[r] = make_float2(0.f, 0.f); }
+        auto tap_step = [&](int j) {
+          const float2 xv = xp[-j];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float2 gg = tp[r * upc * kp + j];
+            A[r].x = fmaf(gg.x, xv.x, A[r].x);
+            A[r].y = fmaf(gg.y, xv.x, A[r].y);
+            B[r].x = fmaf(gg.x, xv.y, B[r].x);
+            B[r].y = fmaf(gg.y, xv.y, B[r].y);
+          }
+        };
+        if (NJ > 0) {
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) tap_step(16 * jj);
+        } else {
 #pragma unroll 2
-        for (int j = 0; j < kp; j += 16) tap_step(j);
-      }
-      // fold the 16 lanes of each row: all 2R partial sums advance one DPP step at a time,
-      // so consecutive instructions are independent (no DPP hazard stalls)
-      float red[2 * R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) { red[2 * r] = A[r].x - B[r].y; red[2 * r + 1] = A[r].y + B[r].x; }
-#pragma unroll
-      for (int q = 0; q < 2 * R; ++q) red[q] += dpp_quad_xor1(red[q]);
-#pragma unroll
-      for (int q = 0; q < 2 * R; ++q) red[q] += dpp_quad_xor2(red[q]);
-#pragma unroll
-      for (int q = 0; q < 2 * R; ++q) red[q] += dpp_half_mirror(red[q]);
-#pragma unroll
-      for (int q = 0; q < 2 * R; ++q) red[q] += dpp_mirror(red[q]);
-      float sr = 0.f, si = 0.f;
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (s == r) { sr = red[2 * r]; si = red[2 * r + 1]; }
-      // The outputs go to an LDS stage, not to memory: stores share vmcnt with the tile
-      // copies and the wait in front of the barrier is vmcnt(0), so a store per tile holds
-      // the next tile hostage to its write acknowledge (measured 4.5 vs 5.1 TB/s).  The
-      // stage is flushed every `yflush` tiles with whole-line coalesced stores.
-      if (valid && s < R) {
-        const uint32_t ph = my_p0 + my_fw * rel;
-        const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
-        const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
-        float2 o;
-        o.x = sr * cs - si * sn;
-        o.y = sr * sn + si * cs;
-        ys[s * a.ycap + (i - i_base)] = o;
+          for (int j = 0; j < kp; j += 16) tap_step(j);
+        }
+        fold_rotate_stage<R>(A, B, R, 0, s, valid, rel, my_p0, my_fw, ys, a.ycap, i - i_base);
       }
     }
     // ---- flush the output stage: RX r, 64 outputs per wave-store (512 contiguous bytes)
