@@ -481,3 +481,22 @@ def test_full_size_psd_frames_do_not_depend_on_the_batch():
         lib.pysdr_spectrum_destroy(sp)
         for d in (d_x, d_o, d_1):
             lib.pysdr_dev_free(0, d)
+
+
+def test_mix_decimate_is_linear_at_batch_size():
+    """Size-independent property of the front end (LO mix + polyphase decimation is linear):
+    iq(x1 + 2*x2) = iq(x1) + 2*iq(x2) over a 64-chunk batch, for every sub-receiver."""
+    cfg = so.CONFIGS['C3']
+    L, B = 170666, 64
+    x1 = so.synth_iq(cfg, B * L, 21)
+    x2 = so.synth_iq(dict(cfg, noise=5e-3), B * L, 22)
+    outs = []
+    for x in (x1, x2, (x1 + 2 * x2).astype(np.complex64)):
+        P, g = make_gpu_receivers(cfg, max_batch_chunks=B)
+        ctx = P._pysdr_stream
+        ctx.process_batch(x, B, L, on_device=False)
+        outs.append([ctx.fetch(i, B)[1].astype(np.complex128) for i in range(len(g))])
+        ctx.close()
+    for i in range(len(outs[0])):
+        want = outs[0][i] + 2 * outs[1][i]
+        assert np.max(np.abs(outs[2][i] - want)) <= 2e-6 * np.max(np.abs(want)), i
