@@ -118,6 +118,7 @@ struct pysdr_ctx {
   // tuning / profiling
   int tile_bytes = 0, threads = 1024;  // per LDS buffer (two per workgroup); 0 = as large as fits
   int wgs_per_cu = 1, num_cus = 256;
+  int dbg_flags = 0, yflush_cap = 0;      // tuning / diagnostic switches, read from the environment once
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
   hipEvent_t ev[kSlots][4] = {};
@@ -142,6 +143,8 @@ struct pysdr_spectrum {
   rocfft_execution_info info = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipEvent_t ev_order = nullptr;
+  bool force_rocfft = false;  // PYSDR_PSD_ROCFFT: rocFFT even for the 32768 -> 65536 size
+  int group = 448;            // frames per launch pair of the four-step path (PYSDR_PSD_GROUP)
 };
 
 // N4: ingest ring.  Pinned host chunk buffers the device reads directly over PCIe (async H2D on
@@ -266,8 +269,7 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   const int ratio = (down + up - 1) / up;
   const size_t taps_bytes = (size_t)nrx * up * d.kpad * sizeof(float2);
   // two tile buffers + the taps must fit the LDS share of one workgroup
-  int wgs = c->wgs_per_cu;
-  { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) wgs = atoi(e); }
+  const int wgs = c->wgs_per_cu;
   const long lds_share = (160L * 1024) / wgs - 512;
   // tile_bytes == 0: the largest tile the LDS share allows (fewer tiles = less per-tile
   // scalar work, the kernel's scarcest resource).  What is left over holds the output stage
@@ -301,7 +303,7 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   }
   a.tile_out = (int)tile_out;
   a.tile_cap = (int)cap;
-  { const char* e = getenv("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0 && atoi(e) < yflush) yflush = atoi(e); }
+  if (c->yflush_cap > 0 && c->yflush_cap < yflush) yflush = c->yflush_cap;
   a.yflush = (int)yflush;
   a.ycap = (int)(yflush * tile_out);
   a.tpc = (int)((((tile_out + up - 1) / up) + 3) >> 2);
@@ -317,7 +319,7 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   a.peak = peak ? peak : c->d_peak_scratch;
   a.chunk_len = peak ? (uint32_t)chunk_len : (uint32_t)std::max<size_t>(n, 1);
   a.magic_chunk = (a.chunk_len == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned long long)a.chunk_len) + 1u;
-  { const char* e = getenv("PYSDR_DEBUG_FLAGS"); a.dbg = e ? atoi(e) : 0; }
+  a.dbg = c->dbg_flags;
   int rc = launch_mixdec(a, c->threads, c->num_cus * wgs, c->stream);
   if (rc) return rc;
   rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, c->stream);
@@ -467,6 +469,10 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   // lines (partial lines are written through as masked writes = read-modify-write at the DRAM)
   c->hy = ((((cfg->ntaps_af + 7) & ~7) + 4 + 1) + 15) & ~15;
   c->cap_samples = (size_t)cfg->max_chunks * (size_t)cfg->in_chunk;
+  // tuning / ablation switches (bench.py and DESIGN.md 4.1 use them; all default to off)
+  { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) c->wgs_per_cu = atoi(e); }
+  { const char* e = getenv("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0) c->yflush_cap = atoi(e); }
+  { const char* e = getenv("PYSDR_DEBUG_FLAGS"); c->dbg_flags = e ? atoi(e) : 0; }
   c->mmax = (int)((c->cap_samples * (size_t)cfg->up) / (size_t)cfg->down) + 4;
   {
     hipDeviceProp_t prop;
@@ -1006,6 +1012,8 @@ int pysdr_spectrum_create(int device, int chunk_size, int nfft, int max_frames, 
   }
   pysdr_spectrum* sp = new pysdr_spectrum();
   sp->device = device; sp->chunk = chunk_size; sp->nfft = nfft; sp->max_frames = max_frames;
+  sp->force_rocfft = getenv("PYSDR_PSD_ROCFFT") != nullptr;
+  { const char* e = getenv("PYSDR_PSD_GROUP"); if (e && atoi(e) > 0) sp->group = atoi(e); }
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_error("pysdr_spectrum_create: %s -> %s", #e, hipGetErrorString(_e)); pysdr_spectrum_destroy(sp); return PYSDR_ERR_HIP; } } while (0)
   CK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
   CK(hipMalloc(&sp->d_win, (size_t)chunk_size * sizeof(float)));
@@ -1059,7 +1067,7 @@ static int ensure_work(pysdr_spectrum* sp, size_t frames) {
 static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int nframes, int is_complex,
                         int db, float* d_out) {
   int rc;
-  if (is_complex && sp->chunk == 32768 && sp->nfft == 65536 && !getenv("PYSDR_PSD_ROCFFT")) {
+  if (is_complex && sp->chunk == 32768 && sp->nfft == 65536 && !sp->force_rocfft) {
     // the RF-waterfall size: fused four-step transform, in groups of 448 frames: the 224 MB
     // of intermediate of one group then stays in the 256 MB Infinity Cache between the two
     // kernels (the input and the PSD stream past it with non-temporal accesses).  Measured per
@@ -1067,8 +1075,7 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
     // streaming hints, 3.6 ms at 576 (no longer fits); below 128 frames launch gaps dominate.
     // Running the rows of group g beside the columns of group g+1 on a second stream was
     // tried and is slower (3.9 ms): the two working sets evict each other.
-    const char* ge = getenv("PYSDR_PSD_GROUP");
-    int group = ge ? atoi(ge) : 448;
+    int group = sp->group;
     if (group < 1) group = 1;
     rc = ensure_work(sp, (size_t)std::min(group, nframes));
     if (rc) return rc;
