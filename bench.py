@@ -1,21 +1,35 @@
 #!/usr/bin/env python3
 """Throughput of the pySDR receiver hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--workload c1|c2|c3|c4|c4mono] [--split stream|rx]
 
-One "step" = one pass of the hot path over one device-resident batch of `--chunks` chunks of
-one synthetic 8 MS/s wideband stream: the fused mix+decimate kernel for all 4 sub-receivers
-(USB/CW/NBFM/AM), the 48 kHz detector/AF/AGC kernels, and the RF
-PSD (chunk 32768 -> 64k FFT, every sample PSD'd) on its own HIP stream.  With N GPUs every rank
-runs its own independent stream (config C5: shard by stream, no data-path collective; weak
-scaling).  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one device-resident batch of `--chunks` chunks of one
+synthetic wideband stream.  Default workload = SURVEY.md 8(d) config C3: the fused mix+decimate
+kernel for all 4 sub-receivers (USB/CW/NBFM/AM), the 48 kHz detector/AF/AGC kernels, and the RF
+PSD (chunk 32768 -> 64k FFT, every sample PSD'd).  The other BASELINE configurations run through
+the same tool: c1 (am.py path: 2.048 MS/s, 1 RX AM, 1001 taps), c2 (8 MS/s, 1 RX NBFM), c4 / c4mono
+(10 MS/s broadcast FM, pilot-PLL stereo / mono).
+
+N > 1: one process per GPU.  Started by `torch.distributed.run` (RANK/LOCAL_RANK/WORLD_SIZE in the
+environment) or, when those are absent, by this script itself: the parent starts N children
+BEFORE it makes any GPU call, waits for them and exits with their worst code; rank 0 prints the
+ONE JSON line.
+  --split stream (default, config C5): every rank runs its own independent stream, no data-path
+      collective, weak scaling;
+  --split rx: ONE stream, sub-receiver r on rank r mod N; rank 0's batch is broadcast to the other
+      GPUs with RCCL (pysdr_comm_bcast = ncclBroadcast over xGMI) every step -- the analogue of
+      MP_SCHEME 3's queue fan-out (receiver.py:728-739); strong scaling over the RX count.
+torch.distributed (gloo) is control plane only: rendezvous, barrier, max-over-ranks clock.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,15 +41,20 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PSD_CHUNK, PSD_NFFT = 32768, 65536
+DEFAULT_CHUNKS = {"c1": 4096, "c2": 2048, "c3": 2048, "c4": 1024, "c4mono": 1024}
+TUNING_ENV = ("PYSDR_MIXDEC_WGS", "PYSDR_MIXDEC_YFLUSH", "PYSDR_DEBUG_FLAGS", "PYSDR_PSD_GROUP",
+              "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
-    ap.add_argument("--chunks", type=int, default=2048, help="chunks per step (batch resident in HBM)")
+    ap.add_argument("--workload", default="c3", choices=sorted(DEFAULT_CHUNKS))
+    ap.add_argument("--split", default="stream", choices=["stream", "rx"])
+    ap.add_argument("--chunks", type=int, default=0, help="chunks per step (batch resident in HBM); 0 = workload default")
+    ap.add_argument("--nrx", type=int, default=0, help="c3 only: first NRX of a 6-RX list (reference MAX_RX), 0 = the 4 of C3")
     ap.add_argument("--no-psd", action="store_true")
     ap.add_argument("--no-cpu-mp", action="store_true", help="skip the one-process-per-RX CPU figure")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
@@ -46,19 +65,81 @@ def parse():
     ap.add_argument("--tile-bytes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-chunks", type=int, default=640, help="chunks timed on the CPU oracle (about 10 s)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks timed on the CPU oracle (0 = about 10 s worth)")
+    return ap.parse_args(argv)
 
 
-def build_receivers(cfg, device, max_chunks):
+# ---------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes.  Nothing in this
+    process has touched the GPU (no library load, no device count), and no process that has is
+    ever exec'ed: the children are fresh interpreters."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT))
+    rc = 0
+    deadline = time.time() + 3600
+    for p in procs:
+        try:
+            rc = max(rc, abs(p.wait(timeout=max(1.0, deadline - time.time()))))
+        except subprocess.TimeoutExpired:
+            rc = max(rc, 124)
+    for p in procs:
+        if p.poll() is None:
+            p.kill()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+RX6 = [dict(frq=200e3, mode='USB', video_bw=10e3, af_bw=3e3),
+       dict(frq=-310e3, mode='CW', video_bw=10e3, af_bw=500.0, bfo=700.0),
+       dict(frq=455e3, mode='NFM', video_bw=20e3, af_bw=4e3),
+       dict(frq=-1.2e6, mode='AM', video_bw=10e3, af_bw=5e3),
+       dict(frq=900e3, mode='LSB', video_bw=10e3, af_bw=3e3),
+       dict(frq=-2.1e6, mode='AM', video_bw=10e3, af_bw=5e3)]
+
+
+def workload_cfg(args):
+    """cfg dict in the shape of pysdr_amd.synth.CONFIGS (+ 'wfm': mono/stereo for C4)."""
+    from pysdr_amd.synth import CONFIGS
+    w = args.workload
+    if w in ("c1", "c2", "c3"):
+        cfg = dict(CONFIGS[w.upper()])
+        if w == "c3" and args.nrx:
+            cfg['rx'] = RX6[:args.nrx]
+        return cfg
+    return dict(fs=10e6, fs_out=48e3, ntaps_dec=255, wfm=('WFM2' if w == "c4" else 'WFM'),
+                rx=[dict(frq=300e3, mode=('WFM2' if w == "c4" else 'WFM'), video_bw=200e3)])
+
+
+def synth_batch(cfg, n, seed):
+    from pysdr_amd.synth import synth_iq, synth_wfm
+    if 'wfm' in cfg:
+        return synth_wfm(cfg['fs'], n, seed)
+    return synth_iq(cfg, n, seed)
+
+
+def build_receivers(cfg, device, max_chunks, rx_idx=None):
+    """sig_proc.Receiver objects of the workload on one context; rx_idx = this rank's share."""
     from pysdr_amd import sig_proc
     from pysdr_amd.params import RunTimeParams
-    r0 = cfg['rx'][0]
-    P = RunTimeParams(fs=cfg['fs'], fsout=cfg['fs_out'], fc=[14.2e6] * len(cfg['rx']),
+    rxl = cfg['rx'] if rx_idx is None else [cfg['rx'][i] for i in rx_idx]
+    if not rxl:
+        return None, []
+    r0 = rxl[0]
+    kw = dict(foffset=300e3, vid_bw=200e3) if 'wfm' in cfg else {}
+    P = RunTimeParams(fs=cfg['fs'], fsout=cfg['fs_out'], fc=[14.2e6] * len(rxl),
                       mode=r0['mode'], nfilt=cfg['ntaps_dec'], device=device,
-                      max_batch_chunks=max_chunks)
+                      max_batch_chunks=max_chunks, **kw)
     rxs = []
-    for i, r in enumerate(cfg['rx']):
+    for i, r in enumerate(rxl):
         P.VIDEO_BW = r.get('video_bw', 10e3)
         rx = sig_proc.Receiver(P, r['frq'], i, str(i + 1))
         rx.mode, rx.af_bw, rx.bfo = r['mode'], r.get('af_bw', 0.0), r.get('bfo', 0.0)
@@ -67,6 +148,15 @@ def build_receivers(cfg, device, max_chunks):
     for rx in rxs:
         rx._sync_controls()
     return P, rxs
+
+
+def oracle_receivers(cfg):
+    from oracle import sdr_oracle as so
+    if 'wfm' in cfg:
+        from oracle import wfm_oracle as wo
+        return [wo.WfmReceiver(cfg['fs'], cfg['fs_out'], r['frq'], stereo=(cfg['wfm'] == 'WFM2'),
+                               ntaps_dec=cfg['ntaps_dec'], video_bw=r['video_bw']) for r in cfg['rx']]
+    return so.make_receivers(cfg, np.float32)
 
 
 def cpu_baseline(cfg, nchunks, with_psd, seed):
@@ -80,11 +170,19 @@ def cpu_baseline(cfg, nchunks, with_psd, seed):
         limiter = None
     L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
     uniq = 8                              # same 8-chunk synthetic loop the GPU batch is built from
-    x = so.synth_iq(cfg, uniq * L, seed)
-    rxs = so.make_receivers(cfg, np.float32)
+    x = synth_batch(cfg, uniq * L, seed)
+    rxs = oracle_receivers(cfg)
     sp = so.Spectrum(cfg['fs'] / 1e3, PSD_CHUNK, PSD_NFFT, 0.0, np.float32)
     for rx in rxs:                       # warm-up chunk (BLAS init, page faults)
         rx.demod_data(x[:L])
+    if nchunks <= 0:                     # size the sample to about 10 s from one timed chunk
+        t0 = time.perf_counter()
+        for rx in rxs:
+            rx.demod_data(x[L:2 * L])
+        if with_psd:
+            for i in range(0, L - PSD_CHUNK + 1, PSD_CHUNK):
+                sp.periodogram(x[i:i + PSD_CHUNK], True)
+        nchunks = int(max(4, min(4096, 10.0 / max(time.perf_counter() - t0, 1e-4))))
     t0 = time.perf_counter()
     for k in range(nchunks):
         xc = x[(k % uniq) * L:(k % uniq + 1) * L]
@@ -99,7 +197,7 @@ def cpu_baseline(cfg, nchunks, with_psd, seed):
     return dict(value=nchunks * L / dt / 1e6, unit="MS/s", cores=1, kind="port",
                 sample=f"{nchunks} chunks x {L} samples ({nchunks * L / cfg['fs']:.2f} s of signal), "
                        f"{len(rxs)} RX serial{' + 64k PSD' if with_psd else ''}, float32 NumPy/SciPy oracle, "
-                       f"{dt:.1f} s wall; host has {os.cpu_count()} cores")
+                       f"{dt:.1f} s wall; host has {os.cpu_count()} cores"), nchunks
 
 
 def _cpu_worker(job):
@@ -114,9 +212,9 @@ def _cpu_worker(job):
         pass
     L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
     uniq = 8
-    x = so.synth_iq(cfg, uniq * L, seed)
+    x = synth_batch(cfg, uniq * L, seed)
     if irx >= 0:
-        rx = so.make_receivers(cfg, np.float32)[irx]
+        rx = oracle_receivers(cfg)[irx]
         rx.demod_data(x[:L])
         t0 = time.perf_counter()
         for k in range(nchunks):
@@ -131,19 +229,21 @@ def _cpu_worker(job):
     return time.perf_counter() - t0
 
 
-def cpu_baseline_per_rx(workload, cfg, nchunks, with_psd, seed):
+def cpu_baseline_per_rx(args, cfg, nchunks, with_psd, seed):
     """The analogue of the reference's MP_SCHEME 3 (one process per sub-receiver,
     receiver.py:726-739): NUM_RX (+1 for the PSD) single-threaded child processes
     (`bench.py --cpu-worker`, plain subprocesses with a deadline: the parent holds a HIP context
     and must neither fork it nor ever wait forever) over the same sample; the job's rate is set
     by the slowest of them.  Returns None if a child fails."""
-    import subprocess
     from oracle import sdr_oracle as so
     L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
     ids = list(range(len(cfg['rx']))) + ([-1] if with_psd else [])
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
     t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--workload", workload,
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i),
+                               "--workload", args.workload, "--nrx", str(args.nrx),
                                "--cpu-chunks", str(nchunks), "--cpu-seed", str(seed)],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT)
              for i in ids]
@@ -165,31 +265,60 @@ def cpu_baseline_per_rx(workload, cfg, nchunks, with_psd, seed):
                        f"({', '.join('%.1f' % t for t in times)}), {wall:.1f} s wall incl. start-up")
 
 
-def measured_traffic(args, nrx, B):
-    """HBM bytes per mix+decimate launch from the committed PMC passes (FETCH_SIZE x2 on
-    gfx950 + WRITE_SIZE), valid only for the configuration that was profiled."""
-    if args.workload != "c3" or B != 2048 or nrx != 4:
-        return None
+def source_sha(name):
     try:
-        rows = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        return [r["hbm_bytes_per_launch"] for r in rows if r["kernel"] == "mixdec_kernel"][0]
-    except Exception:
+        return hashlib.sha256(open(os.path.join(ROOT, "pysdr_amd", "csrc", name), "rb").read()).hexdigest()[:16]
+    except OSError:
         return None
+
+
+def measured_traffic(args, nrx, B, kernel_prefix, sources):
+    """HBM bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950
+    correction of MI355X_MICROARCH.md), or None: valid only for the profiled configuration AND only
+    while the kernel sources still hash to what was profiled (the profile file carries the hashes)."""
+    if args.workload != "c3" or B != 2048 or nrx != 4 or args.no_psd:
+        return None, None
+    for tag in ("r02", "r01"):
+        p = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        try:
+            doc = json.load(open(p))
+        except Exception:
+            continue
+        rows = doc["kernels"] if isinstance(doc, dict) else doc
+        stamp = doc.get("source_sha256", {}) if isinstance(doc, dict) else {}
+        if any(stamp.get(s) != source_sha(s) for s in sources):
+            return None, f"profiles/{tag}_pmc_traffic.json is stale: {', '.join(sources)} changed since it was collected"
+        tot = sum(r["hbm_bytes_per_launch"] for r in rows if r["kernel"].startswith(kernel_prefix))
+        if tot > 0:
+            return tot, (f"profiles/{tag}_pmc_traffic.json (git {doc.get('git_head', '?') if isinstance(doc, dict) else '?'}): "
+                         "2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of this same command")
+    return None, None
 
 
 def main():
     args = parse()
+    cfg = workload_cfg(args)
     if args.cpu_worker is not None:      # child of cpu_baseline_per_rx: CPU only, never touches the GPU
-        from pysdr_amd.synth import CONFIGS
-        print(_cpu_worker((CONFIGS[args.workload.upper()], args.cpu_chunks, args.cpu_seed, args.cpu_worker)))
-        return
+        print(_cpu_worker((cfg, args.cpu_chunks, args.cpu_seed, args.cpu_worker)))
+        return 0
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return spawn_ranks(args)     # before ANY GPU call in this process
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a mislabelled number",
+                  file=sys.stderr)
+            return 2
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
 
     # Load the HIP library BEFORE torch so that both share one libamdhip64.
     from pysdr_amd import _lib
-    from pysdr_amd.synth import CONFIGS, synth_iq
     lib = _lib.lib()
     _lib.require_gpu()
     ndev = _lib.device_count()
@@ -201,25 +330,40 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    cfg = CONFIGS[args.workload.upper()]
-    with_psd = (args.workload == "c3") and not args.no_psd
-    B = args.chunks
-    P, rxs = build_receivers(cfg, device, B)
-    ctx = P._pysdr_stream
-    L = P.IN_CHUNK_SIZE
+    split_rx = args.split == "rx"
+    if split_rx and world > ndev:
+        raise SystemExit(f"--split rx needs one GPU per rank (RCCL): {world} ranks, {ndev} device(s)")
+    with_psd = (args.workload == "c3") and not args.no_psd and (not split_rx or rank == 0)
+    B = args.chunks or DEFAULT_CHUNKS[args.workload]
+    nrx_total = len(cfg['rx'])
+    from pysdr_amd import multi
+    rx_idx = multi.partition_rx(nrx_total, world)[rank] if split_rx else None
+    P, rxs = build_receivers(cfg, device, B, rx_idx)
+    from pysdr_amd import rates
+    L = P.IN_CHUNK_SIZE if P is not None else rates.derive(cfg['fs'], cfg['fs_out'])['IN_CHUNK_SIZE']
+    ctx = P._pysdr_stream if P is not None else None
+    if ctx is None:                       # a rank without sub-receivers still takes part in the broadcast
+        from pysdr_amd import sig_proc
+        from pysdr_amd.params import RunTimeParams
+        P = RunTimeParams(fs=cfg['fs'], fsout=cfg['fs_out'], fc=[14.2e6], mode='AM', nfilt=cfg['ntaps_dec'],
+                          device=device, max_batch_chunks=B)
+        ctx = sig_proc._context_for(P)
     nsamp = B * L
     if args.tile_bytes or args.threads:
         _lib.check(lib.pysdr_set_tile(ctx.h, args.tile_bytes, args.threads or 1024), "set_tile")
 
     # synthetic stream: 8 unique chunks (seed per rank = its own stream), repeated to fill the batch
     uniq = 8
-    xu = synth_iq(cfg, uniq * L, 10 + rank)
+    seed = 10 + (0 if split_rx else rank)
     d_x = C.c_void_p()
     _lib.check(lib.pysdr_dev_alloc(device, nsamp * 8, C.byref(d_x)), "alloc x")
-    for k in range(0, B, uniq):
-        n = min(uniq, B - k) * L
-        _lib.check(lib.pysdr_dev_upload(device, C.c_void_p(d_x.value + k * L * 8),
-                                        C.c_void_p(xu.ctypes.data), n * 8), "upload")
+    if not split_rx or rank == 0:
+        xu = synth_batch(cfg, uniq * L, seed)
+        for k in range(0, B, uniq):
+            n = min(uniq, B - k) * L
+            _lib.check(lib.pysdr_dev_upload(device, C.c_void_p(d_x.value + k * L * 8),
+                                            C.c_void_p(xu.ctypes.data), n * 8), "upload")
+    bc = multi.RcclBroadcaster(ctx, dist) if split_rx else None
 
     sp = None
     nframes = nsamp // PSD_CHUNK
@@ -233,7 +377,13 @@ def main():
         _lib.check(lib.pysdr_dev_alloc(device, nframes * PSD_NFFT * 4, C.byref(d_psd)), "alloc psd")
 
     def step():
-        if not args.no_demod:
+        if bc is not None:
+            # the wideband batch travels root -> every GPU on the context's stream, in front of the
+            # kernels that read it (ncclBroadcast over xGMI)
+            if sp is not None:
+                _lib.check(lib.pysdr_spectrum_order(sp, ctx.h, 1), "spectrum_order")   # PSD of the last step has read d_x
+            bc.bcast(d_x.value, nsamp * 8, 0)
+        if not args.no_demod and rxs:
             ctx.process_batch(d_x.value, B, L, on_device=True)
         if sp is not None:
             # Same order as pySDR's RX thread (demod of the chunk, then its PSD): the two are
@@ -264,97 +414,131 @@ def main():
     for _ in range(args.steps):
         step()
     sync()
+    dt_local = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
 
-    # dominant kernel (fused mix+decimate): HIP events on its stream, averaged over the timed steps
-    nev = 0 if args.no_demod else min(args.steps, 64)
+    # kernel timings: HIP events on the stream the kernels run on, averaged over the timed steps
+    nev = 0 if (args.no_demod or not rxs) else min(args.steps, 64)
     ms = C.c_float(0)
-    k1 = []
-    k2 = []
+    k1, k2 = [], []
     for back in range(nev):
         _lib.check(lib.pysdr_get_elapsed_ms(ctx.h, 0, back, C.byref(ms)), "elapsed")
         k1.append(ms.value)
         _lib.check(lib.pysdr_get_elapsed_ms(ctx.h, 1, back, C.byref(ms)), "elapsed")
         k2.append(ms.value)
     k1_ms = float(np.mean(k1)) if k1 else float('nan')
+    k2_ms = float(np.mean(k2)) if k2 else None
     psd_ms = None
     if sp is not None:
         _lib.check(lib.pysdr_spectrum_elapsed_ms(sp, C.byref(ms)), "psd elapsed")
         psd_ms = ms.value
 
+    per_rank_ms = [dt_local / args.steps * 1e3]
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        allt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([dt_local / args.steps * 1e3], dtype=torch.float64))
+        per_rank_ms = [float(v.item()) for v in allt]
+
+    tune = (C.c_int32 * 8)()
+    _lib.check(lib.pysdr_get_tuning(ctx.h, tune), "get_tuning")
+    sp_tune = (C.c_int32 * 4)()
+    if sp is not None:
+        _lib.check(lib.pysdr_spectrum_get_tuning(sp, sp_tune), "spectrum_get_tuning")
+    ablated = bool(tune[1])               # work-skipping switches active (diagnostic build only)
 
     nrx = len(rxs)
+    is_wfm = 'wfm' in cfg
     n_out = nsamp * P.UP // P.DOWN
-    # algorithmic bytes of ONE mix+decimate launch: every input sample once (8 B, shared by all
-    # RX) + the baseband IQ it writes (8 B per RX per output)   [SURVEY.md 8(d), DESIGN.md 5]
-    k1_bytes = nsamp * 8 + nrx * n_out * 8
-    achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
-    bytes_per_sample_job = 8.0 + nrx * (P.UP / P.DOWN) * 12.0 + (4.0 * PSD_NFFT / PSD_CHUNK if with_psd else 0.0)
+    # algorithmic bytes of ONE front-end launch: every input sample once (8 B, shared by all RX) +
+    # the baseband / IF IQ it writes (8 B per RX per output)   [SURVEY.md 8(d), DESIGN.md 5]
+    n_front_out = (nsamp // rxs[0].demod.wfm_d1) if (is_wfm and rxs) else n_out
+    k1_bytes = nsamp * 8 + nrx * n_front_out * 8
+    psd_bytes = nframes * (PSD_CHUNK * 8 + PSD_NFFT * 4)
+    # whole job, SURVEY 8(d): input once + baseband IQ (8 B) and audio (4 B) per RX per output (+ PSD out)
+    bytes_per_sample_job = 8.0 + nrx_total * (P.UP / P.DOWN) * 12.0 + (4.0 * PSD_NFFT / PSD_CHUNK if (args.workload == "c3" and not args.no_psd) else 0.0)
+    streams = 1 if split_rx else world
+    job_rate = streams * nsamp * args.steps / dt          # input samples per second, whole job
+
+    def roof(kernel, nbytes, t_ms, traffic=(None, None), **extra):
+        if t_ms is None or not (t_ms > 0) or ablated:
+            return None
+        a = nbytes / (t_ms * 1e-3) / 1e9
+        d = dict(kernel=kernel, bound="hbm", achieved=a, peak=HBM_PEAK_GBPS, unit="GB/s", frac=a / HBM_PEAK_GBPS,
+                 traffic=traffic[0], traffic_source=traffic[1], algorithmic_bytes_per_launch=nbytes, avg_launch_ms=t_ms)
+        d.update(extra)
+        return d
+
+    front_name = (f"mixdec_kernel<{nrx}> (fused NCO mix + polyphase decimate, all RX)" if not is_wfm else
+                  "mixdec_kernel<1,16> + wfm_disc/pll + mixdec_kernel<1,..> (FM front end: IF decimate, discriminator, pilot PLL, audio resample)")
+    r_front = roof(front_name, k1_bytes, k1_ms if k1 else None,
+                   measured_traffic(args, nrx, B, "mixdec", ["mixdec.hip"]))
+    r_psd = roof("psd kernels (window, zero-pad, 64k FFT, |.|^2, dB, fftshift)", psd_bytes, psd_ms,
+                 measured_traffic(args, nrx, B, "psd", ["psdfft.hip"]),
+                 note="one call = all frames of the batch; per launch figures are per call")
+    # the kernel (group) that dominates the timed region carries the headline roofline object
+    dominant = r_psd if (r_psd is not None and (not k1 or psd_ms >= k1_ms)) else r_front
 
     out = {
         "metric": "complex IQ MS/s through 4-RX demod chain",
-        "value": world * nsamp * args.steps / dt / 1e6,
+        "value": job_rate / 1e6,
         "unit": "MS/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if split_rx else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": (f"{args.workload.upper()}: 8 MS/s synthetic IQ, {nrx} RX "
-                         f"({'/'.join(r['mode'] for r in cfg['rx'])}), {cfg['ntaps_dec']}-tap polyphase 3/500"
-                         f"{', + 64k-FFT RF PSD on every sample' if with_psd else ''}; "
-                         f"{B} chunks x {L} samples per step resident in HBM; one stream per GPU"),
+            "workload": (f"{args.workload.upper()}: {cfg['fs'] / 1e6:g} MS/s synthetic IQ, {nrx_total} RX "
+                         f"({'/'.join(r['mode'] for r in cfg['rx'])}), {cfg['ntaps_dec']}-tap prototype {P.UP}/{P.DOWN}"
+                         f"{', + 64k-FFT RF PSD on every sample' if (args.workload == 'c3' and not args.no_psd) else ''}; "
+                         f"{B} chunks x {L} samples per step resident in HBM; "
+                         + ("ONE stream, sub-receivers split over the GPUs, batch broadcast by RCCL each step" if split_rx
+                            else "one stream per GPU")),
             "chunks_per_step": B, "in_chunk": L, "samples_per_step": nsamp,
-            "parallelism": f"stream-sharded x{world} (no data-path collective)",
+            "parallelism": (f"rx-split x{world} (ncclBroadcast of the batch per step)" if split_rx
+                            else f"stream-sharded x{world} (no data-path collective)"),
         },
-        "roofline": {
-            "kernel": "mixdec_kernel<%d> (fused NCO mix + polyphase decimate, all RX)" % nrx,
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": measured_traffic(args, nrx, B),
-            "traffic_source": "profiles/r01_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE of mixdec_kernel, separate rocprofv3 --pmc passes of this same command (null when the config differs from the profiled one)",
-            "algorithmic_bytes_per_launch": k1_bytes,
-            "avg_launch_ms": k1_ms,
-        },
-        "kernel_ms": {"mixdec": k1_ms, "stage2": float(np.mean(k2)) if k2 else None, "psd_last": psd_ms},
-        # the spectral path, same accounting: one call = nframes frames, each reads chunk complex
-        # samples and writes nfft dB values (the 512 KB/frame four-step intermediate is traffic,
-        # not algorithmic bytes)
-        "roofline_psd": None if psd_ms is None else {
-            "kernel": "psd_cols_kernel + psd_rows_kernel (window, zero-pad, 64k FFT, |.|^2, dB, fftshift)",
-            "bound": "hbm",
-            "achieved": nframes * (PSD_CHUNK * 8 + PSD_NFFT * 4) / (psd_ms * 1e-3) / 1e9,
-            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": nframes * (PSD_CHUNK * 8 + PSD_NFFT * 4) / (psd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "algorithmic_bytes_per_call": nframes * (PSD_CHUNK * 8 + PSD_NFFT * 4),
-            "avg_call_ms": psd_ms,
-        },
-        "job_bytes_per_sample": bytes_per_sample_job,
-        "job_hbm_frac_per_gpu": (nsamp * args.steps / dt) * bytes_per_sample_job / 1e9 / HBM_PEAK_GBPS,
+        "per_rank_ms": per_rank_ms,
+        "rccl_ranks": world if split_rx else 0,
+        "roofline": dominant,
+        "roofline_mixdec": r_front,
+        "roofline_psd": r_psd,
+        "roofline_job": None if ablated else {
+            "bound": "hbm", "achieved": job_rate / world * bytes_per_sample_job / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": job_rate / world * bytes_per_sample_job / 1e9 / HBM_PEAK_GBPS,
+            "algorithmic_bytes_per_sample": bytes_per_sample_job,
+            "note": "per GPU: whole-step wall clock against SURVEY 8(d)'s compulsory bytes per input sample"},
+        "kernel_ms": {"front": k1_ms if k1 else None, "stage2": k2_ms, "psd_call": psd_ms},
+        "tuning": {"diag_build": int(tune[0]), "debug_flags": int(tune[1]), "mixdec_wgs_per_cu": int(tune[2]),
+                   "mixdec_yflush_cap": int(tune[3]), "tile_bytes": int(tune[4]), "threads": int(tune[5]),
+                   "psd_group": int(sp_tune[0]) if sp is not None else None,
+                   "psd_rocfft": int(sp_tune[1]) if sp is not None else None,
+                   "env": {k: os.environ[k] for k in TUNING_ENV if k in os.environ},
+                   "flags": [a for a in sys.argv[1:] if a.startswith("--") and a not in ("--gpus", "--steps", "--warmup")]},
+        "source_sha256": {s: source_sha(s) for s in ("mixdec.hip", "psdfft.hip", "stage2.hip", "api.hip")},
     }
+    if ablated:
+        out["invalid"] = "PYSDR_DEBUG_FLAGS != 0 in a diagnostic build: work was skipped, no roofline is reported"
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_chunks, with_psd, 10)
-        if not args.no_cpu_mp:
-            out["cpu_baseline_per_rx_process"] = cpu_baseline_per_rx(args.workload, cfg, args.cpu_chunks, with_psd, 10)
+        out["cpu_baseline"], used = cpu_baseline(cfg, args.cpu_chunks, with_psd, 10)
+        if not args.no_cpu_mp and not is_wfm:
+            out["cpu_baseline_per_rx_process"] = cpu_baseline_per_rx(args, cfg, used, with_psd, 10)
     elif rank == 0:
         out["cpu_baseline"] = None
 
+    if bc is not None:
+        bc.close()
     if sp is not None:
         lib.pysdr_spectrum_destroy(sp)
         lib.pysdr_dev_free(device, d_psd)
@@ -365,7 +549,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

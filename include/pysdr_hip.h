@@ -144,6 +144,10 @@ int pysdr_set_profile(pysdr_ctx* ctx, int enable);
 int pysdr_get_elapsed_ms(pysdr_ctx* ctx, int which, int back, float* ms);
 /* tuning knob: LDS bytes of input tile per workgroup in the mix+decimate kernel */
 int pysdr_set_tile(pysdr_ctx* ctx, int tile_bytes, int threads);
+/* What the context was really created with, so that a benchmark line can echo it (VERDICT r1
+ * hygiene): out = {diagnostic build (-DPYSDR_DIAG) 0/1, PYSDR_DEBUG_FLAGS (always 0 outside a
+ * diagnostic build), workgroups per CU, output-stage flush cap, tile bytes, threads, CUs, 0}. */
+int pysdr_get_tuning(pysdr_ctx* ctx, int32_t out[8]);
 
 /* ---- signal_generator.quad_mixer (receiver.py:552-553,822) --------------------
  * y = x * exp(+j*phi_n), 32-bit phase accumulator, returns phase after n samples */
@@ -168,6 +172,8 @@ int pysdr_spectrum_frame(pysdr_spectrum* sp, const float* x, int is_complex, int
 int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size_t hop,
                          void* d_out);
 int pysdr_spectrum_sync(pysdr_spectrum* sp);
+/* out = {frames per launch group of the fused 64k path, rocFFT forced 0/1, 0, 0} */
+int pysdr_spectrum_get_tuning(pysdr_spectrum* sp, int32_t out[4]);
 int pysdr_spectrum_elapsed_ms(pysdr_spectrum* sp, float* ms);
 /* Ordering between the spectrum's stream and a receiver context's stream (both read the same
  * device-resident chunk; Plotting.py:462 runs the PSD after the chunk's demod in one thread):

@@ -8,7 +8,10 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpysdr_hip.so")
+# the diagnostic build (work-skipping ablation switches compiled in) is a different file and is
+# only ever loaded on explicit request
+LIB_PATH = os.path.join(HERE, "libpysdr_hip_diag.so" if os.environ.get("PYSDR_USE_DIAG_LIB") == "1"
+                        else "libpysdr_hip.so")
 
 MAX_RX = 8
 
@@ -64,6 +67,7 @@ PROTOTYPES = {
     "pysdr_set_profile": (_i, [_vp, _i]),
     "pysdr_get_elapsed_ms": (_i, [_vp, _i, _i, _pf]),
     "pysdr_set_tile": (_i, [_vp, _i, _i]),
+    "pysdr_get_tuning": (_i, [_vp, C.POINTER(C.c_int32)]),
     "pysdr_quad_mixer": (_i, [_i, _pf, _pf, _sz, _u32, _u32, C.POINTER(_u32)]),
     "pysdr_freq_word": (_u32, [_d, _d, _pd]),
     "pysdr_fir_real": (_i, [_i, _pf, _pf, _i, _pf, _sz]),
@@ -72,6 +76,7 @@ PROTOTYPES = {
     "pysdr_spectrum_frame": (_i, [_vp, _pf, _i, _i, _pf, _pi]),
     "pysdr_spectrum_batch": (_i, [_vp, _vp, _i, _sz, _vp]),
     "pysdr_spectrum_sync": (_i, [_vp]),
+    "pysdr_spectrum_get_tuning": (_i, [_vp, C.POINTER(C.c_int32)]),
     "pysdr_spectrum_elapsed_ms": (_i, [_vp, _pf]),
     "pysdr_spectrum_order": (_i, [_vp, _vp, _i]),
     "pysdr_ingest_create": (_i, [_vp, _i, C.POINTER(_vp)]),

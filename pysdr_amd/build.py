@@ -14,6 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpysdr_hip.so")
+LIB_DIAG = os.path.join(HERE, "libpysdr_hip_diag.so")   # loaded only when PYSDR_USE_DIAG_LIB=1
 SOURCES = ["api.hip", "mixdec.hip", "stage2.hip", "misc.hip", "psdfft.hip", "waterfall.hip"]
 # per-file extra flags (none needed today; -fno-slp-vectorize on mixdec.hip folds the DPP
 # reduction into v_add_f32_dpp but measured the same 96-99 us, so the default stays)
@@ -31,16 +32,19 @@ def needs_build():
     return (not os.path.exists(LIB)) or os.path.getmtime(LIB) < _newest_source_mtime()
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+def build(force=False, verbose=True, diag=False):
+    """``diag=True`` (``--diag``) compiles the work-skipping ablation switches of the mix+decimate
+    kernel in (-DPYSDR_DIAG, read from PYSDR_DEBUG_FLAGS); the default build has none."""
+    if not force and not diag and not needs_build():
         return LIB
+    lib_out = LIB_DIAG if diag else LIB
     hipcc = os.path.join(ROCM, "bin", "hipcc")
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, src.replace(".hip", ".diag.o" if diag else ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
-               "-Wno-unused-function", "-ffp-contract=off",
+               "-Wno-unused-function", "-ffp-contract=off", *(["-DPYSDR_DIAG"] if diag else []),
                *EXTRA_FLAGS.get(src, []),
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
@@ -50,15 +54,14 @@ def build(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + \
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_out] + objs + \
           ["-L" + os.path.join(ROCM, "lib"), "-lrocfft", "-ldl",
            "-Wl,-rpath," + os.path.join(ROCM, "lib")]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib_out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print("built", LIB)
+    print("built", build(force="--force" in sys.argv, diag="--diag" in sys.argv))

@@ -111,7 +111,7 @@ struct pysdr_ctx {
   unsigned* d_blkcnt = nullptr;  // [MAX_RX][max_chunks]
   RxDevState* d_state = nullptr; // [MAX_RX]
   // last call
-  int last_nout = 0, last_nchunks = 0;
+  int last_nout = 0, last_nchunks = 0, last_nrx = 0;
   size_t last_chunk_len = 0;
   unsigned long long last_s0 = 0;
   int last_complex[PYSDR_MAX_RX] = {0};
@@ -343,8 +343,35 @@ int wfm_setup(pysdr_ctx* c) {
   return decim_init(c->wfm_front, 1, c->d1, c->cfg.ntaps_dec, PYSDR_MAX_RX);
 }
 
-int apply_pending(pysdr_ctx* c) {
+// What one pysdr_process_batch call uses of the receivers' host-side state.  Taken under
+// c->mu by apply_pending, so that a setter running on another thread (gui.py:1713,1938)
+// between two lines of the launch sequence can only affect the NEXT call: the taps on the
+// device, the NCO word, the detector kind and the buffers it needs always belong together.
+struct RxSnap {
+  int mode = PYSDR_AM;
+  uint32_t fword = 0, phase = 0, bfo_fword = 0;
+  float sq_thresh = 0.f;
+  int taps_real = 0;
+  float2 *d_y = nullptr, *d_ypll = nullptr, *d_a = nullptr, *d_y1 = nullptr, *d_w = nullptr;
+  float* d_am = nullptr;
+  float2* d_aftaps = nullptr;
+};
+struct CallSnap {
+  int nrx = 0, nwfm = 0;
+  RxSnap rx[PYSDR_MAX_RX];
+};
+
+int apply_pending(pysdr_ctx* c, CallSnap* snap) {
   std::lock_guard<std::mutex> lk(c->mu);
+  snap->nrx = c->nrx;
+  snap->nwfm = 0;
+  for (int r = 0; r < c->nrx; ++r) snap->nwfm += is_wfm(c->rx[r].mode) ? 1 : 0;
+  if (snap->nwfm != 0 && snap->nwfm != c->nrx) {
+    // the reference's mode is global (P.MODE) and the rate-reduction order differs for
+    // broadcast FM (receiver.py:718-719): one context runs one pipeline
+    set_last_error("pysdr_process_batch: WFM/WFM2 cannot be mixed with narrow-band modes in one context");
+    return PYSDR_ERR_STATE;
+  }
   for (int r = 0; r < c->nrx; ++r) {
     RxHost& x = c->rx[r];
     if (x.taps_dirty) {
@@ -407,6 +434,11 @@ int apply_pending(pysdr_ctx* c) {
       PYSDR_HIP_CHECK(hipMalloc(&x.d_ypll, n * sizeof(float2)));
       PYSDR_HIP_CHECK(hipMemsetAsync(x.d_ypll, 0, n * sizeof(float2), c->stream));
     }
+    RxSnap& q = snap->rx[r];
+    q.mode = x.mode; q.fword = x.fword; q.phase = x.phase; q.bfo_fword = x.bfo_fword;
+    q.sq_thresh = x.sq_thresh; q.taps_real = x.taps_real;
+    q.d_y = x.d_y; q.d_ypll = x.d_ypll; q.d_a = x.d_a; q.d_am = x.d_am; q.d_aftaps = x.d_aftaps;
+    q.d_y1 = x.d_y1; q.d_w = x.d_w;
   }
   return PYSDR_OK;
 }
@@ -472,15 +504,19 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   // tuning / ablation switches (bench.py and DESIGN.md 4.1 use them; all default to off)
   { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) c->wgs_per_cu = atoi(e); }
   { const char* e = getenv("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0) c->yflush_cap = atoi(e); }
+#ifdef PYSDR_DIAG
+  // work-skipping ablation switches exist only in a diagnostic build (python -m pysdr_amd.build --diag)
   { const char* e = getenv("PYSDR_DEBUG_FLAGS"); c->dbg_flags = e ? atoi(e) : 0; }
+#endif
   c->mmax = (int)((c->cap_samples * (size_t)cfg->up) / (size_t)cfg->down) + 4;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
       c->num_cus = prop.multiProcessorCount;
   }
-  if ((double)c->cap_samples * cfg->up + cfg->down >= 4294967295.0) {
-    set_last_error("pysdr_create: max_chunks*in_chunk*up must stay below 2^32");
+  if ((double)c->cap_samples * cfg->up + cfg->down >= 2147483647.0) {
+    // the same bound decim_run enforces per call (31-bit index arithmetic in the kernel)
+    set_last_error("pysdr_create: max_chunks*in_chunk*up must stay below 2^31");
     delete c;
     return PYSDR_ERR_ARG;
   }
@@ -662,6 +698,18 @@ int pysdr_agc_get(pysdr_ctx* c, int irx, pysdr_agc_state* st) {
   return PYSDR_OK;
 }
 
+int pysdr_get_tuning(pysdr_ctx* c, int32_t out[8]) {
+  if (!c || !out) return PYSDR_ERR_ARG;
+#ifdef PYSDR_DIAG
+  out[0] = 1;
+#else
+  out[0] = 0;
+#endif
+  out[1] = c->dbg_flags; out[2] = c->wgs_per_cu; out[3] = c->yflush_cap;
+  out[4] = c->tile_bytes; out[5] = c->threads; out[6] = c->num_cus; out[7] = 0;
+  return PYSDR_OK;
+}
+
 int pysdr_set_profile(pysdr_ctx* c, int enable) {
   if (!c) return PYSDR_ERR_ARG;
   c->profile = enable;
@@ -753,17 +801,13 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_stage, iq, n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
     d_x = c->d_stage;
   }
-  int nwfm = 0;
-  for (int r = 0; r < c->nrx; ++r) nwfm += is_wfm(c->rx[r].mode) ? 1 : 0;
-  if (nwfm != 0 && nwfm != c->nrx) {
-    // the reference's mode is global (P.MODE) and the rate-reduction order differs for
-    // broadcast FM (receiver.py:718-719): one context runs one pipeline
-    set_last_error("pysdr_process_batch: WFM/WFM2 cannot be mixed with narrow-band modes in one context");
-    return PYSDR_ERR_STATE;
-  }
-  const bool wfm = nwfm > 0;
-  rc = apply_pending(c);
+  // everything below uses the snapshot taken under the lock, never c->rx[] fields a setter may
+  // change (mode / fword / pointers re-read after the lock was released)
+  CallSnap snap;
+  rc = apply_pending(c, &snap);
   if (rc) return rc;
+  const int nrx = snap.nrx;
+  const bool wfm = snap.nwfm > 0;
 
   const int up = c->cfg.up, down = c->cfg.down;
   const unsigned long long s0 = wfm ? c->wfm_front.s_abs : c->main.s_abs;
@@ -771,29 +815,29 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
 
   float2* yptr[PYSDR_MAX_RX];
   uint32_t ph[PYSDR_MAX_RX], fw[PYSDR_MAX_RX];
-  for (int r = 0; r < c->nrx; ++r) { ph[r] = c->rx[r].phase; fw[r] = c->rx[r].fword; }
+  for (int r = 0; r < nrx; ++r) { ph[r] = snap.rx[r].phase; fw[r] = snap.rx[r].fword; }
 
   hipEvent_t* ev = c->ev[c->ncalls % pysdr_ctx::kSlots];
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[0], c->stream));
   DecimResult res;
   int n1 = 0;
   if (!wfm) {
-    for (int r = 0; r < c->nrx; ++r) yptr[r] = c->rx[r].d_y + c->hy;
-    rc = decim_run(c, c->main, d_x, n, c->nrx, yptr, ph, fw, c->d_peak, chunk_len, c->mmax, &res);
+    for (int r = 0; r < nrx; ++r) yptr[r] = snap.rx[r].d_y + c->hy;
+    rc = decim_run(c, c->main, d_x, n, nrx, yptr, ph, fw, c->d_peak, chunk_len, c->mmax, &res);
     if (rc) return rc;
     c->wfm_front.s_abs = c->main.s_abs;       // both pipelines count the same input stream
   } else {
     // SRATE -> fs1 (video filter, all RX in one launch), discriminator + pilot PLL at fs1,
     // then each RX's own fs1 -> FS_OUT resampler
-    for (int r = 0; r < c->nrx; ++r) yptr[r] = c->rx[r].d_y1 + 2;
+    for (int r = 0; r < nrx; ++r) yptr[r] = snap.rx[r].d_y1 + 2;
     DecimResult r1;
-    rc = decim_run(c, c->wfm_front, d_x, n, c->nrx, yptr, ph, fw, c->d_peak, chunk_len, c->m1max, &r1);
+    rc = decim_run(c, c->wfm_front, d_x, n, nrx, yptr, ph, fw, c->d_peak, chunk_len, c->m1max, &r1);
     if (rc) return rc;
     c->main.s_abs = c->wfm_front.s_abs;
     n1 = r1.n_out;
     WfmArgs w;
     memset(&w, 0, sizeof(w));
-    w.nrx = c->nrx; w.n1 = n1;
+    w.nrx = nrx; w.n1 = n1;
     const double fs1 = c->cfg.srate / c->d1;
     w.scale = (float)(fs1 / (2.0 * M_PI * 75e3));
     {
@@ -804,19 +848,19 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
       w.rad2word = (float)(kTwo32 / (2.0 * M_PI));
       w.fword0 = pysdr_freq_word(19000.0, fs1, nullptr);
     }
-    for (int r = 0; r < c->nrx; ++r) {
-      w.y1[r] = c->rx[r].d_y1 + 2;
-      w.y1base[r] = c->rx[r].d_y1;
-      w.w[r] = c->rx[r].d_w;
-      w.stereo[r] = (c->rx[r].mode == PYSDR_WFM2) ? 1 : 0;
+    for (int r = 0; r < nrx; ++r) {
+      w.y1[r] = snap.rx[r].d_y1 + 2;
+      w.y1base[r] = snap.rx[r].d_y1;
+      w.w[r] = snap.rx[r].d_w;
+      w.stereo[r] = (snap.rx[r].mode == PYSDR_WFM2) ? 1 : 0;
     }
     w.state = c->d_state;
     rc = launch_wfm(w, c->stream);
     if (rc) return rc;
     const uint32_t zero = 0u;
-    for (int r = 0; r < c->nrx; ++r) {
-      float2* y1 = c->rx[r].d_y + c->hy;
-      rc = decim_run(c, c->rx[r].wfm_audio, c->rx[r].d_w, (size_t)n1, 1, &y1, &zero, &zero, nullptr, 0,
+    for (int r = 0; r < nrx; ++r) {
+      float2* y1 = snap.rx[r].d_y + c->hy;
+      rc = decim_run(c, c->rx[r].wfm_audio, snap.rx[r].d_w, (size_t)n1, 1, &y1, &zero, &zero, nullptr, 0,
                      c->mmax, &res);
       if (rc) return rc;
     }
@@ -827,7 +871,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
 
   Stage2Args s;
   memset(&s, 0, sizeof(s));
-  s.nrx = c->nrx; s.n_out = n_out; s.ntaps = c->cfg.ntaps_af; s.hy = c->hy;
+  s.nrx = nrx; s.n_out = n_out; s.ntaps = c->cfg.ntaps_af; s.hy = c->hy;
   s.t0 = res.t0; s.up = up; s.down = down; s.chunk_len = (uint32_t)chunk_len; s.nchunks = nchunks;
   s.m0_lo = (uint32_t)(res.m0 & 0xFFFFFFFFull);
   const double fs_out = std::floor(c->cfg.srate * up / down);
@@ -838,8 +882,8 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     s.pll_ki = (float)(wn * wn);
   }
   bool any_pll = false;
-  for (int r = 0; r < c->nrx; ++r) {
-    RxHost& x = c->rx[r];
+  for (int r = 0; r < nrx; ++r) {
+    const RxSnap& x = snap.rx[r];
     s.y[r] = x.d_y + c->hy;
     s.ypll[r] = x.d_ypll ? x.d_ypll + c->hy : nullptr;
     s.aftaps[r] = x.d_aftaps;
@@ -861,22 +905,27 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   rc = launch_demod_fir(s, c->stream); if (rc) return rc;
   rc = launch_agc_scan(s, c->stream); if (rc) return rc;
   // WFM (mono) emits the real part of the complex pipeline
-  for (int r = 0; r < c->nrx; ++r) if (c->rx[r].mode == PYSDR_WFM) s.out_complex[r] = 0;
+  for (int r = 0; r < nrx; ++r) if (snap.rx[r].mode == PYSDR_WFM) s.out_complex[r] = 0;
   rc = launch_apply(s, c->stream); if (rc) return rc;
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[2], c->stream));
 
   EpilogueArgs e;
   memset(&e, 0, sizeof(e));
-  e.nrx = c->nrx; e.n_out = n_out; e.hy = c->hy;
-  for (int r = 0; r < c->nrx; ++r) {
-    e.ybase[r] = c->rx[r].d_y;
-    e.ypllbase[r] = (s.det[r] == kDetPll) ? c->rx[r].d_ypll : nullptr;
+  e.nrx = nrx; e.n_out = n_out; e.hy = c->hy;
+  for (int r = 0; r < nrx; ++r) {
+    e.ybase[r] = snap.rx[r].d_y;
+    e.ypllbase[r] = (s.det[r] == kDetPll) ? snap.rx[r].d_ypll : nullptr;
   }
   rc = launch_epilogue(e, c->stream); if (rc) return rc;
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[3], c->stream));
   c->ncalls++;
 
-  for (int r = 0; r < c->nrx; ++r) c->rx[r].phase += c->rx[r].fword * (uint32_t)n;
+  {
+    // the NCO phase belongs to the process thread; the lock only orders it against pysdr_rx_add
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (int r = 0; r < nrx; ++r) c->rx[r].phase = snap.rx[r].phase + snap.rx[r].fword * (uint32_t)n;
+  }
+  c->last_nrx = nrx;
   c->last_nout = n_out; c->last_nchunks = nchunks;
   c->last_chunk_len = chunk_len; c->last_s0 = s0; c->last_wfm = wfm ? 1 : 0;
   return PYSDR_OK;
@@ -922,7 +971,7 @@ int pysdr_process(pysdr_ctx* c, const float* iq, size_t n, pysdr_out* outs) {
   if (!c || !iq || !outs || n < 1) return PYSDR_ERR_ARG;
   int rc = pysdr_process_batch(c, iq, 1, n, 0);
   if (rc) return rc;
-  for (int r = 0; r < c->nrx; ++r) {
+  for (int r = 0; r < c->last_nrx; ++r) {
     int nout = 0, cx = 0;
     float pk = 0.f;
     rc = pysdr_fetch(c, r, outs[r].am, outs[r].iq, outs[r].cap, &nout, &cx, nullptr, &pk);
@@ -1130,6 +1179,12 @@ int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size
                       reinterpret_cast<float*>(d_out));
 }
 
+int pysdr_spectrum_get_tuning(pysdr_spectrum* sp, int32_t out[4]) {
+  if (!sp || !out) return PYSDR_ERR_ARG;
+  out[0] = sp->group; out[1] = sp->force_rocfft ? 1 : 0; out[2] = 0; out[3] = 0;
+  return PYSDR_OK;
+}
+
 int pysdr_spectrum_sync(pysdr_spectrum* sp) {
   if (!sp) return PYSDR_ERR_ARG;
   int rc = use_device(sp->device);
@@ -1285,7 +1340,7 @@ int pysdr_ingest_submit(pysdr_ingest* g, int slot, size_t n) {
   const int nout = c->last_nout;
   if (nout > g->ocap) { set_last_error("pysdr_ingest_submit: %d outputs > capacity %d", nout, g->ocap); return PYSDR_ERR_STATE; }
   g->n_out[slot] = nout;
-  for (int r = 0; r < c->nrx; ++r) {
+  for (int r = 0; r < c->last_nrx; ++r) {
     const int cx = c->last_complex[r];
     g->cx[(size_t)slot * PYSDR_MAX_RX + r] = cx;
     if (nout > 0) {
@@ -1308,7 +1363,7 @@ int pysdr_ingest_collect(pysdr_ingest* g, int slot, pysdr_out* outs) {
   int rc = use_device(g->c->cfg.device);
   if (rc) return rc;
   PYSDR_HIP_CHECK(hipEventSynchronize(g->ev_done[slot]));
-  for (int r = 0; r < g->c->nrx; ++r) {
+  for (int r = 0; r < g->c->last_nrx; ++r) {
     outs[r].am = g->h_am[(size_t)slot * PYSDR_MAX_RX + r];
     outs[r].iq = g->h_iq[(size_t)slot * PYSDR_MAX_RX + r];
     outs[r].cap = g->ocap;

@@ -32,6 +32,14 @@ namespace pysdr {
 
 namespace {
 
+// Work-skipping ablation switches (DESIGN.md 4.1 store-cost / DMA-only measurements) exist
+// only in a diagnostic build (-DPYSDR_DIAG); the shipped kernel has no such branches.
+#ifdef PYSDR_DIAG
+#define PYSDR_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define PYSDR_DBG(a, bit) 0
+#endif
+
 __device__ __forceinline__ float dpp_quad_xor1(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   uint32_t pk_chunk = 0u;
   int pk_lo = 0;                 // samples [pk_lo, pk_hi] of chunk pk_chunk exist in this call
   int pk_hi = (int)(a.chunk_len < a.n_total ? a.chunk_len : a.n_total) - 1;
-  if (!(a.dbg & 2)) stage_tile(a, cur, buf0, tid, nthr);
+  if (!PYSDR_DBG(a, 2)) stage_tile(a, cur, buf0, tid, nthr);
 
   for (int tb = t_begin; tb < t_end; ++tb) {
     float2* const xs = ((tb - t_begin) & 1) ? buf1 : buf0;
@@ -344,14 +352,14 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
     Tile nxt = cur;
     if (tb + 1 < t_end) {
       nxt = (tb + 2 < a.ntiles) ? tile_advance(a, cur) : tile_geometry(a, tb + 1);
-      if (!(a.dbg & 2)) stage_tile(a, nxt, xn, tid, nthr);
+      if (!PYSDR_DBG(a, 2)) stage_tile(a, nxt, xn, tid, nthr);
     }
 
     // ---- raw-chunk peak |x|^2 over the samples this tile owns (rx.auto_mute input).
     // The running maximum of a chunk stays in a register across tiles; the atomic is only
     // issued when the run moves on to another chunk (and once at the end): same-address
     // atomics are slow, and one per tile would sit in vmcnt and stall the next dma_wait.
-    if (cur.own_hi >= cur.own_lo && !(a.dbg & 4)) {
+    if (cur.own_hi >= cur.own_lo && !PYSDR_DBG(a, 4)) {
       const float4* xv = reinterpret_cast<const float4*>(xs);
       const int e_lo = cur.own_lo & ~1, e_hi = cur.own_hi | 1;
       if (e_lo >= pk_lo && e_hi <= pk_hi) {
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
     // one small scalar division per task, one VALU add per lane.
     const int upc = a.up;
     const int kp = (NJ > 0) ? 16 * NJ : a.kpad;
-    const int ntasks = (cur.tile_n > 0 && !(a.dbg & 1)) ? a.ntasks : 0;
+    const int ntasks = (cur.tile_n > 0 && !PYSDR_DBG(a, 1)) ? a.ntasks : 0;
     const int i_last = cur.i_first + cur.tile_n - 1;
     // generic order: task = (branch, quad) round robin over the waves; hold order: see above
     const int t_lim = hold ? (ntasks > 0 ? a.tpc : 0) : ntasks;
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
       __syncthreads();
       const int n_st = cur.i_first + cur.tile_n - i_base;
       const int cpr = (n_st + 63) >> 6;
-      if (!(a.dbg & 8))
+      if (!PYSDR_DBG(a, 8))
         for (int ch = wave; ch < R * cpr; ch += nwaves) {
           int r = 0, c2 = ch;
           while (c2 >= cpr) { c2 -= cpr; ++r; }
@@ -499,15 +507,23 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
 
 template <int R, int NJ>
 int launch_rj(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mixdec_kernel<R, NJ>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      set_last_error("hipFuncSetAttribute(mixdec<%d,%d>): %s", R, NJ, hipGetErrorString(e));
-      return PYSDR_ERR_HIP;
+  // the attribute is per (function, device): one bit per device, guarded against contexts on
+  // other threads / other devices of the same process (P.GPU_DEVICE, cfg.device)
+  static std::mutex attr_mu;
+  static uint64_t attr_done = 0;
+  {
+    int dev = 0;
+    PYSDR_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(attr_mu);
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mixdec_kernel<R, NJ>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        set_last_error("hipFuncSetAttribute(mixdec<%d,%d>): %s", R, NJ, hipGetErrorString(e));
+        return PYSDR_ERR_HIP;
+      }
+      attr_done |= 1ull << (dev & 63);
     }
-    attr_set = true;
   }
   hipLaunchKernelGGL((mixdec_kernel<R, NJ>), dim3(grid), dim3(threads), lds, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());

@@ -100,14 +100,61 @@ class RcclBroadcaster:
         self._lib.lib().pysdr_comm_destroy(self.ctx.h)
 
 
-def run_sharded(streams, make_rx, chunk_len, nchunks, dist=None, mode="stream"):
+class DeviceRxSplit:
+    """One rank of the split-RX layout on GPUs: the wideband chunk (or batch of chunks) lives in a
+    device buffer, rank ``root`` uploads it, ``ncclBroadcast`` (RCCL over xGMI, on the context's
+    stream) hands it to every other GPU, and this rank's sub-receivers demodulate it where it
+    landed -- the executive's ``que[irx].put(('DAT',nchunks,x))`` to every worker followed by the
+    wait on every ``rx_ready`` (``receiver.py:728-739``, ``am.py:85-114``), with the copy done by
+    the fabric instead of a pickled queue.
+
+    ``ctx`` = the ``_StreamContext`` the rank's ``sig_proc.Receiver`` objects share (a context
+    without receivers still takes part in the broadcast)."""
+
+    def __init__(self, ctx, max_samples, dist=None, root=0):
+        from . import _lib
+        self._lib, self.ctx, self.root = _lib, ctx, root
+        self.rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+        self.device = int(ctx.cfg.device)
+        self.cap = int(max_samples)
+        self.d_buf = C.c_void_p()
+        _lib.check(_lib.lib().pysdr_dev_alloc(self.device, self.cap * 8, C.byref(self.d_buf)), "pysdr_dev_alloc")
+        self.bc = RcclBroadcaster(ctx, dist)
+
+    def step(self, x, nchunks, chunk_len):
+        """``x`` (complex64, only read on the root) -> broadcast -> demodulate this rank's RX."""
+        n = int(nchunks) * int(chunk_len)
+        if n > self.cap:
+            raise ValueError(f"DeviceRxSplit: {n} samples > capacity {self.cap}")
+        L = self._lib.lib()
+        if self.rank == self.root:
+            x = np.ascontiguousarray(x, np.complex64)
+            # a blocking copy: the kernels of the previous step were synchronised by fetch()
+            self._lib.check(L.pysdr_dev_upload(self.device, self.d_buf, C.c_void_p(x.ctypes.data), n * 8),
+                            "pysdr_dev_upload")
+        self.bc.bcast(self.d_buf.value, n * 8, self.root)
+        if self.ctx.receivers:
+            self.ctx.process_batch(self.d_buf.value, nchunks, chunk_len, on_device=True)
+
+    def fetch(self, irx_local, nchunks):
+        return self.ctx.fetch(irx_local, nchunks)
+
+    def close(self):
+        self._lib.check(self._lib.lib().pysdr_sync(self.ctx.h), "pysdr_sync")
+        self.bc.close()
+        self._lib.lib().pysdr_dev_free(self.device, self.d_buf)
+
+
+def run_sharded(streams, make_rx, chunk_len, nchunks, dist=None, mode="stream", nrx=None, device_split=None):
     """Process ``streams`` (list of complex64 arrays, all ranks hold the list; only the owner
     touches its entries) for ``nchunks`` chunks and return {(stream, irx): audio} on rank 0.
 
     ``make_rx(stream_index, rx_indices)`` -> list of receiver objects with ``demod_data``
     (``pysdr_amd.sig_proc.Receiver`` on a GPU box, the oracle in CPU tests).
-    mode "stream": shard by stream.  mode "rx": ONE stream (streams[0]), sub-receivers split
-    across ranks, the chunk broadcast from rank 0 each step."""
+    mode "stream": shard by stream.  mode "rx": ONE stream (streams[0]) of ``nrx`` sub-receivers
+    split across ranks, the chunk broadcast from rank 0 each step: over RCCL into device buffers
+    when ``device_split(rank_rx_objects) -> DeviceRxSplit`` is given (GPU boxes), as a host array
+    over gloo otherwise (CPU tests; the receivers then take host arrays)."""
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     local = {}
@@ -122,25 +169,28 @@ def run_sharded(streams, make_rx, chunk_len, nchunks, dist=None, mode="stream"):
             for i in range(len(rxs)):
                 local[(si, i)] = np.concatenate(acc[i])
     elif mode == "rx":
-        mine = None
+        if nrx is None:
+            raise ValueError("run_sharded(mode='rx') needs nrx, the number of sub-receivers of the stream")
+        idx = partition_rx(int(nrx), world)[rank]
+        rxs = make_rx(0, idx)
+        acc = [[] for _ in idx]
+        split = device_split(rxs) if device_split is not None else None
         for k in range(nchunks):
-            if rank == 0:
-                x = np.ascontiguousarray(streams[0][k * chunk_len:(k + 1) * chunk_len], np.complex64)
-            else:
-                x = np.zeros(chunk_len, np.complex64)
+            x = streams[0][k * chunk_len:(k + 1) * chunk_len] if rank == 0 else None
+            if split is not None:
+                split.step(x, 1, chunk_len)
+                for j in range(len(idx)):
+                    acc[j].append(np.array(split.fetch(j, 1)[0]))
+                continue
+            x = np.ascontiguousarray(x, np.complex64) if rank == 0 else np.zeros(chunk_len, np.complex64)
             if world > 1:
                 x = broadcast_chunk_host(x, dist, src=0)
-            if mine is None:
-                nrx = len(make_rx.rx_modes)
-                idx = partition_rx(nrx, world)[rank]
-                mine = (idx, make_rx(0, idx), [[] for _ in idx])
-            idx, rxs, acc = mine
             for j, rx in enumerate(rxs):
                 acc[j].append(np.array(rx.demod_data(x)))
-        if mine is not None:
-            idx, rxs, acc = mine
-            for j, i in enumerate(idx):
-                local[(0, i)] = np.concatenate(acc[j]) if acc[j] else np.zeros(0, np.float32)
+        if split is not None:
+            split.close()
+        for j, i in enumerate(idx):
+            local[(0, i)] = np.concatenate(acc[j]) if acc[j] else np.zeros(0, np.float32)
     else:
         raise ValueError(mode)
     return gather_audio(local, dist, dst=0)

@@ -132,3 +132,54 @@ def test_setters_from_a_second_thread_while_processing():
         t.join()
     assert not errors
     assert abs(g[2].lo.fo) > 0
+
+
+def test_raw_abi_set_mode_and_set_lo_race_pysdr_process():
+    """pysdr_set_mode (-> AM-Synch, which needs a buffer the context allocates lazily)
+    and pysdr_set_lo called straight through the C ABI from a second thread WHILE pysdr_process
+    runs (ctypes drops the GIL for the call).  One process call must see one consistent set of
+    mode / NCO word / taps / buffers: no device fault, status OK, finite output."""
+    import threading
+    lib, h = _ctx()
+    hdec, af = _taps()
+    irx = C.c_int(-1)
+    for k in range(3):
+        assert lib.pysdr_rx_add(h, 0, -455e3 + 2e3 * k, _lib.as_pd(hdec), _lib.as_pd(af), 0.0,
+                                C.byref(irx)) == 0
+    x = so.synth_iq(so.CONFIGS['C2'], 170666, 1)
+    stop = threading.Event()
+    bad = []
+
+    def setter():
+        modes = (1, 0, 9, 5, 1, 3, 6)          # AM-Synch, AM, NFM, CW, AM-Synch, USB, IQ
+        k = 0
+        fa = C.c_double()
+        while not stop.is_set():
+            r = k % 3
+            if lib.pysdr_set_mode(h, r, modes[k % len(modes)], _lib.as_pd(af), 255, 700.0) != 0:
+                bad.append("set_mode")
+            if lib.pysdr_set_lo(h, (r + 1) % 3, -455e3 - 25.0 * (k % 9), C.byref(fa)) != 0:
+                bad.append("set_lo")
+            k += 1
+
+    t = threading.Thread(target=setter)
+    t.start()
+    try:
+        am = [np.empty(2 * 1100, np.float32) for _ in range(3)]
+        iq = [np.empty(2 * 1100, np.float32) for _ in range(3)]
+        outs = (_lib.Out * 3)()
+        for r in range(3):
+            outs[r].am, outs[r].iq, outs[r].cap = _lib.as_pf(am[r]), _lib.as_pf(iq[r]), 1100
+        for _ in range(150):
+            rc = lib.pysdr_process(h, _lib.as_pf(x.view(np.float32)), len(x), outs)
+            assert rc == 0, lib.pysdr_last_error()
+            for r in range(3):
+                n = outs[r].n_out
+                assert n in (1023, 1024, 1025)
+                k = 2 * n if outs[r].am_is_complex else n
+                assert np.all(np.isfinite(am[r][:k])) and np.all(np.isfinite(iq[r][:2 * n]))
+    finally:
+        stop.set()
+        t.join()
+    assert not bad
+    lib.pysdr_destroy(h)

@@ -30,10 +30,9 @@ streams = [so.synth_iq(cfg, nchunks * L, 200 + s) for s in range(nstreams)]
 def make_rx(si, idx):
     rxs = so.make_receivers(cfg, np.float32)
     return rxs if idx is None else [rxs[i] for i in idx]
-make_rx.rx_modes = [r["mode"] for r in cfg["rx"]]
 
 by_stream = multi.run_sharded(streams, make_rx, L, nchunks, dist, mode="stream")
-by_rx = multi.run_sharded(streams, make_rx, L, nchunks, dist, mode="rx")
+by_rx = multi.run_sharded(streams, make_rx, L, nchunks, dist, mode="rx", nrx=len(cfg["rx"]))
 slow = multi.max_over_ranks(1.0 + rank, dist)
 dist.barrier()
 if rank == 0:
