@@ -352,16 +352,19 @@ def main():
     if args.tile_bytes or args.threads:
         _lib.check(lib.pysdr_set_tile(ctx.h, args.tile_bytes, args.threads or 1024), "set_tile")
 
-    # synthetic stream: 8 unique chunks (seed per rank = its own stream), repeated to fill the batch
-    uniq = 8
+    # synthetic stream: a loop of 8 unique chunks (seed per rank = its own stream) repeated to fill
+    # the batch.  Broadcast FM: the loop is 1.7 M samples = a whole number of cycles of the carrier,
+    # the pilot and both tones, so the repeated stream is seamless -- a pilot that jumps every
+    # 8 chunks would keep the pilot PLL re-acquiring, which no real broadcast does.
     seed = 10 + (0 if split_rx else rank)
     d_x = C.c_void_p()
     _lib.check(lib.pysdr_dev_alloc(device, nsamp * 8, C.byref(d_x)), "alloc x")
     if not split_rx or rank == 0:
-        xu = synth_batch(cfg, uniq * L, seed)
-        for k in range(0, B, uniq):
-            n = min(uniq, B - k) * L
-            _lib.check(lib.pysdr_dev_upload(device, C.c_void_p(d_x.value + k * L * 8),
+        nloop = 1700000 if 'wfm' in cfg else 8 * L
+        xu = synth_batch(cfg, nloop, seed)
+        for off in range(0, nsamp, nloop):
+            n = min(nloop, nsamp - off)
+            _lib.check(lib.pysdr_dev_upload(device, C.c_void_p(d_x.value + off * 8),
                                             C.c_void_p(xu.ctypes.data), n * 8), "upload")
     bc = multi.RcclBroadcaster(ctx, dist) if split_rx else None
 
@@ -445,6 +448,11 @@ def main():
         dist.all_gather(allt, torch.tensor([dt_local / args.steps * 1e3], dtype=torch.float64))
         per_rank_ms = [float(v.item()) for v in allt]
 
+    pll = None
+    if 'wfm' in cfg and rxs:
+        sg, pt = C.c_int(0), C.c_int(0)
+        _lib.check(lib.pysdr_pll_stats(ctx.h, 0, C.byref(sg), C.byref(pt)), "pll_stats")
+        pll = {"segments": sg.value, "patched_serially": pt.value}
     tune = (C.c_int32 * 8)()
     _lib.check(lib.pysdr_get_tuning(ctx.h, tune), "get_tuning")
     sp_tune = (C.c_int32 * 4)()
@@ -519,6 +527,7 @@ def main():
             "algorithmic_bytes_per_sample": bytes_per_sample_job,
             "note": "per GPU: whole-step wall clock against SURVEY 8(d)'s compulsory bytes per input sample"},
         "kernel_ms": {"front": k1_ms if k1 else None, "stage2": k2_ms, "psd_call": psd_ms},
+        "pilot_pll": pll,
         "tuning": {"diag_build": int(tune[0]), "debug_flags": int(tune[1]), "mixdec_wgs_per_cu": int(tune[2]),
                    "mixdec_yflush_cap": int(tune[3]), "tile_bytes": int(tune[4]), "threads": int(tune[5]),
                    "psd_group": int(sp_tune[0]) if sp is not None else None,

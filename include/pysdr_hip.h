@@ -113,6 +113,12 @@ int pysdr_set_wfm_taps(pysdr_ctx* ctx, int irx, const double* video, int nv, con
 /* rx.agc.reset() / rx.demod.am_pll.reset() (receiver.py:648-649): what = 1 AGC, 2 PLL, 3 both */
 int pysdr_reset(pysdr_ctx* ctx, int irx, unsigned what);
 int pysdr_agc_get(pysdr_ctx* ctx, int irx, pysdr_agc_state* st);
+/* The serial PLLs (rx.demod.am_pll, receiver.py:649; the WFM2 pilot PLL) run time-parallel on
+ * long calls: `segments` the last call was cut into, `patched` = segments a serial patch-up pass
+ * had to recompute because the loop had not forgotten its start state (0 for a locked loop). */
+int pysdr_pll_stats(pysdr_ctx* ctx, int irx, int* segments, int* patched);
+/* A/B knob for the above: at most `max_segments` per call (1 = the plain serial walk, 0 = default) */
+int pysdr_set_pll_segments(pysdr_ctx* ctx, int max_segments);
 /* NFM noise squelch (north_star "AGC/squelch"; design notes sigs/squelch.m:92-145): per chunk the
  * mean |2nd difference| of the discriminator output is smoothed (one pole) and the chunk is
  * muted while it exceeds `thresh`; thresh <= 0 disables (default). */

@@ -57,6 +57,8 @@ PROTOTYPES = {
     "pysdr_set_wfm_taps": (_i, [_vp, _i, _pd, _i, _pd, _i]),
     "pysdr_reset": (_i, [_vp, _i, C.c_uint]),
     "pysdr_agc_get": (_i, [_vp, _i, C.POINTER(AgcState)]),
+    "pysdr_pll_stats": (_i, [_vp, _i, _pi, _pi]),
+    "pysdr_set_pll_segments": (_i, [_vp, _i]),
     "pysdr_set_agc": (_i, [_vp, _i, _i, _f]),
     "pysdr_set_squelch": (_i, [_vp, _i, _f]),
     "pysdr_squelch_get": (_i, [_vp, _i, _pf, _pi]),

@@ -32,6 +32,27 @@ namespace {
 constexpr double kTwo32 = 4294967296.0;
 constexpr float kNfmFullScaleDev = 5000.0f;
 constexpr double kPllBwHz = 50.0, kPllZeta = 0.7071;
+constexpr double kPllZetaPlan = 0.7071;
+constexpr double kWfmPllBwHz = 30.0;
+
+constexpr int kPllSegMax = 4096;
+
+// Segmentation of a serial PLL over n samples (PllPlan, common.h).  W = warm-up in samples = `taus`
+// time constants 1/(zeta*wn) of the loop; calls shorter than three warm-ups stay one segment.
+PllPlan plan_pll(int n, double fs, double bw_hz, double taus, int t_min, int k_max, uint32_t* seg) {
+  PllPlan p;
+  const double tau = fs / (kPllZetaPlan * 2.0 * M_PI * bw_hz);
+  p.W = ((int)std::ceil(taus * tau) + 63) & ~63;
+  if (n < 3 * p.W || k_max <= 1) {
+    p.K = 1;
+    p.T = (std::max(n, 64) + 63) & ~63;
+  } else {
+    p.T = std::max(t_min, (((n + k_max - 1) / k_max) + 63) & ~63);
+    p.K = (n + p.T - 1) / p.T;
+  }
+  p.seg = seg;
+  return p;
+}
 
 inline bool mode_has_agc(int m) {
   return m == PYSDR_AM || m == PYSDR_AM_SYNCH || m == PYSDR_SSB || m == PYSDR_USB ||
@@ -110,6 +131,7 @@ struct pysdr_ctx {
   float* d_blknoise = nullptr;   // [MAX_RX][max_chunks]
   unsigned* d_blkcnt = nullptr;  // [MAX_RX][max_chunks]
   RxDevState* d_state = nullptr; // [MAX_RX]
+  uint32_t* d_pllseg = nullptr;  // [MAX_RX][kPllSegMax][4] start/end states of the time-parallel PLLs
   // last call
   int last_nout = 0, last_nchunks = 0, last_nrx = 0;
   size_t last_chunk_len = 0;
@@ -119,6 +141,7 @@ struct pysdr_ctx {
   int tile_bytes = 0, threads = 1024;  // per LDS buffer (two per workgroup); 0 = as large as fits
   int wgs_per_cu = 1, num_cus = 256;
   int dbg_flags = 0, yflush_cap = 0;      // tuning / diagnostic switches, read from the environment once
+  int pll_kmax = 0;                       // pysdr_set_pll_segments: 0 = default, 1 = serial
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
   hipEvent_t ev[kSlots][4] = {};
@@ -198,7 +221,9 @@ void build_taps(const Decim& d, const double* h, int nt, uint32_t fword, float2*
   }
 }
 
-int decim_init(Decim& d, int up, int down, int ntaps, int max_rx) {
+// All initial fills go to the context's own stream: it is a non-blocking stream, i.e. NOT ordered
+// against the null stream a plain hipMemset runs on, and the first tap upload follows on it.
+int decim_init(Decim& d, int up, int down, int ntaps, int max_rx, hipStream_t st) {
   d.up = up; d.down = down; d.ntaps = ntaps; d.max_rx = max_rx;
   d.kdec = (ntaps + up - 1) / up;
   d.kpad = (d.kdec + 15) / 16 * 16;
@@ -206,10 +231,10 @@ int decim_init(Decim& d, int up, int down, int ntaps, int max_rx) {
   d.h_taps.assign((size_t)max_rx * d.per(), make_float2(0.f, 0.f));
   for (int i = 0; i < 2; ++i) {
     PYSDR_HIP_CHECK(hipMalloc(&d.d_hist[i], d.hist_len * sizeof(float2)));
-    PYSDR_HIP_CHECK(hipMemset(d.d_hist[i], 0, d.hist_len * sizeof(float2)));
+    PYSDR_HIP_CHECK(hipMemsetAsync(d.d_hist[i], 0, d.hist_len * sizeof(float2), st));
   }
   PYSDR_HIP_CHECK(hipMalloc(&d.d_taps, (size_t)max_rx * d.per() * sizeof(float2)));
-  PYSDR_HIP_CHECK(hipMemset(d.d_taps, 0, (size_t)max_rx * d.per() * sizeof(float2)));
+  PYSDR_HIP_CHECK(hipMemsetAsync(d.d_taps, 0, (size_t)max_rx * d.per() * sizeof(float2), st));
   return PYSDR_OK;
 }
 
@@ -340,7 +365,7 @@ int wfm_setup(pysdr_ctx* c) {
   c->up2 = (int)(a / g);
   c->down2 = (int)(b / g);
   c->m1max = (int)(c->cap_samples / (size_t)c->d1) + 4;
-  return decim_init(c->wfm_front, 1, c->d1, c->cfg.ntaps_dec, PYSDR_MAX_RX);
+  return decim_init(c->wfm_front, 1, c->d1, c->cfg.ntaps_dec, PYSDR_MAX_RX, c->stream);
 }
 
 // What one pysdr_process_batch call uses of the receivers' host-side state.  Taken under
@@ -391,7 +416,7 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
         PYSDR_HIP_CHECK(hipMalloc(&x.d_y1, ((size_t)c->m1max + 2) * sizeof(float2)));
         PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y1, 0, ((size_t)c->m1max + 2) * sizeof(float2), c->stream));
         PYSDR_HIP_CHECK(hipMalloc(&x.d_w, (size_t)c->m1max * sizeof(float2)));
-        rc = decim_init(x.wfm_audio, c->up2, c->down2, (int)x.wfm_resamp.size(), 1);
+        rc = decim_init(x.wfm_audio, c->up2, c->down2, (int)x.wfm_resamp.size(), 1, c->stream);
         if (rc) return rc;
       }
       rc = decim_upload_taps(c, c->wfm_front, r, x.wfm_video.data(), c->cfg.ntaps_dec, x.fword);
@@ -522,19 +547,20 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   }
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_error("pysdr_create: %s -> %s", #e, hipGetErrorString(_e)); pysdr_destroy(c); return PYSDR_ERR_HIP; } } while (0)
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  rc = decim_init(c->main, cfg->up, cfg->down, cfg->ntaps_dec, PYSDR_MAX_RX);
+  rc = decim_init(c->main, cfg->up, cfg->down, cfg->ntaps_dec, PYSDR_MAX_RX, c->stream);
   if (rc) { pysdr_destroy(c); return rc; }
   CK(hipMalloc(&c->d_peak, (size_t)cfg->max_chunks * sizeof(unsigned)));
   CK(hipMalloc(&c->d_peak_scratch, 64 * sizeof(unsigned)));
   CK(hipMalloc(&c->d_blkpeak, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
-  CK(hipMemset(c->d_blkpeak, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
+  CK(hipMemsetAsync(c->d_blkpeak, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned), c->stream));
   CK(hipMalloc(&c->d_gain, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
   CK(hipMalloc(&c->d_blknoise, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
-  CK(hipMemset(c->d_blknoise, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
+  CK(hipMemsetAsync(c->d_blknoise, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float), c->stream));
   CK(hipMalloc(&c->d_blkcnt, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
-  CK(hipMemset(c->d_blkcnt, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
+  CK(hipMemsetAsync(c->d_blkcnt, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned), c->stream));
   CK(hipMalloc(&c->d_state, PYSDR_MAX_RX * sizeof(RxDevState)));
-  CK(hipMemset(c->d_state, 0, PYSDR_MAX_RX * sizeof(RxDevState)));
+  CK(hipMemsetAsync(c->d_state, 0, PYSDR_MAX_RX * sizeof(RxDevState), c->stream));
+  CK(hipMalloc(&c->d_pllseg, (size_t)PYSDR_MAX_RX * kPllSegMax * 4 * sizeof(uint32_t)));
   for (int k = 0; k < pysdr_ctx::kSlots; ++k)
     for (int i = 0; i < 4; ++i) CK(hipEventCreate(&c->ev[k][i]));
   CK(hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming));
@@ -569,6 +595,7 @@ void pysdr_destroy(pysdr_ctx* c) {
   if (c->d_blknoise) (void)hipFree(c->d_blknoise);
   if (c->d_blkcnt) (void)hipFree(c->d_blkcnt);
   if (c->d_state) (void)hipFree(c->d_state);
+  if (c->d_pllseg) (void)hipFree(c->d_pllseg);
   for (int k = 0; k < pysdr_ctx::kSlots; ++k)
     for (int i = 0; i < 4; ++i) if (c->ev[k][i]) (void)hipEventDestroy(c->ev[k][i]);
   if (c->ev_front) (void)hipEventDestroy(c->ev_front);
@@ -603,7 +630,7 @@ int pysdr_rx_add(pysdr_ctx* c, int mode, double lo_freq, const double* h, const 
   x.reset_pending = 3;
   const size_t ny = (size_t)c->hy + c->mmax;
   PYSDR_HIP_CHECK(hipMalloc(&x.d_y, ny * sizeof(float2)));
-  PYSDR_HIP_CHECK(hipMemset(x.d_y, 0, ny * sizeof(float2)));
+  PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y, 0, ny * sizeof(float2), c->stream));
   PYSDR_HIP_CHECK(hipMalloc(&x.d_a, (size_t)c->mmax * sizeof(float2)));
   PYSDR_HIP_CHECK(hipMalloc(&x.d_am, (size_t)c->mmax * 2 * sizeof(float)));
   PYSDR_HIP_CHECK(hipMalloc(&x.d_aftaps, (size_t)((c->cfg.ntaps_af + 7) & ~7) * sizeof(float2)));
@@ -684,6 +711,24 @@ int pysdr_squelch_get(pysdr_ctx* c, int irx, float* level, int* open) {
   PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (level) *level = d.sq_level;
   if (open) *open = d.sq_open;
+  return PYSDR_OK;
+}
+
+int pysdr_pll_stats(pysdr_ctx* c, int irx, int* segments, int* patched) {
+  if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  RxDevState d;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (segments) *segments = d.pll_segments;
+  if (patched) *patched = d.pll_patched;
+  return PYSDR_OK;
+}
+
+int pysdr_set_pll_segments(pysdr_ctx* c, int max_segments) {
+  if (!c || max_segments < 0) return PYSDR_ERR_ARG;
+  c->pll_kmax = max_segments;
   return PYSDR_OK;
 }
 
@@ -841,7 +886,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     const double fs1 = c->cfg.srate / c->d1;
     w.scale = (float)(fs1 / (2.0 * M_PI * 75e3));
     {
-      const double wn = 2.0 * M_PI * 30.0 / fs1;
+      const double wn = 2.0 * M_PI * kWfmPllBwHz / fs1;
       w.kp = (float)(2.0 * 0.7071 * wn);
       w.ki = (float)(wn * wn);
       w.norm = (float)(2.0 / 0.1);
@@ -855,6 +900,8 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
       w.stereo[r] = (snap.rx[r].mode == PYSDR_WFM2) ? 1 : 0;
     }
     w.state = c->d_state;
+    // measured (scripts/experiments/pll_warmup.py): 99 words of 2^32 left after 32768 samples = 17.5 tau
+    w.pll = plan_pll(n1, fs1, kWfmPllBwHz, 18.0, 2048, c->pll_kmax > 0 ? std::min(c->pll_kmax, 1024) : 1024, c->d_pllseg);
     rc = launch_wfm(w, c->stream);
     if (rc) return rc;
     const uint32_t zero = 0u;
@@ -901,7 +948,12 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   }
   s.blkpeak = c->d_blkpeak; s.gain = c->d_gain; s.state = c->d_state;
   s.blknoise = c->d_blknoise; s.blkcnt = c->d_blkcnt;
-  if (any_pll && n_out > 0) { rc = launch_pll(s, c->stream); if (rc) return rc; }
+  if (any_pll && n_out > 0) {
+    // measured: identical floats after 4096 samples = 19 tau of the 50 Hz loop at 48 kHz
+    s.pll = plan_pll(n_out, fs_out, kPllBwHz, 19.0, 512, c->pll_kmax > 0 ? std::min(c->pll_kmax, kPllSegMax) : kPllSegMax, c->d_pllseg);
+    rc = launch_pll(s, c->stream);
+    if (rc) return rc;
+  }
   rc = launch_demod_fir(s, c->stream); if (rc) return rc;
   rc = launch_agc_scan(s, c->stream); if (rc) return rc;
   // WFM (mono) emits the real part of the complex pipeline

@@ -77,6 +77,22 @@ struct RxDevState {       // one per RX, lives in device memory
   float wfm_w;              //                 loop integrator (rad/sample)
   float sq_level;           // NFM noise squelch: smoothed out-of-band noise
   int sq_open;
+  int pll_segments;         // time-parallel PLL of the last call: segments run ...
+  int pll_patched;          // ... and segments the serial patch-up pass had to redo
+};
+
+// Time-parallel form of the serial PLLs (WFM2 pilot, AM-Synch carrier), DESIGN.md 4.2: the call's
+// samples are cut into K segments of T; segment k > 0 first runs the SAME recursion over the W
+// samples in front of it from a guessed state (a locked loop forgets its initial state: measured
+// 99 words of 2^32 after 32768 pilot samples, bit-identical floats after 4096 carrier samples),
+// then its own T samples with outputs.  seg[r][k] = {start state used, end state reached}; a
+// single-wave patch-up pass walks the chain, and where end(k-1) and start(k) disagree by more than
+// the tolerance it recomputes serially from there until the two trajectories meet again -- so the
+// result is the serial recursion's within the tolerance for ANY input (unlocked loops just run at
+// the serial speed).
+struct PllPlan {
+  int K, T, W;
+  uint32_t* seg;            // [nrx][K][4]: S.phase, S.w, E.phase, E.w (float fields as bits)
 };
 
 struct Stage2Args {
@@ -102,6 +118,7 @@ struct Stage2Args {
   unsigned* blkpeak;                  // [nrx][nchunks] float bits
   float* gain;                        // [nrx][nchunks]
   RxDevState* state;                  // [nrx]
+  PllPlan pll;                        // AM-Synch carrier PLL segmentation of this call
 };
 int launch_pll(const Stage2Args& a, hipStream_t st);
 int launch_demod_fir(const Stage2Args& a, hipStream_t st);
@@ -129,6 +146,7 @@ struct WfmArgs {
   float2* w[PYSDR_MAX_RX];            // out: mpx*(1 + 2j*sin(2*theta)) (WFM: imag 0)
   int stereo[PYSDR_MAX_RX];
   RxDevState* state;
+  PllPlan pll;                        // pilot PLL segmentation of this call
 };
 int launch_wfm(const WfmArgs& a, hipStream_t st);
 

@@ -24,30 +24,26 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// ---- AM-Synch carrier PLL (rx.demod.am_pll, receiver.py:649): inherently serial (theta
-// feeds back through sin/cos and atan2).  One wave per RX, blocks of 64 samples loaded
-// coalesced and broadcast with v_readlane; every lane runs the same recursion, lane j keeps
-// v = y*exp(-j*theta) of sample j for the detector stage, stored coalesced.  Nothing but
-// arithmetic sits on the critical path (sin/cos by v_sin/v_cos on theta/2pi).
-__global__ __launch_bounds__(64) void pll_kernel(const Stage2Args a) {
-  const int r = blockIdx.x;
-  const int lane = threadIdx.x;
-  if (a.det[r] != kDetPll) return;
-  RxDevState* st = a.state + r;
-  float th = st->pll_theta, w = st->pll_w;
+// ---- AM-Synch carrier PLL (rx.demod.am_pll, receiver.py:649): theta feeds back through
+// sin/cos and atan2, so the recursion itself is serial.  One wave walks a range in blocks of 64
+// samples loaded coalesced and broadcast with v_readlane; every lane runs the same recursion,
+// lane j keeps v = y*exp(-j*theta) of sample j for the detector stage, stored coalesced.
+// Nothing but arithmetic sits on the critical path (sin/cos by v_sin/v_cos on theta/2pi).
+// Parallelism comes from time: segments with warm-up + a patch-up pass (PllPlan, common.h).
+template <bool EMIT>
+__device__ __forceinline__ void am_pll_walk(const Stage2Args& a, const float2* __restrict__ y,
+                                            float2* __restrict__ o, int i_begin, int i_end, float& th,
+                                            float& w, int lane) {
   const float kp = a.pll_kp, ki = a.pll_ki;
   const float pi = 3.14159265358979323846f, twopi = 6.28318530717958647692f;
   const float inv2pi = 0.15915494309189533577f;
-  const float2* y = a.y[r];
-  float2* o = a.ypll[r];
-  const int n = a.n_out;
-  float2 y_next = (lane < n) ? y[lane] : make_float2(0.f, 0.f);
-  for (int i0 = 0; i0 < n; i0 += 64) {
+  float2 y_next = (i_begin + lane < i_end) ? y[i_begin + lane] : make_float2(0.f, 0.f);
+  for (int i0 = i_begin; i0 < i_end; i0 += 64) {
     const float2 yv = y_next;
     const int nidx = i0 + 64 + lane;
-    y_next = (nidx < n) ? y[nidx] : make_float2(0.f, 0.f);     // in flight during the steps below
+    y_next = (nidx < i_end) ? y[nidx] : make_float2(0.f, 0.f);     // in flight during the steps below
     float2 mine = make_float2(0.f, 0.f);
-    const int count = (n - i0 < 64) ? n - i0 : 64;
+    const int count = (i_end - i0 < 64) ? i_end - i0 : 64;
 #pragma unroll 4
     for (int j = 0; j < count; ++j) {
       const float yr = lane_bcast(yv.x, j), yi = lane_bcast(yv.y, j);
@@ -62,11 +58,87 @@ __global__ __launch_bounds__(64) void pll_kernel(const Stage2Args a) {
       else if (th < -pi) th += twopi;
       if (lane == j) mine = make_float2(vr, vi);
     }
-    if (lane < count) o[i0 + lane] = mine;
+    if (EMIT && lane < count) o[i0 + lane] = mine;
+  }
+}
+
+// tolerances of the patch-up pass: the carrier loop's trajectories merge to identical floats
+// (scripts/experiments/pll_warmup.py); 2e-6 rad of phase = 2e-6 of the detector output
+__device__ __forceinline__ bool am_state_differs(float th_a, float w_a, float th_b, float w_b) {
+  const float pi = 3.14159265358979323846f, twopi = 6.28318530717958647692f;
+  float d = th_a - th_b;
+  if (d >= pi) d -= twopi;
+  else if (d < -pi) d += twopi;
+  return !(fabsf(d) <= 2.0e-6f && fabsf(w_a - w_b) <= 2.0e-8f);
+}
+
+// grid (K, nrx): segment k of RX r
+__global__ __launch_bounds__(64) void am_pll_seg_kernel(const Stage2Args a) {
+  const int r = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
+  if (a.det[r] != kDetPll) return;
+  const PllPlan& pl = a.pll;
+  const RxDevState* st = a.state + r;
+  const int n = a.n_out;
+  const int s0 = k * pl.T, s1 = (s0 + pl.T < n) ? s0 + pl.T : n;
+  float th = st->pll_theta, w = st->pll_w;
+  int wb = s0 - pl.W;
+  if (k > 0 && wb > 0) {
+    // guessed state W samples ahead of the segment: free-running at the call's initial rate
+    th = 0.f;
+  } else {
+    wb = 0;                                  // the true state of the call: exact, however short
+  }
+  if (wb < s0) am_pll_walk<false>(a, a.y[r], a.ypll[r], wb, s0, th, w, lane);
+  uint32_t* sg = pl.seg + ((size_t)r * pl.K + k) * 4;
+  if (lane == 0) { sg[0] = __float_as_uint(th); sg[1] = __float_as_uint(w); }
+  am_pll_walk<true>(a, a.y[r], a.ypll[r], s0, s1, th, w, lane);
+  if (lane == 0) { sg[2] = __float_as_uint(th); sg[3] = __float_as_uint(w); }
+}
+
+// grid (nrx): walk the chain of segments, redo what does not join up
+__global__ __launch_bounds__(64) void am_pll_patch_kernel(const Stage2Args a) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  if (a.det[r] != kDetPll) return;
+  const PllPlan& pl = a.pll;
+  const int K = pl.K, n = a.n_out;
+  const uint32_t* sg = pl.seg + (size_t)r * K * 4;
+  float th_fin = __uint_as_float(sg[(size_t)(K - 1) * 4 + 2]), w_fin = __uint_as_float(sg[(size_t)(K - 1) * 4 + 3]);
+  int patched = 0;
+  int k = 1;
+  while (k < K) {
+    int bad = K;
+    for (int base = k; base < K && bad == K; base += 64) {
+      const int kk = base + lane;
+      bool mm = false;
+      if (kk < K)
+        mm = am_state_differs(__uint_as_float(sg[(size_t)(kk - 1) * 4 + 2]), __uint_as_float(sg[(size_t)(kk - 1) * 4 + 3]),
+                              __uint_as_float(sg[(size_t)kk * 4 + 0]), __uint_as_float(sg[(size_t)kk * 4 + 1]));
+      const unsigned long long bal = __ballot(mm);
+      if (bal) bad = base + __builtin_ctzll(bal);
+    }
+    if (bad >= K) break;
+    float th = __uint_as_float(sg[(size_t)(bad - 1) * 4 + 2]), w = __uint_as_float(sg[(size_t)(bad - 1) * 4 + 3]);
+    int j = bad;
+    bool joined = false;
+    while (j < K) {
+      const int s0 = j * pl.T, s1 = (s0 + pl.T < n) ? s0 + pl.T : n;
+      am_pll_walk<true>(a, a.y[r], a.ypll[r], s0, s1, th, w, lane);
+      ++patched;
+      ++j;
+      if (j < K && !am_state_differs(th, w, __uint_as_float(sg[(size_t)j * 4 + 0]), __uint_as_float(sg[(size_t)j * 4 + 1]))) {
+        joined = true;                        // segment j was started from (nearly) this state: it stands
+        break;
+      }
+    }
+    if (!joined) { th_fin = th; w_fin = w; break; }
+    k = j + 1;
   }
   if (lane == 0) {
-    st->pll_theta = th;
-    st->pll_w = w;
+    RxDevState* st = a.state + r;
+    st->pll_theta = th_fin;
+    st->pll_w = w_fin;
+    st->pll_segments = K;
+    st->pll_patched = patched;
   }
 }
 
@@ -419,23 +491,16 @@ __device__ __forceinline__ void wfm_pll_step(float mj, uint32_t& ph, float& w, c
   ph = ph + a.fword0 + (uint32_t)corr;
 }
 
-__global__ __launch_bounds__(64) void wfm_pll_kernel(const WfmArgs a) {
-  const int r = blockIdx.x;
-  const int lane = threadIdx.x;
-  // roll the 1-sample IF history for the next call (disc kernel is done: same stream)
-  if (lane == 0 && a.n1 > 0) a.y1base[r][1] = a.y1[r][a.n1 - 1];
-  if (!a.stereo[r]) return;
-  RxDevState* st = a.state + r;
-  uint32_t ph = st->wfm_phase;
-  float w = st->wfm_w;
-  float2* o = a.w[r];
-  float m_next = (lane < a.n1) ? o[lane].x : 0.f;
-  for (int i0 = 0; i0 < a.n1; i0 += 64) {
+template <bool EMIT>
+__device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restrict__ o, int i_begin, int i_end,
+                                             uint32_t& ph, float& w, int lane) {
+  float m_next = (i_begin + lane < i_end) ? o[i_begin + lane].x : 0.f;
+  for (int i0 = i_begin; i0 < i_end; i0 += 64) {
     const float m = m_next;
     const int nidx = i0 + 64 + lane;
-    m_next = (nidx < a.n1) ? o[nidx].x : 0.f;             // in flight during the 64 steps below
+    m_next = (nidx < i_end) ? o[nidx].x : 0.f;             // in flight during the 64 steps below
     uint32_t myph = 0u;
-    const int count = (a.n1 - i0 < 64) ? a.n1 - i0 : 64;
+    const int count = (i_end - i0 < 64) ? i_end - i0 : 64;
     if (count == 64) {
 #pragma unroll
       for (int j = 0; j < 64; ++j) {
@@ -450,22 +515,103 @@ __global__ __launch_bounds__(64) void wfm_pll_kernel(const WfmArgs a) {
         wfm_pll_step(mj, ph, w, a);
       }
     }
-    if (lane < count) {
+    if (EMIT && lane < count) {
       const float rev = (float)(int)myph * (1.0f / 4294967296.0f);
       const float s2 = __builtin_amdgcn_sinf(2.f * rev);
       o[i0 + lane] = make_float2(m, __fmul_rn(m, __fmul_rn(2.f, s2)));
     }
   }
+}
+
+// 512 words of 2^32 = 7.5e-7 rad of pilot phase (1.5e-6 of the 38 kHz carrier); the integrator
+// within 1e-9 rad/sample (x 1/(zeta*wn) = 1900 samples of memory = 2e-6 rad)
+__device__ __forceinline__ bool wfm_state_differs(uint32_t ph_a, float w_a, uint32_t ph_b, float w_b) {
+  const int d = (int)(ph_a - ph_b);
+  return !(d <= 512 && d >= -512 && fabsf(w_a - w_b) <= 1.0e-9f);
+}
+
+// grid (K, nrx): segment k of RX r.  The warm-up re-reads mpx values other segments are
+// rewriting in place as (mpx, carrier): the .x they read is the same bits before and after.
+__global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
+  const int r = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
+  if (!a.stereo[r]) return;
+  const PllPlan& pl = a.pll;
+  const RxDevState* st = a.state + r;
+  const int n = a.n1;
+  const int s0 = k * pl.T, s1 = (s0 + pl.T < n) ? s0 + pl.T : n;
+  uint32_t ph = st->wfm_phase;
+  float w = st->wfm_w;
+  int wb = s0 - pl.W;
+  if (k > 0 && wb > 0) {
+    // guess: the call's initial state free-running at its own rate up to the warm-up start
+    const int corr = __float2int_rn(__fmul_rn(w, a.rad2word));
+    ph = ph + (uint32_t)wb * (a.fword0 + (uint32_t)corr);
+  } else {
+    wb = 0;
+  }
+  if (wb < s0) wfm_pll_walk<false>(a, a.w[r], wb, s0, ph, w, lane);
+  uint32_t* sg = pl.seg + ((size_t)r * pl.K + k) * 4;
+  if (lane == 0) { sg[0] = ph; sg[1] = __float_as_uint(w); }
+  wfm_pll_walk<true>(a, a.w[r], s0, s1, ph, w, lane);
+  if (lane == 0) { sg[2] = ph; sg[3] = __float_as_uint(w); }
+}
+
+__global__ __launch_bounds__(64) void wfm_pll_patch_kernel(const WfmArgs a) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  // roll the 1-sample IF history for the next call (the discriminator kernel is done: same stream)
+  if (lane == 0 && a.n1 > 0) a.y1base[r][1] = a.y1[r][a.n1 - 1];
+  if (!a.stereo[r] || a.n1 <= 0) return;
+  const PllPlan& pl = a.pll;
+  const int K = pl.K, n = a.n1;
+  const uint32_t* sg = pl.seg + (size_t)r * K * 4;
+  uint32_t ph_fin = sg[(size_t)(K - 1) * 4 + 2];
+  float w_fin = __uint_as_float(sg[(size_t)(K - 1) * 4 + 3]);
+  int patched = 0;
+  int k = 1;
+  while (k < K) {
+    int bad = K;
+    for (int base = k; base < K && bad == K; base += 64) {
+      const int kk = base + lane;
+      bool mm = false;
+      if (kk < K)
+        mm = wfm_state_differs(sg[(size_t)(kk - 1) * 4 + 2], __uint_as_float(sg[(size_t)(kk - 1) * 4 + 3]),
+                               sg[(size_t)kk * 4 + 0], __uint_as_float(sg[(size_t)kk * 4 + 1]));
+      const unsigned long long bal = __ballot(mm);
+      if (bal) bad = base + __builtin_ctzll(bal);
+    }
+    if (bad >= K) break;
+    uint32_t ph = sg[(size_t)(bad - 1) * 4 + 2];
+    float w = __uint_as_float(sg[(size_t)(bad - 1) * 4 + 3]);
+    int j = bad;
+    bool joined = false;
+    while (j < K) {
+      const int s0 = j * pl.T, s1 = (s0 + pl.T < n) ? s0 + pl.T : n;
+      wfm_pll_walk<true>(a, a.w[r], s0, s1, ph, w, lane);
+      ++patched;
+      ++j;
+      if (j < K && !wfm_state_differs(ph, w, sg[(size_t)j * 4 + 0], __uint_as_float(sg[(size_t)j * 4 + 1]))) {
+        joined = true;
+        break;
+      }
+    }
+    if (!joined) { ph_fin = ph; w_fin = w; break; }
+    k = j + 1;
+  }
   if (lane == 0) {
-    st->wfm_phase = ph;
-    st->wfm_w = w;
+    RxDevState* st = a.state + r;
+    st->wfm_phase = ph_fin;
+    st->wfm_w = w_fin;
+    st->pll_segments = K;
+    st->pll_patched = patched;
   }
 }
 
 }  // namespace
 
 int launch_pll(const Stage2Args& a, hipStream_t st) {
-  hipLaunchKernelGGL(pll_kernel, dim3(a.nrx), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(am_pll_seg_kernel, dim3(a.pll.K, a.nrx), dim3(64), 0, st, a);
+  PYSDR_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(am_pll_patch_kernel, dim3(a.nrx), dim3(64), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }
@@ -516,7 +662,13 @@ int launch_wfm(const WfmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(wfm_disc_kernel, dim3((a.n1 + 255) / 256, a.nrx), dim3(256), 0, st, a);
     PYSDR_HIP_CHECK(hipGetLastError());
   }
-  hipLaunchKernelGGL(wfm_pll_kernel, dim3(a.nrx), dim3(64), 0, st, a);
+  bool any_stereo = false;
+  for (int r = 0; r < a.nrx; ++r) any_stereo |= (a.stereo[r] != 0);
+  if (any_stereo && a.n1 > 0) {
+    hipLaunchKernelGGL(wfm_pll_seg_kernel, dim3(a.pll.K, a.nrx), dim3(64), 0, st, a);
+    PYSDR_HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(wfm_pll_patch_kernel, dim3(a.nrx), dim3(64), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }

@@ -21,7 +21,9 @@ def run_exec(cfg, nchunks, dsp, seed, modes=True, **kw):
     if modes:
         for i, r in enumerate(cfg['rx']):
             P.rx[i].mode, P.rx[i].af_bw, P.rx[i].bfo = r['mode'], r.get('af_bw'), r.get('bfo', 0.0)
-    ex.Run()
+    P.trace = []          # per chunk: max |x|, max |rx.iq|, max |rx.am| of RX 0 (printed when an assert fails)
+    ex.Run(on_chunk=lambda e: P.trace.append((float(np.abs(e.x).max()), float(np.abs(P.rx[0].iq).max()),
+                                              float(np.abs(P.rx[0].am).max()), bool(P.MUTED[0]), bool(P.AUTO_MUTED))))
     return P, [pl.rb.pull(pl.rb.nsamps) for pl in P.players]
 
 
@@ -31,7 +33,7 @@ def test_am_py_path_c1():
     Pg, ag = run_exec(cfg, 8, None, 31)
     Po, ao = run_exec(cfg, 8, oracle_dsp, 31)
     assert len(ag[0]) == len(ao[0]) and len(ag[0]) in range(8 * 1023, 8 * 1024 + 1)
-    assert np.max(np.abs(ag[0] - ao[0])) <= 1e-5 * np.max(np.abs(ao[0]))
+    assert np.max(np.abs(ag[0] - ao[0])) <= 1e-5 * np.max(np.abs(ao[0])), (Pg.trace, Po.trace)
 
 
 def test_four_rx_loop_with_short_reads_and_stereo_routing():
