@@ -32,3 +32,7 @@ class Receiver:
 
     def auto_mute(self, x):
         return self._rx.auto_mute(x, getattr(self.P, 'MUTE_CHUNKS', 1))
+
+    @property
+    def peak_in(self):
+        return float(self._rx.peak_in)

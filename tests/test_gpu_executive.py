@@ -123,12 +123,12 @@ def test_ingest_ring_pipelined_run_equals_the_synchronous_run():
     cfg = so.CONFIGS['C3']
     nchunks = 6
 
-    def run(pipelined):
+    def run(pipelined, dsp=None):
         P = make_P(cfg, nchunks, audio=2)
         L = P.IN_CHUNK_SIZE
         P.sdr = stream.SynthSDR(cfg, seed=51, nsamp=(nchunks + 1) * L)
         P.ENABLE_AUTO_MUTE = True
-        ex = executive.SDR_EXECUTIVE(P, dsp=None)
+        ex = executive.SDR_EXECUTIVE(P, dsp=dsp)
         for i, r in enumerate(cfg['rx']):
             P.rx[i].mode, P.rx[i].af_bw, P.rx[i].bfo = r['mode'], r.get('af_bw'), r.get('bfo', 0.0)
         seen, peaks = [], []
@@ -148,6 +148,14 @@ def test_ingest_ring_pipelined_run_equals_the_synchronous_run():
     for u, v in zip(aa, ab):
         assert u.shape == v.shape and np.array_equal(u, v)
     assert Pb.sdr.ncall > nchunks
+    # ... and the pipelined run against the ORACLE's loop directly (not only against the other GPU
+    # path): same chunks, same routing, same auto-mute input
+    Po, ao, so_, po = run(False, dsp=oracle_dsp)
+    assert all(np.array_equal(u, v) for u, v in zip(so_, sb))
+    assert np.allclose(po, pb, rtol=1e-6, atol=0)
+    for u, v in zip(ao, ab):
+        assert u.shape == v.shape
+        assert np.max(np.abs(u[300:] - v[300:])) <= 1e-5 * np.max(np.abs(u))     # NFM start-up skipped, see test_gpu_parity
 
 
 _RCCL_CHILD = r"""
