@@ -83,7 +83,10 @@ __global__ __launch_bounds__(256) void psd_post_kernel(const float2* __restrict_
   const float2* w = work + (size_t)f * nfft;
   float* o = out + (size_t)f * nout;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += gridDim.x * blockDim.x) {
-    const int k = half ? j : ((j + nfft / 2) & (nfft - 1));
+    // np.fft.fftshift = roll by nfft/2: out[j] = X[(j + ceil(nfft/2)) mod nfft]; nfft need not be a
+    // power of two (the GUI's clamp passes 65636, Plotting.py:374-375)
+    int k = j;
+    if (!half) { k = j + (nfft + 1) / 2; if (k >= nfft) k -= nfft; }
     const float2 v = w[k];
     float p = v.x * v.x + v.y * v.y;
     if (db) p = 10.f * log10f(p + 1.0e-30f);
