@@ -939,6 +939,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     s.am[r] = x.d_am;
     s.det[r] = mode_detector(x.mode);
     s.out_complex[r] = (x.mode == PYSDR_IQ || wfm) ? 1 : 0;
+    s.fir_complex[r] = s.out_complex[r];
     s.single_block[r] = wfm ? 1 : 0;
     s.matrix[r] = (x.mode == PYSDR_WFM2) ? 1 : 0;
     s.bfo_fword[r] = x.bfo_fword;

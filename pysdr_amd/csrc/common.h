@@ -109,6 +109,7 @@ struct Stage2Args {
   float* am[PYSDR_MAX_RX];            // final audio (float, or float2 when IQ)
   int det[PYSDR_MAX_RX];
   int out_complex[PYSDR_MAX_RX];
+  int fir_complex[PYSDR_MAX_RX];      // what out_complex was when the FIR kernel stored `a` (layout of a)
   uint32_t bfo_fword[PYSDR_MAX_RX];
   int single_block[PYSDR_MAX_RX];     // WFM: no AGC blocks, the whole call is block 0
   int matrix[PYSDR_MAX_RX];           // WFM2: (S, D) -> (S+D) + j(S-D) = L + jR

@@ -143,19 +143,25 @@ __global__ __launch_bounds__(64) void am_pll_patch_kernel(const Stage2Args a) {
 }
 
 // ---- detector + AF FIR + block peak.  grid = (tiles, nrx), 2048 outputs per workgroup,
-// EIGHT consecutive outputs per thread.  The detector output d is staged in LDS as eight
-// de-interleaved sub-arrays D_m[q] = d[8q+m]: thread t owns outputs 8t..8t+7, and at tap k
-// needs d[8t+j-k] -- a window that slides by ONE element per tap, so each tap costs one
-// conflict-free LDS read (lanes read consecutive q of one sub-array) for eight outputs.
-// The (<= 256) taps live in VGPRs, one per lane, and are broadcast with v_readlane.
-// Arithmetic is specialised by what the mode needs (kFir* below): AM/NFM/AM-Synch have a
-// real detector and real taps (1 FMA per tap), the SSB family needs only Re(c*d) (2 FMA).
-constexpr int kW = 8;                  // outputs per thread = window length
+// EIGHT consecutive outputs per thread.  The detector output d is staged in LDS as two float
+// arrays (re, im) with S[e + 3] = d[e]: a thread's outputs 8t .. 8t+7 need, for the four taps
+// 4m .. 4m+3, the eleven values S[8t - 4m .. 8t - 4m + 10] -- three 16-byte chunks, of which only
+// ONE is new per block of four taps.  So four taps cost one ds_read_b128 per array for the data,
+// one broadcast ds_read_b128 per array for the taps (all lanes the same address) and 32 / 64 / 128
+// plain FMAs (real x real, Re(c*d), complex): 94 % of the issue slots are arithmetic.  (The first
+// version read one dword per tap and broadcast the taps with v_readlane: the SGPR hand-off and
+// the v_pk_fma pairs hipcc built from it -- half rate, fed by v_mov shuffles -- left it at 18 %
+// of the FMA peak; this file is compiled with -fno-slp-vectorize.)
+// A chunk read has lanes 32 bytes apart; 4 floats of padding after every 128 keep the sixteen
+// lanes the LDS serves per cycle on sixteen different bank quads.
+constexpr int kW = 8;                  // outputs per thread
 constexpr int kFirThreads = 256;
 constexpr int kFirOut = kW * kFirThreads;   // outputs per workgroup
 constexpr int kFirRealReal = 0;        // d real, c real    -> real
 constexpr int kFirRePart = 1;          // d cplx, c cplx    -> Re(c*d)
 constexpr int kFirCplx = 2;            // d cplx, c cplx    -> cplx (IQ)
+__host__ __device__ __forceinline__ constexpr int fir_pad(int e) { return e + 4 * (e >> 7); }
+__host__ __device__ __forceinline__ constexpr int fir_taps_padded(int ntaps) { return (ntaps + 11) / 12 * 12; }
 
 __device__ __forceinline__ float2 detect(const Stage2Args& a, int r, int det, const float2* y, int i) {
   float2 d = make_float2(0.f, 0.f);
@@ -182,75 +188,68 @@ __device__ __forceinline__ float2 detect(const Stage2Args& a, int r, int det, co
   return d;
 }
 
-// One tap for the kW outputs of a lane (window slots rotate instead of moving registers).
-template <int KIND>
-__device__ __forceinline__ void fir_tap(float2 c, int u, const float (&wr)[kW], const float (&wi)[kW],
-                                        float2 (&acc)[kW]) {
+// Four taps (one block) for the 8 outputs of a lane.  w*[12] = three chunks; ROT = block index
+// mod 3 says which physical chunk is logical chunk 0 (the lowest addresses).
+template <int KIND, int ROT>
+__device__ __forceinline__ void fir_block(const float4 cr4, const float4 ci4, const float (&wr)[12],
+                                          const float (&wi)[12], float2 (&acc)[kW]) {
+  const float cr[4] = {cr4.x, cr4.y, cr4.z, cr4.w};
+  const float ci[4] = {ci4.x, ci4.y, ci4.z, ci4.w};
 #pragma unroll
-  for (int j = 0; j < kW; ++j) {
-    const int sl = (j - u) & (kW - 1);
-    acc[j].x = fmaf(c.x, wr[sl], acc[j].x);
-    if (KIND != kFirRealReal) {
-      acc[j].x = fmaf(-c.y, wi[sl], acc[j].x);
-      if (KIND == kFirCplx) {
-        acc[j].y = fmaf(c.x, wi[sl], acc[j].y);
-        acc[j].y = fmaf(c.y, wr[sl], acc[j].y);
-      }
-    }
-  }
-}
-
-// TAPS_IN_LANES: the (<= 256) taps sit in four VGPR pairs, lane l holding taps l, 64+l, ...;
-// each tap is broadcast with v_readlane -- no scalar-cache load (an s_load in flight forces
-// every LDS wait to drain lgkmcnt completely) and no extra LDS read.
-template <int KIND, bool TAPS_IN_LANES>
-__device__ __forceinline__ void fir_window(int hq, const float2* __restrict__ taps, int ngroups,
-                                           const float* dre, const float* dim, int sub, int tid,
-                                           float2 (&acc)[kW]) {
-  // window w[j] = d[e0 + j - k], e0 = kW*(hq + tid); element e lives at D[e % kW][e / kW]
-  float wr[kW], wi[kW];
+  for (int q = 0; q < 4; ++q)
 #pragma unroll
-  for (int j = 0; j < kW; ++j) {
-    wr[j] = dre[j * sub + hq + tid];
-    wi[j] = (KIND == kFirRealReal) ? 0.f : dim[j * sub + hq + tid];
-    acc[j] = make_float2(0.f, 0.f);
-  }
-  // after tap k = kW*g+u the window moves down one element: the slot that held d[e0+kW-1-k]
-  // is refilled with d[e0-k-1] = D[kW-1-u][hq + tid - g - 1]
-  if (TAPS_IN_LANES) {
-    const int lane = tid & 63;
-    constexpr int kGroupsPerReg = 64 / kW;
-    float2 tc[4];
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
-      tc[jb] = (64 * jb + lane < kW * ngroups) ? taps[64 * jb + lane] : make_float2(0.f, 0.f);
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-      const int left = ngroups - kGroupsPerReg * jb;
-      const int g_end = left < kGroupsPerReg ? left : kGroupsPerReg;
-      for (int gg = 0; gg < g_end; ++gg) {
-        const int q = hq + tid - (kGroupsPerReg * jb + gg) - 1;
-#pragma unroll
-        for (int u = 0; u < kW; ++u) {
-          const float2 c = make_float2(lane_bcast(tc[jb].x, kW * gg + u),
-                                       KIND == kFirRealReal ? 0.f : lane_bcast(tc[jb].y, kW * gg + u));
-          fir_tap<KIND>(c, u, wr, wi, acc);
-          const int m = (kW - 1 - u) & (kW - 1);
-          wr[m] = dre[m * sub + q];
-          if (KIND != kFirRealReal) wi[m] = dim[m * sub + q];
+    for (int j = 0; j < kW; ++j) {
+      const int pos = 3 + j - q;                               // logical window position 0 .. 10
+      const int ph = ((pos >> 2) + 3 - ROT) % 3 * 4 + (pos & 3);   // physical register
+      acc[j].x = fmaf(cr[q], wr[ph], acc[j].x);
+      if (KIND != kFirRealReal) {
+        acc[j].x = fmaf(-ci[q], wi[ph], acc[j].x);
+        if (KIND == kFirCplx) {
+          acc[j].y = fmaf(cr[q], wi[ph], acc[j].y);
+          acc[j].y = fmaf(ci[q], wr[ph], acc[j].y);
         }
       }
     }
-  } else {
-    for (int g = 0; g < ngroups; ++g) {
-      const int q = hq + tid - g - 1;
+}
+
+template <int KIND>
+__device__ __forceinline__ void fir_run(const float* sre, const float* sim, const float* tre, const float* tim,
+                                        int nblk, int H, int tid, float2 (&acc)[kW]) {
+  float wr[12], wi[12];
 #pragma unroll
-      for (int u = 0; u < kW; ++u) {
-        fir_tap<KIND>(taps[kW * g + u], u, wr, wi, acc);      // wave-uniform: scalar load
-        const int m = (kW - 1 - u) & (kW - 1);
-        wr[m] = dre[m * sub + q];
-        if (KIND != kFirRealReal) wi[m] = dim[m * sub + q];
-      }
+  for (int j = 0; j < kW; ++j) acc[j] = make_float2(0.f, 0.f);
+  int e0 = kW * tid + H;                                       // logical chunk 0 of block 0
+  auto chunk = [&](const float* s, int e) { return *reinterpret_cast<const float4*>(s + fir_pad(e)); };
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float4 v = chunk(sre, e0 + 4 * c);
+    wr[4 * c] = v.x; wr[4 * c + 1] = v.y; wr[4 * c + 2] = v.z; wr[4 * c + 3] = v.w;
+    if (KIND != kFirRealReal) {
+      const float4 u = chunk(sim, e0 + 4 * c);
+      wi[4 * c] = u.x; wi[4 * c + 1] = u.y; wi[4 * c + 2] = u.z; wi[4 * c + 3] = u.w;
+    } else {
+      wi[4 * c] = wi[4 * c + 1] = wi[4 * c + 2] = wi[4 * c + 3] = 0.f;
+    }
+  }
+  // nblk is a multiple of 3: the register roles repeat every three blocks
+  for (int m = 0; m < nblk; m += 3) {
+#pragma unroll
+    for (int rot = 0; rot < 3; ++rot) {
+      const float4 cr4 = *reinterpret_cast<const float4*>(tre + 4 * (m + rot));
+      const float4 ci4 = (KIND == kFirRealReal) ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                                : *reinterpret_cast<const float4*>(tim + 4 * (m + rot));
+      // the chunk the NEXT block adds below the window (never read past the staged history:
+      // the last block's successor is e0 - 4 >= 0 and simply goes unused)
+      const float4 nr = chunk(sre, e0 - 4);
+      const float4 ni = (KIND == kFirRealReal) ? make_float4(0.f, 0.f, 0.f, 0.f) : chunk(sim, e0 - 4);
+      if (rot == 0) fir_block<KIND, 0>(cr4, ci4, wr, wi, acc);
+      else if (rot == 1) fir_block<KIND, 1>(cr4, ci4, wr, wi, acc);
+      else fir_block<KIND, 2>(cr4, ci4, wr, wi, acc);
+      // it replaces this block's logical chunk 2 = physical chunk (2 - rot) mod 3
+      const int pc = (5 - rot) % 3 * 4;
+      wr[pc] = nr.x; wr[pc + 1] = nr.y; wr[pc + 2] = nr.z; wr[pc + 3] = nr.w;
+      if (KIND != kFirRealReal) { wi[pc] = ni.x; wi[pc + 1] = ni.y; wi[pc + 2] = ni.z; wi[pc + 3] = ni.w; }
+      e0 -= 4;
     }
   }
 }
@@ -262,33 +261,35 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   const int i0 = blockIdx.x * kFirOut;
   const int det = a.det[r];
   const float2* y = (det == kDetPll) ? a.ypll[r] : a.y[r];
-  const int ngroups = (a.ntaps + kW - 1) / kW;           // taps are zero padded to kW*ngroups
-  const int hq = ngroups;                                // history groups in front of the tile
-  const int sub = kFirOut / kW + hq;                     // length of one sub-array
-  float* dre = lds_f;                                    // [kW][sub]
-  float* dim = lds_f + kW * sub;                         // [kW][sub]
+  const int H = fir_taps_padded(a.ntaps);                // taps, zero padded to whole groups of 12
+  const int nblk = H / 4;
+  const int E = kFirOut + H + 12;                        // staged elements: S[e] = d[i0 - H + e - 3]
+  const int EP = (fir_pad(E) + 3) & ~3;
+  float* sre = lds_f;                                    // [EP]
+  float* sim = lds_f + EP;                               // [EP]
+  float* tre = lds_f + 2 * EP;                           // [H]
+  float* tim = tre + H;                                  // [H]
   const bool real_det = (det == kDetAbs || det == kDetFm || det == kDetPll);
-
   const float2* taps = a.aftaps[r];
   const int kind = a.out_complex[r] ? kFirCplx : (real_det && a.taps_real[r] ? kFirRealReal : kFirRePart);
-  // stage d[i0 - kW hq + e], e = 0 .. kW*sub-1
-  for (int e = tid; e < kW * sub; e += kFirThreads) {
-    const float2 d = detect(a, r, det, y, i0 - kW * hq + e);
-    dre[(e & (kW - 1)) * sub + (e / kW)] = d.x;
-    if (kind != kFirRealReal) dim[(e & (kW - 1)) * sub + (e / kW)] = d.y;
+  for (int e = tid; e < E; e += kFirThreads) {
+    const int i = i0 - H + e - 3;
+    // (indices in front of the kept history only ever meet zero-padded taps)
+    const float2 d = (i >= -a.hy + 2) ? detect(a, r, det, y, i) : make_float2(0.f, 0.f);
+    sre[fir_pad(e)] = d.x;
+    sim[fir_pad(e)] = d.y;
+  }
+  for (int k = tid; k < H; k += kFirThreads) {
+    const float2 c = (k < a.ntaps) ? taps[k] : make_float2(0.f, 0.f);
+    tre[k] = c.x;
+    tim[k] = c.y;
   }
   __syncthreads();
 
   float2 acc[kW];
-  if (ngroups * kW <= 256) {
-    if (kind == kFirRealReal) fir_window<kFirRealReal, true>(hq, taps, ngroups, dre, dim, sub, tid, acc);
-    else if (kind == kFirRePart) fir_window<kFirRePart, true>(hq, taps, ngroups, dre, dim, sub, tid, acc);
-    else fir_window<kFirCplx, true>(hq, taps, ngroups, dre, dim, sub, tid, acc);
-  } else {
-    if (kind == kFirRealReal) fir_window<kFirRealReal, false>(hq, taps, ngroups, dre, dim, sub, tid, acc);
-    else if (kind == kFirRePart) fir_window<kFirRePart, false>(hq, taps, ngroups, dre, dim, sub, tid, acc);
-    else fir_window<kFirCplx, false>(hq, taps, ngroups, dre, dim, sub, tid, acc);
-  }
+  if (kind == kFirRealReal) fir_run<kFirRealReal>(sre, sim, tre, tim, nblk, H, tid, acc);
+  else if (kind == kFirRePart) fir_run<kFirRePart>(sre, sim, tre, tim, nblk, H, tid, acc);
+  else fir_run<kFirCplx>(sre, sim, tre, tim, nblk, H, tid, acc);
 
   const int ib = i0 + kW * tid;
   float mag = 0.f;
@@ -300,7 +301,8 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
 #pragma unroll
     for (int j = 0; j < kW; ++j)
       if (ib + j < a.n_out) {
-        a.a[r][ib + j] = acc[j];
+        if (a.out_complex[r]) a.a[r][ib + j] = acc[j];
+        else reinterpret_cast<float*>(a.a[r])[ib + j] = acc[j].x;     // real outputs: 4 bytes each
         const float m = a.out_complex[r] ? sqrtf(acc[j].x * acc[j].x + acc[j].y * acc[j].y) : fabsf(acc[j].x);
         if (blk_lo == blk_hi) mag = fmaxf(mag, m);
         else atomicMax(a.blkpeak + (size_t)r * a.nchunks + block_of(a, r, ib + j), __float_as_uint(m));
@@ -315,10 +317,10 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
 #pragma unroll
     for (int j = 0; j < kW; ++j)
       if (ib + j < a.n_out) {
-        const int e = kW * (hq + tid) + j;                // element of output ib+j
-        const float d0 = dre[(e & (kW - 1)) * sub + (e / kW)];
-        const float d1 = dre[((e - 1) & (kW - 1)) * sub + ((e - 1) / kW)];
-        const float d2 = dre[((e - 2) & (kW - 1)) * sub + ((e - 2) / kW)];
+        const int e = kW * tid + H + 3 + j;               // S element of output ib+j
+        const float d0 = sre[fir_pad(e)];
+        const float d1 = sre[fir_pad(e - 1)];
+        const float d2 = sre[fir_pad(e - 2)];
         const float hp = fabsf(d0 - 2.f * d1 + d2);
         if (blk_lo == blk_hi) { nz += hp; cnt += 1u; }
         else {
@@ -427,6 +429,11 @@ __global__ __launch_bounds__(256) void apply_kernel(const Stage2Args a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_out) return;
   const float g = a.gain[(size_t)r * a.nchunks + block_of(a, r, i)];
+  if (!a.out_complex[r] && !a.matrix[r]) {
+    // real outputs were stored densely by the FIR kernel; WFM mono takes the real part of a complex one
+    a.am[r][i] = (a.fir_complex[r] ? a.a[r][i].x : reinterpret_cast<const float*>(a.a[r])[i]) * g;
+    return;
+  }
   const float2 v = a.a[r][i];
   if (a.matrix[r]) {
     reinterpret_cast<float2*>(a.am[r])[i] = make_float2((v.x + v.y) * g, (v.x - v.y) * g);
@@ -618,8 +625,9 @@ int launch_pll(const Stage2Args& a, hipStream_t st) {
 
 int launch_demod_fir(const Stage2Args& a, hipStream_t st) {
   if (a.n_out <= 0) return PYSDR_OK;
-  const int ngroups = (a.ntaps + kW - 1) / kW;
-  const size_t lds = (size_t)2 * kW * (kFirOut / kW + ngroups) * sizeof(float);
+  const int H = fir_taps_padded(a.ntaps);
+  const int EP = (fir_pad(kFirOut + H + 12) + 3) & ~3;
+  const size_t lds = (size_t)(2 * EP + 2 * H) * sizeof(float);
   dim3 grid((a.n_out + kFirOut - 1) / kFirOut, a.nrx);
   hipLaunchKernelGGL(demod_fir_kernel, grid, dim3(kFirThreads), lds, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());

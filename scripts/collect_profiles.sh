@@ -1,13 +1,32 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun):  bash scripts/collect_profiles.sh gpurun_out/r1
-# Collects what profiles/ is built from: the default bench line, rocprofv3 kernel stats of the
-# same command, and the HBM-traffic PMC counters in their own passes (never with a trace).
+# Run ON THE GPU BOX (via gpurun):  bash scripts/collect_profiles.sh gpurun_out/prof_r2 [quick]
+# Collects what profiles/ is built from, for every BASELINE configuration that fits one GPU:
+#   <cfg>/bench.json                 the plain bench line (events only, no profiler attached)
+#   <cfg>/kt/...kernel_stats.csv     rocprofv3 --kernel-trace --stats of the same command
+#   c3/pmc_fetch, c3/pmc_write, c2/... HBM-traffic PMC counters in their OWN passes (never with a trace)
 set -u
 OUT=${1:-gpurun_out/prof}
+QUICK=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$OUT" && mkdir -p "$OUT"
-python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --no-cpu-baseline > "$OUT/bench_kt.json" 2> "$OUT/kt.err"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
-tail -c 400 "$OUT/bench_default.json"
+run_cfg() {  # name, pmc(0/1), bench args...
+  local name=$1 pmc=$2; shift 2
+  mkdir -p "$OUT/$name"
+  python3 bench.py "$@" > "$OUT/$name/bench.json" 2> "$OUT/$name/bench.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name/kt" -- python3 bench.py "$@" --no-cpu-baseline > "$OUT/$name/bench_kt.json" 2> "$OUT/$name/kt.err"
+  if [ "$pmc" = 1 ]; then
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$name/pmc_fetch" -- python3 bench.py "$@" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/$name/pmc_fetch.json" 2> "$OUT/$name/pmc_fetch.err"
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$name/pmc_write" -- python3 bench.py "$@" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/$name/pmc_write.json" 2> "$OUT/$name/pmc_write.err"
+  fi
+  # keep only the small summaries (the per-dispatch traces are tens of MB)
+  find "$OUT/$name" -name "*kernel_trace.csv" -delete
+  echo "$name: $(tail -c 300 "$OUT/$name/bench.json" | head -c 120)"
+}
+run_cfg c3 1
+[ -n "$QUICK" ] && exit 0
+run_cfg c3_nopsd 0 --no-psd --no-cpu-baseline
+run_cfg c2 1 --workload c2
+run_cfg c1 0 --workload c1
+run_cfg c4 0 --workload c4
+run_cfg c4mono 0 --workload c4mono --no-cpu-baseline
+run_cfg rx6 0 --nrx 6 --no-psd --no-cpu-baseline

@@ -1,50 +1,76 @@
 """Condense a gpurun_out/<dir> profile collection (scripts/collect_profiles.sh) into the small
-files committed under profiles/: per-kernel rocprofv3 stats, per-kernel HBM traffic from the
-FETCH_SIZE / WRITE_SIZE PMC passes (gfx950 correction: FETCH_SIZE counts 128-B requests as
-64 B, so read bytes = 2 x FETCH_SIZE; both counters are in KiB -- MI355X_MICROARCH.md, HBM),
-and the bench JSON lines."""
+files committed under profiles/:  <tag>_<cfg>_kernel_stats.csv (rocprofv3 per-kernel stats),
+<tag>_<cfg>_bench.json (the un-profiled bench line), <tag>_pmc_traffic.json (per-kernel HBM
+traffic of C3 from the FETCH_SIZE / WRITE_SIZE passes; gfx950 correction: FETCH_SIZE counts
+128-B requests as 64 B, so read bytes = 2 x FETCH_SIZE; both counters are in KiB --
+MI355X_MICROARCH.md, HBM) stamped with the git head and the sha256 of the kernel sources, so
+that bench.py can tell whether the numbers still describe the code it runs.
+
+    python scripts/summarize_profiles.py gpurun_out/prof_r2 profiles r02"""
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
+import re
+import subprocess
 import sys
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs(dst, exist_ok=True)
 
-ks = glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv"))
-if ks:
-    open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w").write(open(ks[0]).read())
+
+def sha(name):
+    return hashlib.sha256(open(os.path.join(ROOT, "pysdr_amd", "csrc", name), "rb").read()).hexdigest()[:16]
 
 
-def pmc(name):
+def pmc(cfg, name):
     out = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(src, name, "*", "*counter_collection.csv")):
+    for f in glob.glob(os.path.join(src, cfg, name, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             out[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
     return out
 
 
-fetch, write = pmc("pmc_fetch"), pmc("pmc_write")
-kernels = sorted({k for k, _ in fetch} | {k for k, _ in write})
-rows = []
-for k in kernels:
-    if "pysdr" not in k:
+try:
+    head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "pysdr_amd/csrc"], text=True).strip())
+except Exception:
+    head, dirty = "unknown", False
+
+for cfg in sorted(os.listdir(src)):
+    d = os.path.join(src, cfg)
+    if not os.path.isdir(d):
         continue
-    f = fetch.get((k, "FETCH_SIZE"), [])
-    w = write.get((k, "WRITE_SIZE"), [])
-    fm = sum(f) / len(f) if f else 0.0
-    wm = sum(w) / len(w) if w else 0.0
-    import re
-    m = re.search(r"(\w+_kernel)", k)
-    rows.append(dict(kernel=m.group(1) if m else k, launches_sampled=len(f),
-                     FETCH_SIZE_KiB=fm, WRITE_SIZE_KiB=wm,
-                     read_bytes=2 * fm * 1024, write_bytes=wm * 1024,
-                     hbm_bytes_per_launch=2 * fm * 1024 + wm * 1024))
-json.dump(rows, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-for name in ("bench_default.json", "bench_kt.json"):
-    p = os.path.join(src, name)
-    if os.path.exists(p) and os.path.getsize(p):
-        open(os.path.join(dst, f"{tag}_{name}"), "w").write(open(p).read())
-print(json.dumps(rows, indent=1))
+    ks = glob.glob(os.path.join(d, "kt", "*", "*kernel_stats.csv"))
+    if ks:
+        open(os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"), "w").write(open(ks[0]).read())
+    for name in ("bench.json", "bench_kt.json"):
+        p = os.path.join(d, name)
+        if os.path.exists(p) and os.path.getsize(p):
+            open(os.path.join(dst, f"{tag}_{cfg}_{name}"), "w").write(open(p).read())
+    fetch, write = pmc(cfg, "pmc_fetch"), pmc(cfg, "pmc_write")
+    kernels = sorted({k for k, _ in fetch} | {k for k, _ in write})
+    rows = []
+    for k in kernels:
+        if "pysdr" not in k:
+            continue
+        f = fetch.get((k, "FETCH_SIZE"), [])
+        w = write.get((k, "WRITE_SIZE"), [])
+        fm = sum(f) / len(f) if f else 0.0
+        wm = sum(w) / len(w) if w else 0.0
+        m = re.search(r"(\w+_kernel)", k)
+        rows.append(dict(kernel=m.group(1) if m else k, launches_sampled=len(f),
+                         FETCH_SIZE_KiB=fm, WRITE_SIZE_KiB=wm,
+                         read_bytes=2 * fm * 1024, write_bytes=wm * 1024,
+                         hbm_bytes_per_launch=2 * fm * 1024 + wm * 1024))
+    if rows:
+        doc = dict(config=cfg, git_head=head + ("+dirty" if dirty else ""),
+                   source_sha256={s: sha(s) for s in ("mixdec.hip", "psdfft.hip", "stage2.hip", "api.hip")},
+                   note="per launch: 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate rocprofv3 --pmc passes of bench.py",
+                   kernels=rows)
+        name = f"{tag}_pmc_traffic.json" if cfg == "c3" else f"{tag}_{cfg}_pmc_traffic.json"
+        json.dump(doc, open(os.path.join(dst, name), "w"), indent=1)
+        print(cfg, json.dumps([(r["kernel"], round(r["hbm_bytes_per_launch"] / 1e6, 1)) for r in rows]))
