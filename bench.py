@@ -65,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--tile-bytes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive ingest-ring figure")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks timed on the CPU oracle (0 = about 10 s worth)")
     return ap.parse_args(argv)
 
@@ -263,6 +264,36 @@ def cpu_baseline_per_rx(args, cfg, nchunks, with_psd, seed):
                 sample=f"{nchunks} chunks x {L} samples, one process per sub-receiver"
                        f"{' + one for the 64k PSD' if with_psd else ''}, slowest {dt:.1f} s "
                        f"({', '.join('%.1f' % t for t in times)}), {wall:.1f} s wall incl. start-up")
+
+
+def host_fed_rate(ctx, cfg, L, cps, nslots_run=24):
+    from pysdr_amd.ingest import IngestRing
+    x = synth_batch(cfg, 8 * L, 10)
+    ring = IngestRing(ctx, 3, cps)
+    slot, pending = 0, None
+
+    def one(slot):
+        buf = ring.buffer(slot)
+        for k in range(cps):
+            buf[k * L:(k + 1) * L] = x[(k % 8) * L:(k % 8 + 1) * L]
+        ring.submit(slot, cps * L)
+
+    for w in range(3):
+        one(w)
+        ring.collect(w)
+    t0 = time.perf_counter()
+    for j in range(nslots_run):
+        one(slot)
+        if pending is not None:
+            ring.collect(pending)
+        pending, slot = slot, (slot + 1) % 3
+    ring.collect(pending)
+    dt = (time.perf_counter() - t0) / (nslots_run * cps)
+    ring.close()
+    return {"ms_per_chunk": dt * 1e3, "value": L / dt / 1e6, "unit": "MS/s", "chunks_per_slot": cps,
+            "note": "host arrays in, audio + baseband out over PCIe: pinned ring slots, one H2D copy + one launch "
+                    "sequence + 2*NUM_RX+1 D2H copies per slot, results collected one slot late; includes the host "
+                    "memcpy into the slot that stands for readStream()"}
 
 
 def source_sha(name):
@@ -538,6 +569,12 @@ def main():
     }
     if ablated:
         out["invalid"] = "PYSDR_DEBUG_FLAGS != 0 in a diagnostic build: work was skipped, no roofline is reported"
+
+    # PCIe-inclusive figure (never `value`): the same chunks handed over as HOST arrays through the
+    # ingest ring (N4), slots of 16 chunks, including the host memcpy that stands for readStream()
+    if rank == 0 and world == 1 and not args.no_host_fed and not split_rx and rxs and not is_wfm:
+        out["host_fed"] = host_fed_rate(ctx, cfg, L, 16 if B >= 16 else B)
+        out["host_fed_ms_per_chunk"] = out["host_fed"]["ms_per_chunk"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], used = cpu_baseline(cfg, args.cpu_chunks, with_psd, 10)

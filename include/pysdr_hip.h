@@ -228,6 +228,14 @@ int pysdr_comm_destroy(pysdr_ctx* ctx);
  * ring before the context it was created on. */
 typedef struct pysdr_ingest pysdr_ingest;
 int  pysdr_ingest_create(pysdr_ctx* ctx, int nslots, pysdr_ingest** out);
+/* Slots of `chunks_per_slot` chunks (<= cfg.max_chunks): one DMA, one launch sequence and one set of
+ * result copies per slot instead of per chunk -- the per-chunk fixed costs (about ten kernel
+ * launches, 2 NUM_RX + 1 copies) are what bounds the one-chunk ring at 1.6 GS/s.  A slot submitted
+ * with a whole number of IN_CHUNK_SIZE chunks is processed exactly as that many pysdr_process
+ * calls; pysdr_ingest_chunks tells the per-chunk output counts and raw peaks (rx.auto_mute input)
+ * so that the caller can cut the slot's audio back into chunks (receiver.py:238-252). */
+int  pysdr_ingest_create_batched(pysdr_ctx* ctx, int nslots, int chunks_per_slot, pysdr_ingest** out);
+int  pysdr_ingest_chunks(pysdr_ingest* ing, int slot, int cap, int* nchunks, int* chunk_nout, float* peaks);
 void pysdr_ingest_destroy(pysdr_ingest* ing);
 int  pysdr_ingest_buffer(pysdr_ingest* ing, int slot, float** iq, size_t* cap_samples);
 int  pysdr_ingest_submit(pysdr_ingest* ing, int slot, size_t n);

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "pysdr_spectrum_elapsed_ms": (_i, [_vp, _pf]),
     "pysdr_spectrum_order": (_i, [_vp, _vp, _i]),
     "pysdr_ingest_create": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "pysdr_ingest_create_batched": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "pysdr_ingest_chunks": (_i, [_vp, _i, _i, _pi, _pi, _pf]),
     "pysdr_ingest_destroy": (None, [_vp]),
     "pysdr_ingest_buffer": (_i, [_vp, _i, C.POINTER(_pf), C.POINTER(C.c_size_t)]),
     "pysdr_ingest_submit": (_i, [_vp, _i, C.c_size_t]),

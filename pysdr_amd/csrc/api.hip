@@ -175,7 +175,8 @@ struct pysdr_spectrum {
 struct pysdr_ingest {
   pysdr_ctx* c = nullptr;
   int nslots = 0;
-  size_t cap = 0;                         // samples per chunk buffer
+  int chunks_per_slot = 1;
+  size_t cap = 0;                         // samples per slot buffer (chunks_per_slot chunks)
   int ocap = 0;                           // outputs per RX per chunk
   hipStream_t copy_stream = nullptr;
   std::vector<float2*> h_in;              // [nslots] pinned
@@ -185,7 +186,8 @@ struct pysdr_ingest {
   std::vector<hipEvent_t> ev_copied, ev_done;   // [nslots]
   std::vector<float*> h_am, h_iq;         // [nslots*MAX_RX] pinned
   std::vector<float*> h_peak;             // [nslots] pinned
-  std::vector<int> n_out, in_flight;
+  std::vector<int> n_out, in_flight, n_chunks;
+  std::vector<std::vector<int>> chunk_nout;     // [nslots][chunks of the slot's last submit]
   std::vector<int> cx;                    // [nslots*MAX_RX]
   unsigned long long seq = 0;
 };
@@ -984,6 +986,23 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   return PYSDR_OK;
 }
 
+// outputs of the last call per chunk: those whose newest input sample falls into chunk k (a
+// two-level cascade for WFM); host arithmetic only
+static void last_chunk_counts(pysdr_ctx* c, int* chunk_nout) {
+  auto first_out = [&](unsigned long long s) -> unsigned long long {
+    if (!c->last_wfm) {
+      const unsigned long long up = c->cfg.up, down = c->cfg.down;
+      return (s * up + down - 1) / down;
+    }
+    const unsigned long long m1 = (s + c->d1 - 1) / (unsigned long long)c->d1;
+    return (m1 * (unsigned long long)c->up2 + c->down2 - 1) / (unsigned long long)c->down2;
+  };
+  for (int k = 0; k < c->last_nchunks; ++k) {
+    const unsigned long long a0 = c->last_s0 + (unsigned long long)k * c->last_chunk_len;
+    chunk_nout[k] = (int)(first_out(a0 + c->last_chunk_len) - first_out(a0));
+  }
+}
+
 int pysdr_fetch(pysdr_ctx* c, int irx, float* am, float* iq, int cap, int* n_out,
                 int* am_is_complex, int* chunk_nout, float* peaks) {
   if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
@@ -1002,21 +1021,7 @@ int pysdr_fetch(pysdr_ctx* c, int irx, float* am, float* iq, int cap, int* n_out
   PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (n_out) *n_out = n;
   if (am_is_complex) *am_is_complex = cx;
-  if (chunk_nout) {
-    // outputs whose newest input sample falls into chunk k (a two-level cascade for WFM)
-    auto first_out = [&](unsigned long long s) -> unsigned long long {
-      if (!c->last_wfm) {
-        const unsigned long long up = c->cfg.up, down = c->cfg.down;
-        return (s * up + down - 1) / down;
-      }
-      const unsigned long long m1 = (s + c->d1 - 1) / (unsigned long long)c->d1;
-      return (m1 * (unsigned long long)c->up2 + c->down2 - 1) / (unsigned long long)c->down2;
-    };
-    for (int k = 0; k < c->last_nchunks; ++k) {
-      const unsigned long long a0 = c->last_s0 + (unsigned long long)k * c->last_chunk_len;
-      chunk_nout[k] = (int)(first_out(a0 + c->last_chunk_len) - first_out(a0));
-    }
-  }
+  if (chunk_nout) last_chunk_counts(c, chunk_nout);
   return PYSDR_OK;
 }
 
@@ -1329,12 +1334,21 @@ void pysdr_ingest_destroy(pysdr_ingest* g) {
 }
 
 int pysdr_ingest_create(pysdr_ctx* c, int nslots, pysdr_ingest** out) {
-  if (!c || !out || nslots < 2 || nslots > 64) return PYSDR_ERR_ARG;
+  return pysdr_ingest_create_batched(c, nslots, 1, out);
+}
+
+int pysdr_ingest_create_batched(pysdr_ctx* c, int nslots, int chunks_per_slot, pysdr_ingest** out) {
+  if (!c || !out || nslots < 2 || nslots > 64 || chunks_per_slot < 1) return PYSDR_ERR_ARG;
+  if (chunks_per_slot > c->cfg.max_chunks) {
+    set_last_error("pysdr_ingest_create_batched: %d chunks per slot > the context's max_chunks %d", chunks_per_slot,
+                   c->cfg.max_chunks);
+    return PYSDR_ERR_ARG;
+  }
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   pysdr_ingest* g = new pysdr_ingest();
-  g->c = c; g->nslots = nslots;
-  g->cap = (size_t)c->cfg.in_chunk;
+  g->c = c; g->nslots = nslots; g->chunks_per_slot = chunks_per_slot;
+  g->cap = (size_t)c->cfg.in_chunk * (size_t)chunks_per_slot;
   g->ocap = (int)((g->cap * (size_t)c->cfg.up) / (size_t)c->cfg.down) + 8;
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_error("pysdr_ingest_create: %s -> %s", #e, hipGetErrorString(_e)); pysdr_ingest_destroy(g); return PYSDR_ERR_HIP; } } while (0)
   CK(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
@@ -1346,10 +1360,12 @@ int pysdr_ingest_create(pysdr_ctx* c, int nslots, pysdr_ingest** out) {
   g->h_peak.assign(nslots, nullptr);
   g->n_out.assign(nslots, 0);
   g->in_flight.assign(nslots, 0);
+  g->n_chunks.assign(nslots, 0);
+  g->chunk_nout.assign(nslots, std::vector<int>());
   g->cx.assign((size_t)nslots * PYSDR_MAX_RX, 0);
   for (int s = 0; s < nslots; ++s) {
     CK(hipHostMalloc(reinterpret_cast<void**>(&g->h_in[s]), g->cap * sizeof(float2), hipHostMallocDefault));
-    CK(hipHostMalloc(reinterpret_cast<void**>(&g->h_peak[s]), sizeof(float), hipHostMallocDefault));
+    CK(hipHostMalloc(reinterpret_cast<void**>(&g->h_peak[s]), (size_t)chunks_per_slot * sizeof(float), hipHostMallocDefault));
     CK(hipEventCreateWithFlags(&g->ev_copied[s], hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&g->ev_done[s], hipEventDisableTiming));
     for (int r = 0; r < PYSDR_MAX_RX; ++r) {
@@ -1386,7 +1402,11 @@ int pysdr_ingest_submit(pysdr_ingest* g, int slot, size_t n) {
   PYSDR_HIP_CHECK(hipMemcpyAsync(g->d_in[b], g->h_in[slot], n * sizeof(float2), hipMemcpyHostToDevice, g->copy_stream));
   PYSDR_HIP_CHECK(hipEventRecord(g->ev_copied[slot], g->copy_stream));
   PYSDR_HIP_CHECK(hipStreamWaitEvent(c->stream, g->ev_copied[slot], 0));
-  rc = pysdr_process_batch(c, g->d_in[b], 1, n, 1);
+  // a slot of whole chunks is ONE launch sequence over all of them (same arithmetic as chunk by
+  // chunk: pysdr_process_batch); anything else is a single (possibly short) chunk
+  const size_t lc = (size_t)c->cfg.in_chunk;
+  const int nch = (n > lc && n % lc == 0) ? (int)(n / lc) : 1;
+  rc = pysdr_process_batch(c, g->d_in[b], nch, nch > 1 ? lc : n, 1);
   if (rc) return rc;
   PYSDR_HIP_CHECK(hipEventRecord(g->ev_free[b], c->stream));
   g->used[b] = true;
@@ -1403,10 +1423,29 @@ int pysdr_ingest_submit(pysdr_ingest* g, int slot, size_t n) {
                                      (size_t)nout * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
     }
   }
-  PYSDR_HIP_CHECK(hipMemcpyAsync(g->h_peak[slot], c->d_peak, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipMemcpyAsync(g->h_peak[slot], c->d_peak, (size_t)nch * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   PYSDR_HIP_CHECK(hipEventRecord(g->ev_done[slot], c->stream));
+  g->n_chunks[slot] = nch;
+  g->chunk_nout[slot].assign(nch, 0);
+  last_chunk_counts(c, g->chunk_nout[slot].data());
   g->in_flight[slot] = 1;
   g->seq += 1;
+  return PYSDR_OK;
+}
+
+int pysdr_ingest_chunks(pysdr_ingest* g, int slot, int cap, int* nchunks, int* chunk_nout, float* peaks) {
+  if (!g || slot < 0 || slot >= g->nslots || !nchunks) return PYSDR_ERR_ARG;
+  if (!g->in_flight[slot]) { set_last_error("pysdr_ingest_chunks: slot %d was not submitted", slot); return PYSDR_ERR_STATE; }
+  int rc = use_device(g->c->cfg.device);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipEventSynchronize(g->ev_done[slot]));
+  const int n = g->n_chunks[slot];
+  *nchunks = n;
+  if ((chunk_nout || peaks) && cap < n) { set_last_error("pysdr_ingest_chunks: cap %d < %d chunks", cap, n); return PYSDR_ERR_ARG; }
+  for (int k = 0; k < n; ++k) {
+    if (chunk_nout) chunk_nout[k] = g->chunk_nout[slot][k];
+    if (peaks) peaks[k] = g->h_peak[slot][k];
+  }
   return PYSDR_OK;
 }
 

@@ -231,33 +231,58 @@ class SDR_EXECUTIVE:
             P.RX_DONE = P.RX_DONE or t >= P.DURATION
         self.quit_rx()
 
-    def Run_pipelined(self, on_chunk=None, nslots=3):
-        """``Run`` with the ingest ring (N4): ``self.x`` is a pinned ring slot, the chunk is
-        submitted asynchronously and its audio is post-processed one chunk later, while the
-        next chunk is being read.  Same chunks, same order, same results as ``Run``."""
+    def Run_pipelined(self, on_chunk=None, nslots=3, batch_chunks=1):
+        """``Run`` with the ingest ring (N4): ``self.x`` is (a chunk of) a pinned ring slot, the slot
+        is submitted asynchronously and its audio is post-processed one slot later, while the next
+        chunks are being read.  ``batch_chunks`` > 1 puts that many chunks into one slot = one DMA
+        and one launch sequence (throughput, at the price of that many chunks of latency).  Same
+        chunks, same order, same results as ``Run``."""
         from .ingest import IngestRing
         P = self.P
-        ring = IngestRing(P._pysdr_stream, nslots)
-        dt = float(P.IN_CHUNK_SIZE) / P.SRATE
+        B = max(1, int(batch_chunks))
+        if B > 1 and getattr(P._pysdr_stream, 'max_chunks', 1) < B:
+            raise ValueError(f"Run_pipelined(batch_chunks={B}) needs P.MAX_BATCH_CHUNKS >= {B}")
+        L = P.IN_CHUNK_SIZE
+        ring = IngestRing(P._pysdr_stream, nslots, B)
+        dt = float(L) / P.SRATE
         t = 0.0
         self.Startup()
-        slot, pending = 0, None
+        slot, pending, filled = 0, None, 0
 
         def finish(ps):
-            res = ring.collect(ps)
-            xs = ring.buffer(ps)
-            for irx in range(P.NUM_RX):
-                rx = P.rx[irx]
-                rx.am, rx.iq, rx.peak_in = res[irx]
-                post_demod(P, xs, irx, rx.am)
-            audio_out(P)
-            if P.SHOW_RF_PSD:
-                P.rb_rf.push(xs.copy())
-            if P.SAVE_IQ:
-                P.raw_iq_io.save_data(xs)
-            if on_chunk is not None:
-                self.x = xs
-                on_chunk(self)
+            nfill = ps[1]
+            cn, pk = ring.chunks(ps[0])          # (before collect: collecting releases the slot)
+            res = ring.collect(ps[0])
+            xs_all = ring.buffer(ps[0])
+            pos = 0
+            for k in range(nfill):
+                xs = xs_all[k * L:(k + 1) * L]
+                n = int(cn[k])
+                for irx in range(P.NUM_RX):
+                    rx = P.rx[irx]
+                    am, iq, _ = res[irx]
+                    rx.am, rx.iq, rx.peak_in = am[pos:pos + n], iq[pos:pos + n], float(pk[k])
+                    post_demod(P, xs, irx, rx.am)
+                pos += n
+                audio_out(P)
+                if P.SHOW_RF_PSD:
+                    P.rb_rf.push(xs.copy())
+                if P.SAVE_IQ:
+                    P.raw_iq_io.save_data(xs)
+                if on_chunk is not None:
+                    self.x = xs
+                    on_chunk(self)
+
+        def flush():
+            nonlocal slot, pending, filled
+            if filled == 0:
+                return
+            ring.submit(slot, filled * L)
+            if pending is not None:
+                finish(pending)
+            pending = (slot, filled)
+            slot = (slot + 1) % nslots
+            filled = 0
 
         try:
             while not P.RX_DONE:
@@ -266,24 +291,33 @@ class SDR_EXECUTIVE:
                 if P.Stopper and P.Stopper.is_set():
                     P.RX_DONE = True
                     break
-                self.x = ring.buffer(slot)
+                dst = ring.buffer(slot)[filled * L:(filled + 1) * L]
+                self.x = dst
                 self.read_chunk()
                 if P.RX_DONE:
                     break
-                if self.x is not ring.buffer(slot):         # replay hands back its own array
-                    ring.buffer(slot)[:] = self.x
+                if self.x is not dst:                       # replay hands back its own array
+                    dst[:] = self.x
+                if self.mode_freq_change_pending():
+                    flush()                                 # a retune / mode change applies from THIS chunk on
+                    dst2 = ring.buffer(slot)[0:L]
+                    if dst2 is not dst:
+                        dst2[:] = dst
                 self.mode_freq_change()
-                ring.submit(slot, P.IN_CHUNK_SIZE)
-                if pending is not None:
-                    finish(pending)
-                pending = slot
-                slot = (slot + 1) % nslots
+                filled += 1
+                if filled == B:
+                    flush()
                 P.RX_DONE = P.RX_DONE or t >= P.DURATION
+            flush()
             if pending is not None:
                 finish(pending)
         finally:
             ring.close()
         self.quit_rx()
+
+    def mode_freq_change_pending(self):
+        P = self.P
+        return bool(getattr(P, 'MODE_CHANGE', False) or getattr(P, 'FREQ_CHANGE', False))
 
     # -- receiver.py:461-500
     def quit_rx(self):

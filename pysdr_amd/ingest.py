@@ -16,13 +16,17 @@ from ._lib import check
 
 
 class IngestRing:
-    def __init__(self, ctx, nslots=3):
-        """``ctx`` = the stream context shared by the sub-receivers (``P._pysdr_stream``)."""
+    def __init__(self, ctx, nslots=3, chunks_per_slot=1):
+        """``ctx`` = the stream context shared by the sub-receivers (``P._pysdr_stream``).
+        ``chunks_per_slot`` > 1: a slot holds that many consecutive chunks and goes through the
+        device as ONE batch (same arithmetic; the per-chunk fixed costs are paid once per slot)."""
         self.ctx = ctx
         self.nslots = int(nslots)
+        self.chunks_per_slot = int(chunks_per_slot)
         self.L = _lib.lib()
         h = C.c_void_p()
-        check(self.L.pysdr_ingest_create(ctx.h, self.nslots, C.byref(h)), "pysdr_ingest_create")
+        check(self.L.pysdr_ingest_create_batched(ctx.h, self.nslots, self.chunks_per_slot, C.byref(h)),
+              "pysdr_ingest_create_batched")
         self.h = h
         if not hasattr(ctx, '_rings'):
             ctx._rings = []
@@ -44,7 +48,16 @@ class IngestRing:
         for rx in self.ctx.receivers:
             rx._sync_controls()
         check(self.L.pysdr_ingest_submit(self.h, slot, n), "pysdr_ingest_submit")
-        self.ctx.seq += 1
+        self.ctx.seq += max(1, n // max(1, int(self.ctx.cfg.in_chunk)))
+
+    def chunks(self, slot):
+        """-> (per-chunk output counts, per-chunk raw peaks max|x|^2) of a submitted slot (waits for it)."""
+        n = C.c_int(0)
+        cn = np.zeros(self.chunks_per_slot, np.int32)
+        pk = np.zeros(self.chunks_per_slot, np.float32)
+        check(self.L.pysdr_ingest_chunks(self.h, slot, self.chunks_per_slot, C.byref(n),
+                                         cn.ctypes.data_as(C.POINTER(C.c_int)), _lib.as_pf(pk)), "pysdr_ingest_chunks")
+        return cn[:n.value].copy(), pk[:n.value].copy()
 
     def collect(self, slot):
         """-> [(am, iq, peak_in)] per sub-receiver (copies: the slot may be reused at once)."""

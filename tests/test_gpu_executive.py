@@ -123,8 +123,8 @@ def test_ingest_ring_pipelined_run_equals_the_synchronous_run():
     cfg = so.CONFIGS['C3']
     nchunks = 6
 
-    def run(pipelined, dsp=None):
-        P = make_P(cfg, nchunks, audio=2)
+    def run(pipelined, dsp=None, batch=1):
+        P = make_P(cfg, nchunks, audio=2, max_batch_chunks=max(batch, 1))
         L = P.IN_CHUNK_SIZE
         P.sdr = stream.SynthSDR(cfg, seed=51, nsamp=(nchunks + 1) * L)
         P.ENABLE_AUTO_MUTE = True
@@ -137,7 +137,10 @@ def test_ingest_ring_pipelined_run_equals_the_synchronous_run():
             seen.append(e.x.copy())
             peaks.append(P.rx[0].peak_in)
 
-        (ex.Run_pipelined if pipelined else ex.Run)(on_chunk=on_chunk)
+        if pipelined:
+            ex.Run_pipelined(on_chunk=on_chunk, batch_chunks=batch)
+        else:
+            ex.Run(on_chunk=on_chunk)
         return P, [pl.rb.pull(pl.rb.nsamps) for pl in P.players], seen, peaks
 
     Pa, aa, sa, pa = run(False)
@@ -148,6 +151,12 @@ def test_ingest_ring_pipelined_run_equals_the_synchronous_run():
     for u, v in zip(aa, ab):
         assert u.shape == v.shape and np.array_equal(u, v)
     assert Pb.sdr.ncall > nchunks
+    # slots of 4 chunks (6 chunks = one full slot + a partial one): one DMA + one launch sequence per
+    # slot, the audio cut back into chunks on the host -- still the synchronous run, bit for bit
+    Pc, ac, sc, pc = run(True, batch=4)
+    assert len(sc) == nchunks and all(np.array_equal(u, v) for u, v in zip(sa, sc)) and pa == pc
+    for u, v in zip(aa, ac):
+        assert u.shape == v.shape and np.array_equal(u, v)
     # ... and the pipelined run against the ORACLE's loop directly (not only against the other GPU
     # path): same chunks, same routing, same auto-mute input
     Po, ao, so_, po = run(False, dsp=oracle_dsp)
