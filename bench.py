@@ -564,7 +564,7 @@ def main():
                    "psd_group": int(sp_tune[0]) if sp is not None else None,
                    "psd_rocfft": int(sp_tune[1]) if sp is not None else None,
                    "env": {k: os.environ[k] for k in TUNING_ENV if k in os.environ},
-                   "flags": [a for a in sys.argv[1:] if a.startswith("--") and a not in ("--gpus", "--steps", "--warmup")]},
+                   "argv": " ".join(sys.argv[1:])},
         "source_sha256": {s: source_sha(s) for s in ("mixdec.hip", "psdfft.hip", "stage2.hip", "api.hip")},
     }
     if ablated:
@@ -594,6 +594,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        try:                     # RCCL prints a version banner through C stdio: the JSON stays the LAST line
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     return 0
 
