@@ -517,8 +517,11 @@ def main():
                   "mixdec_kernel<1,16> + wfm_disc/pll + mixdec_kernel<1,..> (FM front end: IF decimate, discriminator, pilot PLL, audio resample)")
     r_front = roof(front_name, k1_bytes, k1_ms if k1 else None,
                    measured_traffic(args, nrx, B, "mixdec", ["mixdec.hip"]))
-    r_psd = roof("psd kernels (window, zero-pad, 64k FFT, |.|^2, dB, fftshift)", psd_bytes, psd_ms,
-                 measured_traffic(args, nrx, B, "psd", ["psdfft.hip"]),
+    psd_tr = measured_traffic(args, nrx, B, "psd", ["psdfft.hip"])
+    if psd_tr[0] is not None and sp is not None and sp_tune[0] > 0:
+        # the profile's figure is per launch pair of one group of frames; one call = nframes / group of them
+        psd_tr = (psd_tr[0] * nframes / float(sp_tune[0]), psd_tr[1] + f"; per group of {int(sp_tune[0])} frames, scaled to the call")
+    r_psd = roof("psd kernels (window, zero-pad, 64k FFT, |.|^2, dB, fftshift)", psd_bytes, psd_ms, psd_tr,
                  note="one call = all frames of the batch; per launch figures are per call")
     # the kernel (group) that dominates the timed region carries the headline roofline object
     dominant = r_psd if (r_psd is not None and (not k1 or psd_ms >= k1_ms)) else r_front

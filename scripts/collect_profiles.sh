@@ -13,10 +13,10 @@ run_cfg() {  # name, pmc(0/1), bench args...
   local name=$1 pmc=$2; shift 2
   mkdir -p "$OUT/$name"
   python3 bench.py "$@" > "$OUT/$name/bench.json" 2> "$OUT/$name/bench.err"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name/kt" -- python3 bench.py "$@" --no-cpu-baseline > "$OUT/$name/bench_kt.json" 2> "$OUT/$name/kt.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name/kt" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed > "$OUT/$name/bench_kt.json" 2> "$OUT/$name/kt.err"
   if [ "$pmc" = 1 ]; then
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$name/pmc_fetch" -- python3 bench.py "$@" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/$name/pmc_fetch.json" 2> "$OUT/$name/pmc_fetch.err"
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$name/pmc_write" -- python3 bench.py "$@" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/$name/pmc_write.json" 2> "$OUT/$name/pmc_write.err"
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$name/pmc_fetch" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --steps 3 --warmup 1 > "$OUT/$name/pmc_fetch.json" 2> "$OUT/$name/pmc_fetch.err"
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$name/pmc_write" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --steps 3 --warmup 1 > "$OUT/$name/pmc_write.json" 2> "$OUT/$name/pmc_write.err"
   fi
   # keep only the small summaries (the per-dispatch traces are tens of MB)
   find "$OUT/$name" -name "*kernel_trace.csv" -delete
