@@ -48,13 +48,16 @@ class RTTY_Filterbank:
         self._L = _lib.lib()
         h = C.c_void_p()
         win = np.ascontiguousarray(self.window, np.float32)
-        check(self._L.pysdr_spectrum_create(device, p.N, p.NFFT, self.max_symbols, _lib.as_pf(win),
+        # the four quarter-symbol lines of a symbol start N/4 apart: when that is a whole number of
+        # samples (48 kHz: N = 1056) all 4k lines of k symbols are ONE batch with hop N/4
+        self._uniform = all(int(p.NSTART[i]) * 4 == i * p.N for i in range(4))
+        check(self._L.pysdr_spectrum_create(device, p.N, p.NFFT, 4 * self.max_symbols, _lib.as_pf(win),
                                             C.byref(h)), "pysdr_spectrum_create")
         self._h = h
         self._d_in = C.c_void_p()
         self._d_out = C.c_void_p()
         check(self._L.pysdr_dev_alloc(device, (self.max_symbols + 1) * p.N * 8, C.byref(self._d_in)), "alloc")
-        check(self._L.pysdr_dev_alloc(device, self.max_symbols * p.NFFT * 4, C.byref(self._d_out)), "alloc")
+        check(self._L.pysdr_dev_alloc(device, 4 * self.max_symbols * p.NFFT * 4, C.byref(self._d_out)), "alloc")
         self._fifo = np.zeros(0, np.complex64)
         self._prev = None
 
@@ -93,6 +96,15 @@ class RTTY_Filterbank:
             x = np.ascontiguousarray(np.concatenate((self._prev, cur)))
             check(self._L.pysdr_dev_upload(self.device, self._d_in, C.c_void_p(x.ctypes.data), x.nbytes), "upload")
             lines = np.empty((4 * k, p.NFFT), np.float32)
+            if self._uniform:
+                # one launch sequence, one download: frame 4 s + i starts at s N + i N/4
+                check(self._L.pysdr_spectrum_batch(self._h, self._d_in, 4 * k, p.N // 4, self._d_out), "spectrum_batch")
+                check(self._L.pysdr_spectrum_sync(self._h), "spectrum_sync")
+                check(self._L.pysdr_dev_download(self.device, C.c_void_p(lines.ctypes.data), self._d_out, lines.nbytes),
+                      "download")
+                out.append(lines[:, ::-1].copy())                # np.flipud of the shifted spectrum
+                self._prev = cur[-p.N:].copy()
+                continue
             tmp = np.empty((k, p.NFFT), np.float32)
             for i in range(4):
                 # frames of quarter i: start NSTART[i] + s*N, s = 0..k-1
