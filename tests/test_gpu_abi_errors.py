@@ -183,3 +183,45 @@ def test_raw_abi_set_mode_and_set_lo_race_pysdr_process():
         t.join()
     assert not bad
     lib.pysdr_destroy(h)
+
+
+def test_batched_ingest_ring_misuse():
+    """Slots of several chunks (pysdr_ingest_create_batched / pysdr_ingest_chunks): capacity and call
+    order violations return a status, and a proper submit / chunks / collect still works afterwards."""
+    lib, h = _ctx(max_chunks=4)
+    hdec, af = _taps()
+    irx = C.c_int(-1)
+    assert lib.pysdr_rx_add(h, 9, -455e3, _lib.as_pd(hdec), _lib.as_pd(af), 0.0, C.byref(irx)) == 0
+    ing = C.c_void_p()
+    assert lib.pysdr_ingest_create_batched(h, 3, 5, C.byref(ing)) < 0          # > max_chunks
+    assert b"max_chunks" in lib.pysdr_last_error()
+    assert lib.pysdr_ingest_create_batched(h, 3, 0, C.byref(ing)) < 0
+    _lib.check(lib.pysdr_ingest_create_batched(h, 3, 4, C.byref(ing)), "create_batched")
+    n = C.c_int(0)
+    cn = np.zeros(4, np.int32)
+    pk = np.zeros(4, np.float32)
+    pcn, ppk = cn.ctypes.data_as(C.POINTER(C.c_int)), _lib.as_pf(pk)
+    assert lib.pysdr_ingest_chunks(ing, 0, 4, C.byref(n), pcn, ppk) < 0         # never submitted
+    p = C.POINTER(C.c_float)()
+    cap = C.c_size_t(0)
+    _lib.check(lib.pysdr_ingest_buffer(ing, 0, C.byref(p), C.byref(cap)), "buffer")
+    assert cap.value == 4 * 170666
+    buf = np.ctypeslib.as_array(p, shape=(2 * cap.value,)).view(np.complex64)
+    buf[:] = so.synth_iq(so.CONFIGS['C2'], cap.value, 7)
+    assert lib.pysdr_ingest_submit(ing, 0, cap.value + 1) < 0                   # more than the slot holds
+    _lib.check(lib.pysdr_ingest_submit(ing, 0, 3 * 170666), "submit")           # three whole chunks
+    assert lib.pysdr_ingest_submit(ing, 0, 170666) < 0                          # already in flight
+    assert lib.pysdr_ingest_chunks(ing, 0, 2, C.byref(n), pcn, ppk) < 0         # cap < 3 chunks
+    _lib.check(lib.pysdr_ingest_chunks(ing, 0, 4, C.byref(n), pcn, ppk), "chunks")
+    assert n.value == 3 and all(c in (1023, 1024, 1025) for c in cn[:3]) and np.all(pk[:3] > 0)
+    outs = (_lib.Out * 1)()
+    _lib.check(lib.pysdr_ingest_collect(ing, 0, outs), "collect")
+    assert outs[0].n_out == int(cn[:3].sum())
+    assert lib.pysdr_ingest_chunks(ing, 0, 4, C.byref(n), pcn, ppk) < 0         # collected: released
+    # a slot that is not a whole number of chunks is ONE (short) chunk
+    _lib.check(lib.pysdr_ingest_submit(ing, 1, 100000), "submit short")
+    _lib.check(lib.pysdr_ingest_chunks(ing, 1, 4, C.byref(n), pcn, ppk), "chunks")
+    assert n.value == 1
+    _lib.check(lib.pysdr_ingest_collect(ing, 1, outs), "collect")
+    lib.pysdr_ingest_destroy(ing)
+    lib.pysdr_destroy(h)
