@@ -41,7 +41,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PSD_CHUNK, PSD_NFFT = 32768, 65536
-DEFAULT_CHUNKS = {"c1": 4096, "c2": 2048, "c3": 2048, "c4": 1024, "c4mono": 1024}
+DEFAULT_CHUNKS = {"c1": 4096, "c2": 2048, "c3": 2048, "c4": 2048, "c4mono": 2048}
 TUNING_ENV = ("PYSDR_MIXDEC_WGS", "PYSDR_MIXDEC_YFLUSH", "PYSDR_DEBUG_FLAGS", "PYSDR_PSD_GROUP",
               "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS")
 
@@ -387,16 +387,22 @@ def main():
     # the batch.  Broadcast FM: the loop is 1.7 M samples = a whole number of cycles of the carrier,
     # the pilot and both tones, so the repeated stream is seamless -- a pilot that jumps every
     # 8 chunks would keep the pilot PLL re-acquiring, which no real broadcast does.
+    # A batch of B chunks is not a whole number of those 1.7 M samples, so step k reads the (one loop
+    # longer) buffer from offset k * nsamp mod 1.7 M: what the receiver sees across steps is ONE
+    # continuous stream, as from an antenna, not a station that jumps in phase every step.
     seed = 10 + (0 if split_rx else rank)
+    nloop = 1700000 if 'wfm' in cfg else 8 * L
+    seam = nsamp % nloop                                  # 0 for the narrow-band configurations
+    nbuf = nsamp + (nloop if seam else 0)
     d_x = C.c_void_p()
-    _lib.check(lib.pysdr_dev_alloc(device, nsamp * 8, C.byref(d_x)), "alloc x")
+    _lib.check(lib.pysdr_dev_alloc(device, nbuf * 8, C.byref(d_x)), "alloc x")
     if not split_rx or rank == 0:
-        nloop = 1700000 if 'wfm' in cfg else 8 * L
         xu = synth_batch(cfg, nloop, seed)
-        for off in range(0, nsamp, nloop):
-            n = min(nloop, nsamp - off)
+        for off in range(0, nbuf, nloop):
+            n = min(nloop, nbuf - off)
             _lib.check(lib.pysdr_dev_upload(device, C.c_void_p(d_x.value + off * 8),
                                             C.c_void_p(xu.ctypes.data), n * 8), "upload")
+    step_no = [0]
     bc = multi.RcclBroadcaster(ctx, dist) if split_rx else None
 
     sp = None
@@ -418,7 +424,10 @@ def main():
                 _lib.check(lib.pysdr_spectrum_order(sp, ctx.h, 1), "spectrum_order")   # PSD of the last step has read d_x
             bc.bcast(d_x.value, nsamp * 8, 0)
         if not args.no_demod and rxs:
-            ctx.process_batch(d_x.value, B, L, on_device=True)
+            off = (step_no[0] * seam) % nloop if seam else 0
+            off -= off & 1                               # keep the 16-byte alignment of the fast load path
+            step_no[0] += 1
+            ctx.process_batch(d_x.value + off * 8, B, L, on_device=True)
         if sp is not None:
             # Same order as pySDR's RX thread (demod of the chunk, then its PSD): the two are
             # both HBM-bound, so overlapping them on two streams buys nothing and only smears

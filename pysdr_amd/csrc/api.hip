@@ -39,10 +39,11 @@ constexpr int kPllSegMax = 4096;
 
 // Segmentation of a serial PLL over n samples (PllPlan, common.h).  W = warm-up in samples = `taus`
 // time constants 1/(zeta*wn) of the loop; calls shorter than three warm-ups stay one segment.
-PllPlan plan_pll(int n, double fs, double bw_hz, double taus, int t_min, int k_max, uint32_t* seg) {
+PllPlan plan_pll(int n, double fs, double bw_hz, double taus, double taus_fast, int t_min, int k_max, uint32_t* seg) {
   PllPlan p;
   const double tau = fs / (kPllZetaPlan * 2.0 * M_PI * bw_hz);
   p.W = ((int)std::ceil(taus * tau) + 63) & ~63;
+  p.Wfast = taus_fast > 0 ? (((int)std::ceil(taus_fast * tau) + 63) & ~63) : 0;
   if (n < 3 * p.W || k_max <= 1) {
     p.K = 1;
     p.T = (std::max(n, 64) + 63) & ~63;
@@ -444,7 +445,7 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       PYSDR_HIP_CHECK(hipMemcpyAsync(&st, c->d_state + r, sizeof(st), hipMemcpyDeviceToHost, c->stream));
       PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (x.reset_pending & 1u) { st.env = 0.f; st.gain = 1.f; st.maxbuf = 0.f; st.err = 0.f; st.sq_level = 0.f; st.sq_open = 1; }
-      if (x.reset_pending & 2u) { st.pll_theta = 0.f; st.pll_w = 0.f; st.wfm_phase = 0u; st.wfm_w = 0.f; }
+      if (x.reset_pending & 2u) { st.pll_theta = 0.f; st.pll_w = 0.f; st.wfm_phase = 0u; st.wfm_w = 0.f; st.wfm_slope_ok = 0; }
       st.ref = x.agc_ref; st.agc_enable = x.agc_enable;
       PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_state + r, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
       PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -902,8 +903,11 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
       w.stereo[r] = (snap.rx[r].mode == PYSDR_WFM2) ? 1 : 0;
     }
     w.state = c->d_state;
-    // measured (scripts/experiments/pll_warmup.py): 99 words of 2^32 left after 32768 samples = 17.5 tau
-    w.pll = plan_pll(n1, fs1, kWfmPllBwHz, 18.0, 2048, c->pll_kmax > 0 ? std::min(c->pll_kmax, 1024) : 1024, c->d_pllseg);
+    // measured (scripts/experiments/pll_warmup.py), words of 2^32 left of a wrong start state: from
+    // the call's initial state free-running, 60-270 after 32768 samples = 17.5 tau (one segment in
+    // 200 beyond the 512-word tolerance: 20 tau); from the previous call's MEAN increment (the loop
+    // follows a crystal, so its phase is a straight line plus a bounded wobble) 54 after 13 tau
+    w.pll = plan_pll(n1, fs1, kWfmPllBwHz, 20.0, 13.0, 2048, c->pll_kmax > 0 ? std::min(c->pll_kmax, 1024) : 1024, c->d_pllseg);
     rc = launch_wfm(w, c->stream);
     if (rc) return rc;
     const uint32_t zero = 0u;
@@ -953,7 +957,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   s.blknoise = c->d_blknoise; s.blkcnt = c->d_blkcnt;
   if (any_pll && n_out > 0) {
     // measured: identical floats after 4096 samples = 19 tau of the 50 Hz loop at 48 kHz
-    s.pll = plan_pll(n_out, fs_out, kPllBwHz, 19.0, 512, c->pll_kmax > 0 ? std::min(c->pll_kmax, kPllSegMax) : kPllSegMax, c->d_pllseg);
+    s.pll = plan_pll(n_out, fs_out, kPllBwHz, 19.0, 0.0, 512, c->pll_kmax > 0 ? std::min(c->pll_kmax, kPllSegMax) : kPllSegMax, c->d_pllseg);
     rc = launch_pll(s, c->stream);
     if (rc) return rc;
   }

@@ -79,6 +79,9 @@ struct RxDevState {       // one per RX, lives in device memory
   int sq_open;
   int pll_segments;         // time-parallel PLL of the last call: segments run ...
   int pll_patched;          // ... and segments the serial patch-up pass had to redo
+  int wfm_slope_ok;         // the last call ran in segments and none had to be patched: wfm_slope is usable
+  int wfm_redo;             // this call's short warm-ups did not meet (stream discontinuity): run the long ones
+  double wfm_slope;         // its mean pilot-phase increment per sample beyond fword0 (words of 2^32)
 };
 
 // Time-parallel form of the serial PLLs (WFM2 pilot, AM-Synch carrier), DESIGN.md 4.2: the call's
@@ -92,6 +95,7 @@ struct RxDevState {       // one per RX, lives in device memory
 // the serial speed).
 struct PllPlan {
   int K, T, W;
+  int Wfast;                // shorter warm-up for calls that start from the previous call's mean increment (0: none)
   uint32_t* seg;            // [nrx][K][4]: S.phase, S.w, E.phase, E.w (float fields as bits)
 };
 
@@ -148,6 +152,7 @@ struct WfmArgs {
   int stereo[PYSDR_MAX_RX];
   RxDevState* state;
   PllPlan pll;                        // pilot PLL segmentation of this call
+  int pll_pass;                       // 0: first pass over the segments, 1: the redo pass (only if state.wfm_redo)
 };
 int launch_wfm(const WfmArgs& a, hipStream_t st);
 

@@ -606,13 +606,24 @@ __global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
   const RxDevState* st = a.state + r;
   const int n = a.n1;
   const int s0 = k * pl.T, s1 = (s0 + pl.T < n) ? s0 + pl.T : n;
+  if (a.pll_pass == 1 && !st->wfm_redo) return;
   uint32_t ph = st->wfm_phase;
   float w = st->wfm_w;
-  int wb = s0 - pl.W;
+  const bool fast = pl.Wfast > 0 && st->wfm_slope_ok;
+  int wb = s0 - (fast ? pl.Wfast : pl.W);
   if (k > 0 && wb > 0) {
-    // guess: the call's initial state free-running at its own rate up to the warm-up start
-    const int corr = __float2int_rn(__fmul_rn(w, a.rad2word));
-    ph = ph + (uint32_t)wb * (a.fword0 + (uint32_t)corr);
+    if (fast) {
+      // guess: the call's initial phase carried forward at the MEAN increment of the previous call
+      // (a locked loop follows the station's crystal: a straight line plus a bounded wobble, off by
+      // < 0.005 revolutions where the instantaneous rate below drifts by 0.1), integrator at its mean
+      const double sl = st->wfm_slope;
+      ph = ph + (uint32_t)wb * a.fword0 + (uint32_t)(long long)llrint(sl * (double)wb);
+      w = (float)(sl / (double)a.rad2word);
+    } else {
+      // guess: the call's initial state free-running at its own rate up to the warm-up start
+      const int corr = __float2int_rn(__fmul_rn(w, a.rad2word));
+      ph = ph + (uint32_t)wb * (a.fword0 + (uint32_t)corr);
+    }
   } else {
     wb = 0;
   }
@@ -621,6 +632,35 @@ __global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
   if (lane == 0) { sg[0] = ph; sg[1] = __float_as_uint(w); }
   wfm_pll_walk<true>(a, a.w[r], s0, s1, ph, w, lane);
   if (lane == 0) { sg[2] = ph; sg[3] = __float_as_uint(w); }
+}
+
+// Between the two passes: did the short warm-ups of pass 0 meet their neighbours?  A handful of
+// misses is the patch-up pass's business; many mean that the call's initial state says nothing
+// about the pilot phase further on (the stream is not continuous with the previous call, the pilot
+// came back, ...): then the mean increment is withdrawn and pass 1 runs every segment again with
+// the long warm-up, still side by side, instead of leaving the whole call to the serial pass.
+__global__ __launch_bounds__(64) void wfm_pll_check_kernel(const WfmArgs a) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  if (!a.stereo[r]) return;
+  RxDevState* st = a.state + r;
+  const PllPlan& pl = a.pll;
+  int redo = 0;
+  if (pl.Wfast > 0 && st->wfm_slope_ok && pl.K > 1) {
+    const uint32_t* sg = pl.seg + (size_t)r * pl.K * 4;
+    int miss = 0;
+    for (int base = 1; base < pl.K; base += 64) {
+      const int kk = base + lane;
+      const bool mm = kk < pl.K &&
+          wfm_state_differs(sg[(size_t)(kk - 1) * 4 + 2], __uint_as_float(sg[(size_t)(kk - 1) * 4 + 3]),
+                            sg[(size_t)kk * 4 + 0], __uint_as_float(sg[(size_t)kk * 4 + 1]));
+      miss += __popcll(__ballot(mm));
+    }
+    redo = miss > 2;
+  }
+  if (lane == 0) {
+    st->wfm_redo = redo;
+    if (redo) st->wfm_slope_ok = 0;
+  }
 }
 
 __global__ __launch_bounds__(64) void wfm_pll_patch_kernel(const WfmArgs a) {
@@ -664,12 +704,27 @@ __global__ __launch_bounds__(64) void wfm_pll_patch_kernel(const WfmArgs a) {
     if (!joined) { ph_fin = ph; w_fin = w; break; }
     k = j + 1;
   }
+  // the call's mean phase increment beyond fword0, for the next call's guesses: per segment the
+  // deviation is far below half a revolution (2 Hz of pilot offset = 0.01 cycles over 2048 samples),
+  // so the 32-bit differences are unambiguous and their 64-bit sum is exact
+  // (the first quarter of the call is left out: a pull-in after a discontinuity would tilt the line)
+  long long dev = 0;
+  const int k_lo = K / 4;
+  if (patched == 0 && K > 1)
+    for (int kk = k_lo + lane; kk < K; kk += 64) {
+      const int len = ((kk + 1) * pl.T < n ? (kk + 1) * pl.T : n) - kk * pl.T;
+      dev += (int)(sg[(size_t)kk * 4 + 2] - sg[(size_t)kk * 4 + 0] - (uint32_t)len * a.fword0);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dev += __shfl_xor(dev, o, 64);
   if (lane == 0) {
     RxDevState* st = a.state + r;
     st->wfm_phase = ph_fin;
     st->wfm_w = w_fin;
     st->pll_segments = K;
     st->pll_patched = patched;
+    st->wfm_slope_ok = (patched == 0 && K > 1) ? 1 : 0;
+    st->wfm_slope = (double)dev / (double)(n - k_lo * pl.T);
   }
 }
 
@@ -735,6 +790,14 @@ int launch_wfm(const WfmArgs& a, hipStream_t st) {
   if (any_stereo && a.n1 > 0) {
     hipLaunchKernelGGL(wfm_pll_seg_kernel, dim3(a.pll.K, a.nrx), dim3(64), 0, st, a);
     PYSDR_HIP_CHECK(hipGetLastError());
+    if (a.pll.Wfast > 0 && a.pll.K > 1) {
+      hipLaunchKernelGGL(wfm_pll_check_kernel, dim3(a.nrx), dim3(64), 0, st, a);
+      PYSDR_HIP_CHECK(hipGetLastError());
+      WfmArgs b = a;
+      b.pll_pass = 1;
+      hipLaunchKernelGGL(wfm_pll_seg_kernel, dim3(a.pll.K, a.nrx), dim3(64), 0, st, b);
+      PYSDR_HIP_CHECK(hipGetLastError());
+    }
   }
   hipLaunchKernelGGL(wfm_pll_patch_kernel, dim3(a.nrx), dim3(64), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());

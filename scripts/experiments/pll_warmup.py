@@ -66,7 +66,7 @@ rng = np.random.default_rng(1)
 def pilot():
     from oracle import wfm_oracle as wo
     from pysdr_amd.synth import synth_wfm
-    fs, L, nch = 10e6, 213333, 40
+    fs, L, nch = 10e6, 213333, 80
     x = synth_wfm(fs, nch * L, 4)
     rx = wo.WfmReceiver(fs, 48e3, 300e3, stereo=False, ntaps_dec=255)
     mp, orig = [], rx.audio.process
@@ -90,9 +90,15 @@ def pilot():
                     wo_.ctypes.data_as(fp) if trace else None)
         return phc.value, wc.value, po, wo_
     _, _, P, Wt = run(m, 0, 0.0, True)
+    g0 = []
     print("pilot PLL, %d IF samples; tau = %.0f samples" % (n, fs1 / (0.7071 * 2 * math.pi * 30)))
-    for W in (8192, 16384, 24576, 32768):
-        er, ee = [], []
+    # the mean increment of a past stretch (exact: unwrapped phase advance / samples) as the predictor
+    base, span = 40000, 60000
+    adv = np.cumsum(((P[base + 1:base + span + 1].astype(np.int64) - P[base:base + span].astype(np.int64)) % 2 ** 32))
+    slope = float(adv[-1]) / span
+    wmean = float(np.mean(Wt[base:base + span]))
+    for W in (4096, 16384, 20480, 22528, 24576, 32768):
+        er, ee, es, ws = [], [], [], []
         for s in range(60000, n - 1000, 7919):
             ph, _, _, _ = run(m[s - W:s], int(rng.integers(0, 2 ** 32)), float(Wt[0]))
             er.append(abs((int(ph) - int(P[s]) + 2 ** 31) % 2 ** 32 - 2 ** 31))
@@ -100,7 +106,16 @@ def pilot():
             inc = fw0 + int(np.rint(np.float32(Wt[base]) * R))
             ph, _, _, _ = run(m[s - W:s], (int(P[base]) + (s - W - base) * inc) % 2 ** 32, float(Wt[base]))
             ee.append(abs((int(ph) - int(P[s]) + 2 ** 31) % 2 ** 32 - 2 ** 31))
-        print("  W %5d: random start -> max %d words (median %d); extrapolated start -> max %d" % (W, max(er), np.median(er), max(ee)))
+            g = (int(P[base]) + int(round((s - W - base) * slope))) % 2 ** 32
+            if W == 4096:
+                g0.append(abs((g - int(P[s - W]) + 2 ** 31) % 2 ** 32 - 2 ** 31))
+            ph, wv, _, _ = run(m[s - W:s], g, wmean)
+            es.append(abs((int(ph) - int(P[s]) + 2 ** 31) % 2 ** 32 - 2 ** 31))
+            ws.append(abs(float(wv) - float(Wt[s])))
+        if W == 4096:
+            print("  mean-increment guess itself is off by max %d words (median %d)" % (max(g0), np.median(g0)))
+        print("  W %5d: random start -> max %d words (median %d); extrapolated start -> max %d; mean-increment start -> max %d (median %d), integrator off by max %.2g"
+              % (W, max(er), np.median(er), max(ee), max(es), np.median(es), max(ws)))
 
 
 def carrier():
