@@ -554,13 +554,13 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   if (rc) { pysdr_destroy(c); return rc; }
   CK(hipMalloc(&c->d_peak, (size_t)cfg->max_chunks * sizeof(unsigned)));
   CK(hipMalloc(&c->d_peak_scratch, 64 * sizeof(unsigned)));
-  CK(hipMalloc(&c->d_blkpeak, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
-  CK(hipMemsetAsync(c->d_blkpeak, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned), c->stream));
+  CK(hipMalloc(&c->d_blkpeak, (size_t)PYSDR_MAX_RX * cfg->max_chunks * kBlkStride * sizeof(unsigned)));
+  CK(hipMemsetAsync(c->d_blkpeak, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * kBlkStride * sizeof(unsigned), c->stream));
   CK(hipMalloc(&c->d_gain, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
-  CK(hipMalloc(&c->d_blknoise, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
-  CK(hipMemsetAsync(c->d_blknoise, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float), c->stream));
-  CK(hipMalloc(&c->d_blkcnt, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned)));
-  CK(hipMemsetAsync(c->d_blkcnt, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(unsigned), c->stream));
+  CK(hipMalloc(&c->d_blknoise, (size_t)PYSDR_MAX_RX * cfg->max_chunks * kBlkStride * sizeof(float)));
+  CK(hipMemsetAsync(c->d_blknoise, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * kBlkStride * sizeof(float), c->stream));
+  CK(hipMalloc(&c->d_blkcnt, (size_t)PYSDR_MAX_RX * cfg->max_chunks * kBlkStride * sizeof(unsigned)));
+  CK(hipMemsetAsync(c->d_blkcnt, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * kBlkStride * sizeof(unsigned), c->stream));
   CK(hipMalloc(&c->d_state, PYSDR_MAX_RX * sizeof(RxDevState)));
   CK(hipMemsetAsync(c->d_state, 0, PYSDR_MAX_RX * sizeof(RxDevState), c->stream));
   CK(hipMalloc(&c->d_pllseg, (size_t)PYSDR_MAX_RX * kPllSegMax * 4 * sizeof(uint32_t)));

@@ -69,6 +69,15 @@ int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st);
 size_t mixdec_lds_bytes(const MixDecArgs& a);
 
 // ---- stage 2 at FS_OUT (stage2.hip) --------------------------------------------------
+#ifndef PYSDR_BLK_STRIDE
+#define PYSDR_BLK_STRIDE 64
+#endif
+// Words between the per-block accumulators (block peak, noise sum, count) of consecutive blocks.
+// Atomics on one 128-byte line serialise at the L2 / memory side: with the accumulators of 32
+// blocks in a line the FIR kernel spent 50 of its 165 us waiting for them (measured: stride 1 ->
+// 165 us, 64 words = 256 bytes -> 115 us, 1024 -> 118 us).
+constexpr int kBlkStride = PYSDR_BLK_STRIDE;
+
 struct RxDevState {       // one per RX, lives in device memory
   float env, gain, maxbuf, err, ref;
   int agc_enable;
@@ -114,6 +123,7 @@ struct Stage2Args {
   int det[PYSDR_MAX_RX];
   int out_complex[PYSDR_MAX_RX];
   int fir_complex[PYSDR_MAX_RX];      // what out_complex was when the FIR kernel stored `a` (layout of a)
+  int fir_rx[PYSDR_MAX_RX];           // the FIR kernel's blockIdx.y -> RX (one launch per kind of product)
   uint32_t bfo_fword[PYSDR_MAX_RX];
   int single_block[PYSDR_MAX_RX];     // WFM: no AGC blocks, the whole call is block 0
   int matrix[PYSDR_MAX_RX];           // WFM2: (S, D) -> (S+D) + j(S-D) = L + jR

@@ -142,18 +142,22 @@ __global__ __launch_bounds__(64) void am_pll_patch_kernel(const Stage2Args a) {
   }
 }
 
-// ---- detector + AF FIR + block peak.  grid = (tiles, nrx), 2048 outputs per workgroup,
-// EIGHT consecutive outputs per thread.  The detector output d is staged in LDS as two float
-// arrays (re, im) with S[e + 3] = d[e]: a thread's outputs 8t .. 8t+7 need, for the four taps
+// ---- detector + AF FIR + block peak.  grid = (tiles, RX of this launch), 2048 outputs per
+// workgroup, EIGHT consecutive outputs per thread.  The detector output d is staged in LDS as two
+// float arrays (re, im) with S[e + 3] = d[e]: a thread's outputs 8t .. 8t+7 need, for the four taps
 // 4m .. 4m+3, the eleven values S[8t - 4m .. 8t - 4m + 10] -- three 16-byte chunks, of which only
-// ONE is new per block of four taps.  So four taps cost one ds_read_b128 per array for the data,
-// one broadcast ds_read_b128 per array for the taps (all lanes the same address) and 32 / 64 / 128
-// plain FMAs (real x real, Re(c*d), complex): 94 % of the issue slots are arithmetic.  (The first
-// version read one dword per tap and broadcast the taps with v_readlane: the SGPR hand-off and
-// the v_pk_fma pairs hipcc built from it -- half rate, fed by v_mov shuffles -- left it at 18 %
-// of the FMA peak; this file is compiled with -fno-slp-vectorize.)
+// ONE is new per block of four taps.  So four taps cost one ds_read_b128 per array for the data, two
+// broadcast ds_read_b128 per array for the taps (all lanes the same address) and 16 / 32 / 64 packed
+// FMAs (real x real, Re(c*d), complex) -- see fir_block.  This file is compiled with
+// -fno-slp-vectorize (hipcc's own v_pk pairs come with v_mov shuffles).
 // A chunk read has lanes 32 bytes apart; 4 floats of padding after every 128 keep the sixteen
 // lanes the LDS serves per cycle on sixteen different bank quads.
+// Where the time goes (C3, 4 RX x 2.1 M outputs, ablations by rocprofv3, scripts/diag/stage2_kt.sh):
+// 165 us with one dword of block peak per block side by side (the per-wave atomicMax of 32 blocks
+// hit ONE 128-byte line and serialise: 60 us), 115 us with the accumulators 256 bytes apart
+// (kBlkStride); of those the inner product is 46-63 us (114 as plain v_fmac), staging the tile
+// (loads from HBM + detector) 44, the remaining atomics 21, the stores 3 (16-byte stores; 23 as
+// eight strided dwords) -- the phases of the workgroups of a CU run in step and barely overlap.
 constexpr int kW = 8;                  // outputs per thread
 constexpr int kFirThreads = 256;
 constexpr int kFirOut = kW * kFirThreads;   // outputs per workgroup
@@ -188,25 +192,51 @@ __device__ __forceinline__ float2 detect(const Stage2Args& a, int r, int det, co
   return d;
 }
 
-// Four taps (one block) for the 8 outputs of a lane.  w*[12] = three chunks; ROT = block index
-// mod 3 says which physical chunk is logical chunk 0 (the lowest addresses).
+// ---- the inner product in packed FMAs.  v_pk_fma_f32 does two FMAs for 5.9 issue cycles where
+// v_fmac_f32 does one for 5.4 (scripts/experiments/valu_rate.hip), but its three operands are
+// 64-bit register PAIRS on even registers -- pairing two OUTPUTS of a lane needs, for every other
+// tap, a data pair that starts on an odd register (hipcc then shuffles with v_mov and the gain is
+// gone: round 1, and the first round-2 attempt).  So the pair runs over two TAPS of one output:
+//     acc2[j] += (c[k] * S[e_j - k], c[k+1] * S[e_j - k - 1])
+// whose data pair is the aligned one when e_j - k - 1 is even: even outputs pair the taps
+// (0,1)(2,3).. and odd outputs (1,2)(3,4).., read from a second copy of the taps shifted by one
+// (tap 0 of the odd outputs is their accumulator's initial value, tap H of the copy is zero).  The
+// data pair is used crosswise (op_sel: low half x high half), the two halves of acc2 are added at
+// the end.  Per block of four taps and 8 outputs: 16 / 32 / 64 packed FMAs where the scalar form
+// issued 32 / 64 / 128.
+typedef float v2f __attribute__((ext_vector_type(2)));
+// acc += (c.lo * w.hi, c.hi * w.lo)
+__device__ __forceinline__ void pk_fma_x(v2f& acc, const v2f c, const v2f w) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(c), "v"(w));
+}
+// acc -= (c.lo * w.hi, c.hi * w.lo)
+__device__ __forceinline__ void pk_fms_x(v2f& acc, const v2f c, const v2f w) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+      : "+v"(acc) : "v"(c), "v"(w));
+}
+
+// One block of four taps for the 8 outputs of a lane.  wr/wi[6] = the window of three 16-byte
+// chunks as six pairs; ROT = block index mod 3 says which physical chunk is logical chunk 0 (the
+// lowest addresses).  a4 = taps 4m .. 4m+3, b4 = taps 4m+1 .. 4m+4 (re / im).
 template <int KIND, int ROT>
-__device__ __forceinline__ void fir_block(const float4 cr4, const float4 ci4, const float (&wr)[12],
-                                          const float (&wi)[12], float2 (&acc)[kW]) {
-  const float cr[4] = {cr4.x, cr4.y, cr4.z, cr4.w};
-  const float ci[4] = {ci4.x, ci4.y, ci4.z, ci4.w};
+__device__ __forceinline__ void fir_block(const float4 ar4, const float4 ai4, const float4 br4, const float4 bi4,
+                                          const v2f (&wr)[6], const v2f (&wi)[6], v2f (&ax)[kW], v2f (&ay)[kW]) {
+  const v2f tr[2][2] = {{{ar4.x, ar4.y}, {ar4.z, ar4.w}}, {{br4.x, br4.y}, {br4.z, br4.w}}};
+  const v2f ti[2][2] = {{{ai4.x, ai4.y}, {ai4.z, ai4.w}}, {{bi4.x, bi4.y}, {bi4.z, bi4.w}}};
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int j = 0; j < kW; ++j)
 #pragma unroll
-    for (int j = 0; j < kW; ++j) {
-      const int pos = 3 + j - q;                               // logical window position 0 .. 10
-      const int ph = ((pos >> 2) + 3 - ROT) % 3 * 4 + (pos & 3);   // physical register
-      acc[j].x = fmaf(cr[q], wr[ph], acc[j].x);
+    for (int h = 0; h < 2; ++h) {
+      // logical pair holding the window positions of this tap pair (see above)
+      const int lp = (j & 1) ? (h == 0 ? (1 + j) / 2 : (j - 1) / 2) : (h == 0 ? (2 + j) / 2 : j / 2);
+      const int pp = (((lp >> 1) + 3 - ROT) % 3) * 2 + (lp & 1);       // physical pair
+      const v2f cr = tr[j & 1][h], ci = ti[j & 1][h];
+      pk_fma_x(ax[j], cr, wr[pp]);
       if (KIND != kFirRealReal) {
-        acc[j].x = fmaf(-ci[q], wi[ph], acc[j].x);
+        pk_fms_x(ax[j], ci, wi[pp]);
         if (KIND == kFirCplx) {
-          acc[j].y = fmaf(cr[q], wi[ph], acc[j].y);
-          acc[j].y = fmaf(ci[q], wr[ph], acc[j].y);
+          pk_fma_x(ay[j], cr, wi[pp]);
+          pk_fma_x(ay[j], ci, wr[pp]);
         }
       }
     }
@@ -214,49 +244,70 @@ __device__ __forceinline__ void fir_block(const float4 cr4, const float4 ci4, co
 
 template <int KIND>
 __device__ __forceinline__ void fir_run(const float* sre, const float* sim, const float* tre, const float* tim,
-                                        int nblk, int H, int tid, float2 (&acc)[kW]) {
-  float wr[12], wi[12];
-#pragma unroll
-  for (int j = 0; j < kW; ++j) acc[j] = make_float2(0.f, 0.f);
+                                        const float* tre_s, const float* tim_s, int nblk, int H, int tid,
+                                        float2 (&acc)[kW]) {
+  v2f wr[6], wi[6], ax[kW], ay[kW];
   int e0 = kW * tid + H;                                       // logical chunk 0 of block 0
   auto chunk = [&](const float* s, int e) { return *reinterpret_cast<const float4*>(s + fir_pad(e)); };
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float4 v = chunk(sre, e0 + 4 * c);
-    wr[4 * c] = v.x; wr[4 * c + 1] = v.y; wr[4 * c + 2] = v.z; wr[4 * c + 3] = v.w;
+    wr[2 * c] = (v2f){v.x, v.y}; wr[2 * c + 1] = (v2f){v.z, v.w};
     if (KIND != kFirRealReal) {
       const float4 u = chunk(sim, e0 + 4 * c);
-      wi[4 * c] = u.x; wi[4 * c + 1] = u.y; wi[4 * c + 2] = u.z; wi[4 * c + 3] = u.w;
+      wi[2 * c] = (v2f){u.x, u.y}; wi[2 * c + 1] = (v2f){u.z, u.w};
     } else {
-      wi[4 * c] = wi[4 * c + 1] = wi[4 * c + 2] = wi[4 * c + 3] = 0.f;
+      wi[2 * c] = wi[2 * c + 1] = (v2f){0.f, 0.f};
+    }
+  }
+  // tap 0 of the odd outputs (their pairs start at tap 1): window position 3 + j of block 0
+  {
+    const float c0r = tre[0], c0i = (KIND == kFirRealReal) ? 0.f : tim[0];
+#pragma unroll
+    for (int j = 0; j < kW; ++j) {
+      ax[j] = (v2f){0.f, 0.f};
+      ay[j] = (v2f){0.f, 0.f};
+      if (j & 1) {
+        const int pos = 3 + j;                                  // even: the low half of pair pos / 2
+        const float dr = wr[pos >> 1].x, di = wi[pos >> 1].x;
+        ax[j].x = (KIND == kFirRealReal) ? c0r * dr : fmaf(c0r, dr, -c0i * di);
+        if (KIND == kFirCplx) ay[j].x = fmaf(c0r, di, c0i * dr);
+      }
     }
   }
   // nblk is a multiple of 3: the register roles repeat every three blocks
   for (int m = 0; m < nblk; m += 3) {
 #pragma unroll
     for (int rot = 0; rot < 3; ++rot) {
-      const float4 cr4 = *reinterpret_cast<const float4*>(tre + 4 * (m + rot));
-      const float4 ci4 = (KIND == kFirRealReal) ? make_float4(0.f, 0.f, 0.f, 0.f)
-                                                : *reinterpret_cast<const float4*>(tim + 4 * (m + rot));
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 ar4 = *reinterpret_cast<const float4*>(tre + 4 * (m + rot));
+      const float4 br4 = *reinterpret_cast<const float4*>(tre_s + 4 * (m + rot));
+      const float4 ai4 = (KIND == kFirRealReal) ? z4 : *reinterpret_cast<const float4*>(tim + 4 * (m + rot));
+      const float4 bi4 = (KIND == kFirRealReal) ? z4 : *reinterpret_cast<const float4*>(tim_s + 4 * (m + rot));
       // the chunk the NEXT block adds below the window (never read past the staged history:
       // the last block's successor is e0 - 4 >= 0 and simply goes unused)
       const float4 nr = chunk(sre, e0 - 4);
-      const float4 ni = (KIND == kFirRealReal) ? make_float4(0.f, 0.f, 0.f, 0.f) : chunk(sim, e0 - 4);
-      if (rot == 0) fir_block<KIND, 0>(cr4, ci4, wr, wi, acc);
-      else if (rot == 1) fir_block<KIND, 1>(cr4, ci4, wr, wi, acc);
-      else fir_block<KIND, 2>(cr4, ci4, wr, wi, acc);
+      const float4 ni = (KIND == kFirRealReal) ? z4 : chunk(sim, e0 - 4);
+      if (rot == 0) fir_block<KIND, 0>(ar4, ai4, br4, bi4, wr, wi, ax, ay);
+      else if (rot == 1) fir_block<KIND, 1>(ar4, ai4, br4, bi4, wr, wi, ax, ay);
+      else fir_block<KIND, 2>(ar4, ai4, br4, bi4, wr, wi, ax, ay);
       // it replaces this block's logical chunk 2 = physical chunk (2 - rot) mod 3
-      const int pc = (5 - rot) % 3 * 4;
-      wr[pc] = nr.x; wr[pc + 1] = nr.y; wr[pc + 2] = nr.z; wr[pc + 3] = nr.w;
-      if (KIND != kFirRealReal) { wi[pc] = ni.x; wi[pc + 1] = ni.y; wi[pc + 2] = ni.z; wi[pc + 3] = ni.w; }
+      const int pc = (5 - rot) % 3 * 2;
+      wr[pc] = (v2f){nr.x, nr.y}; wr[pc + 1] = (v2f){nr.z, nr.w};
+      if (KIND != kFirRealReal) { wi[pc] = (v2f){ni.x, ni.y}; wi[pc + 1] = (v2f){ni.z, ni.w}; }
       e0 -= 4;
     }
   }
+#pragma unroll
+  for (int j = 0; j < kW; ++j) acc[j] = make_float2(ax[j].x + ax[j].y, ay[j].x + ay[j].y);
 }
 
+// Two instantiations: the complex product (IQ mode, broadcast FM) needs twice the accumulators --
+// compiled together, every RX would run at its 104 registers = 4 waves per SIMD instead of 7.
+template <bool CPLX>
 __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
-  const int r = blockIdx.y;
+  const int r = a.fir_rx[blockIdx.y];
   const int tid = threadIdx.x;
   const int i0 = blockIdx.x * kFirOut;
   const int det = a.det[r];
@@ -269,9 +320,9 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   float* sim = lds_f + EP;                               // [EP]
   float* tre = lds_f + 2 * EP;                           // [H]
   float* tim = tre + H;                                  // [H]
-  const bool real_det = (det == kDetAbs || det == kDetFm || det == kDetPll);
+  float* tre_s = tim + H;                                // [H]  taps shifted by one: tre_s[k] = tre[k + 1]
+  float* tim_s = tre_s + H;                              // [H]
   const float2* taps = a.aftaps[r];
-  const int kind = a.out_complex[r] ? kFirCplx : (real_det && a.taps_real[r] ? kFirRealReal : kFirRePart);
   // a thread's ~9 elements are independent: unrolled, their loads are in flight together
 #pragma unroll 5
   for (int e = tid; e < E; e += kFirThreads) {
@@ -281,17 +332,21 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
     sre[fir_pad(e)] = d.x;
     sim[fir_pad(e)] = d.y;
   }
-  for (int k = tid; k < H; k += kFirThreads) {
+  for (int k = tid; k <= H; k += kFirThreads) {
     const float2 c = (k < a.ntaps) ? taps[k] : make_float2(0.f, 0.f);
-    tre[k] = c.x;
-    tim[k] = c.y;
+    if (k < H) { tre[k] = c.x; tim[k] = c.y; }
+    if (k > 0) { tre_s[k - 1] = c.x; tim_s[k - 1] = c.y; }
   }
   __syncthreads();
 
   float2 acc[kW];
-  if (kind == kFirRealReal) fir_run<kFirRealReal>(sre, sim, tre, tim, nblk, H, tid, acc);
-  else if (kind == kFirRePart) fir_run<kFirRePart>(sre, sim, tre, tim, nblk, H, tid, acc);
-  else fir_run<kFirCplx>(sre, sim, tre, tim, nblk, H, tid, acc);
+  if (CPLX) {
+    fir_run<kFirCplx>(sre, sim, tre, tim, tre_s, tim_s, nblk, H, tid, acc);
+  } else {
+    const bool real_det = (det == kDetAbs || det == kDetFm || det == kDetPll);
+    if (real_det && a.taps_real[r]) fir_run<kFirRealReal>(sre, sim, tre, tim, tre_s, tim_s, nblk, H, tid, acc);
+    else fir_run<kFirRePart>(sre, sim, tre, tim, tre_s, tim_s, nblk, H, tid, acc);
+  }
 
   const int ib = i0 + kW * tid;
   float mag = 0.f;
@@ -300,14 +355,28 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
     const int last = (ib + kW - 1 < a.n_out) ? ib + kW - 1 : a.n_out - 1;
     blk_lo = block_of(a, r, ib);
     blk_hi = block_of(a, r, last);
+    // the lane's 8 outputs are 32 (64) contiguous bytes: 16-byte stores, not eight strided dwords
+    if (ib + kW <= a.n_out) {
+      if (CPLX) {
+        float4* o = reinterpret_cast<float4*>(a.a[r] + ib);
+#pragma unroll
+        for (int j = 0; j < kW; j += 2) o[j / 2] = make_float4(acc[j].x, acc[j].y, acc[j + 1].x, acc[j + 1].y);
+      } else {
+        float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.a[r]) + ib);
+        o[0] = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
+        o[1] = make_float4(acc[4].x, acc[5].x, acc[6].x, acc[7].x);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < kW; ++j)
       if (ib + j < a.n_out) {
-        if (a.out_complex[r]) a.a[r][ib + j] = acc[j];
-        else reinterpret_cast<float*>(a.a[r])[ib + j] = acc[j].x;     // real outputs: 4 bytes each
-        const float m = a.out_complex[r] ? sqrtf(acc[j].x * acc[j].x + acc[j].y * acc[j].y) : fabsf(acc[j].x);
+        if (ib + kW > a.n_out) {
+          if (CPLX) a.a[r][ib + j] = acc[j];
+          else reinterpret_cast<float*>(a.a[r])[ib + j] = acc[j].x;   // real outputs: 4 bytes each
+        }
+        const float m = CPLX ? sqrtf(acc[j].x * acc[j].x + acc[j].y * acc[j].y) : fabsf(acc[j].x);
         if (blk_lo == blk_hi) mag = fmaxf(mag, m);
-        else atomicMax(a.blkpeak + (size_t)r * a.nchunks + block_of(a, r, ib + j), __float_as_uint(m));
+        else atomicMax(a.blkpeak + ((size_t)r * a.nchunks + block_of(a, r, ib + j)) * kBlkStride, __float_as_uint(m));
       }
   }
   // NFM noise squelch (sigs/squelch.m:92-145): block sum of |2nd difference| of the
@@ -327,8 +396,8 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
         if (blk_lo == blk_hi) { nz += hp; cnt += 1u; }
         else {
           const uint32_t bj = block_of(a, r, ib + j);
-          atomicAdd(a.blknoise + (size_t)r * a.nchunks + bj, hp);
-          atomicAdd(a.blkcnt + (size_t)r * a.nchunks + bj, 1u);
+          atomicAdd(a.blknoise + ((size_t)r * a.nchunks + bj) * kBlkStride, hp);
+          atomicAdd(a.blkcnt + ((size_t)r * a.nchunks + bj) * kBlkStride, 1u);
         }
       }
   }
@@ -340,22 +409,22 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((tid & 63) == 0 && b0 != 0xFFFFFFFFu)
-      atomicMax(a.blkpeak + (size_t)r * a.nchunks + b0, __float_as_uint(m));
+      atomicMax(a.blkpeak + ((size_t)r * a.nchunks + b0) * kBlkStride, __float_as_uint(m));
     if (squelch) {
       float sn = nz;
       unsigned sc = cnt;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { sn += __shfl_xor(sn, o); sc += __shfl_xor(sc, o); }
       if ((tid & 63) == 0 && b0 != 0xFFFFFFFFu) {
-        atomicAdd(a.blknoise + (size_t)r * a.nchunks + b0, sn);
-        atomicAdd(a.blkcnt + (size_t)r * a.nchunks + b0, sc);
+        atomicAdd(a.blknoise + ((size_t)r * a.nchunks + b0) * kBlkStride, sn);
+        atomicAdd(a.blkcnt + ((size_t)r * a.nchunks + b0) * kBlkStride, sc);
       }
     }
   } else if (blk_lo != 0xFFFFFFFFu && blk_lo == blk_hi) {
-    atomicMax(a.blkpeak + (size_t)r * a.nchunks + blk_lo, __float_as_uint(mag));
+    atomicMax(a.blkpeak + ((size_t)r * a.nchunks + blk_lo) * kBlkStride, __float_as_uint(mag));
     if (squelch) {
-      atomicAdd(a.blknoise + (size_t)r * a.nchunks + blk_lo, nz);
-      atomicAdd(a.blkcnt + (size_t)r * a.nchunks + blk_lo, cnt);
+      atomicAdd(a.blknoise + ((size_t)r * a.nchunks + blk_lo) * kBlkStride, nz);
+      atomicAdd(a.blkcnt + ((size_t)r * a.nchunks + blk_lo) * kBlkStride, cnt);
     }
   }
 }
@@ -379,7 +448,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
   float* sS = ev + a.nchunks;          // [256] start state each segment used, [256] end state it reached
   float* sE = sS + 256;
   for (int c = tid; c < a.nchunks; c += 256)
-    pk[c] = __uint_as_float(a.blkpeak[(size_t)r * a.nchunks + c]);
+    pk[c] = __uint_as_float(a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride]);
   __syncthreads();
   const RxDevState st = a.state[r];
   // The recursion is serial, but an attack (peak > env) overwrites the state and a decay forgets it
@@ -419,7 +488,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
     const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(pk[c], 1e-12f)), 1.0e4f) : 1.f;
     a.gain[(size_t)r * a.nchunks + c] = g;
     // the raw block peaks are consumed: leave them zeroed for the next call
-    a.blkpeak[(size_t)r * a.nchunks + c] = 0u;
+    a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] = 0u;
   }
   if (a.sq_thresh[r] > 0.f) {
     __syncthreads();
@@ -429,15 +498,15 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
       int open = st.sq_open;
       for (int c = 0; c < a.nchunks; ++c) {
         const size_t k = (size_t)r * a.nchunks + c;
-        const unsigned n = a.blkcnt[k];
+        const unsigned n = a.blkcnt[k * kBlkStride];
         if (n > 0u) {
-          const float noise = __fdiv_rn(a.blknoise[k], (float)n);
+          const float noise = __fdiv_rn(a.blknoise[k * kBlkStride], (float)n);
           lvl = __fadd_rn(lvl, __fmul_rn(0.64f, __fsub_rn(noise, lvl)));
           open = (lvl <= a.sq_thresh[r]) ? 1 : 0;
           if (!open) a.gain[k] = 0.f;
         }
-        a.blknoise[k] = 0.f;
-        a.blkcnt[k] = 0u;
+        a.blknoise[k * kBlkStride] = 0.f;
+        a.blkcnt[k * kBlkStride] = 0u;
       }
       a.state[r].sq_level = lvl;
       a.state[r].sq_open = open;
@@ -742,10 +811,18 @@ int launch_demod_fir(const Stage2Args& a, hipStream_t st) {
   if (a.n_out <= 0) return PYSDR_OK;
   const int H = fir_taps_padded(a.ntaps);
   const int EP = (fir_pad(kFirOut + H + 12) + 3) & ~3;
-  const size_t lds = (size_t)(2 * EP + 2 * H) * sizeof(float);
-  dim3 grid((a.n_out + kFirOut - 1) / kFirOut, a.nrx);
-  hipLaunchKernelGGL(demod_fir_kernel, grid, dim3(kFirThreads), lds, st, a);
-  PYSDR_HIP_CHECK(hipGetLastError());
+  const size_t lds = (size_t)(2 * EP + 4 * H) * sizeof(float);
+  for (int cplx = 0; cplx < 2; ++cplx) {
+    Stage2Args b = a;
+    int n = 0;
+    for (int r = 0; r < a.nrx; ++r)
+      if ((a.out_complex[r] ? 1 : 0) == cplx) b.fir_rx[n++] = r;
+    if (n == 0) continue;
+    dim3 grid((a.n_out + kFirOut - 1) / kFirOut, n);
+    if (cplx) hipLaunchKernelGGL(demod_fir_kernel<true>, grid, dim3(kFirThreads), lds, st, b);
+    else hipLaunchKernelGGL(demod_fir_kernel<false>, grid, dim3(kFirThreads), lds, st, b);
+    PYSDR_HIP_CHECK(hipGetLastError());
+  }
   return PYSDR_OK;
 }
 

@@ -20,6 +20,9 @@ __global__ void k(float* out, int iters, float a, float b) {
       if (OP == 3) asm volatile("v_add_f32 %0, %1, %0" : "+v"(x[i]) : "v"(a));
       if (OP == 4) asm volatile("v_sin_f32 %0, %0" : "+v"(x[i]));
       if (OP == 5) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(p[i]) : "v"(pa));
+      if (OP == 6) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(p[i]) : "v"(pa), "v"(pb));
+      if (OP == 7) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p[i]) : "v"(pa), "v"(pb));
+      if (OP == 8) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(p[i]) : "v"(pa), "v"(pb));
     }
   }
   float s = 0;
@@ -46,11 +49,13 @@ double run(int waves_per_simd, float* d) {
 }
 int main() {
   float* d; hipMalloc(&d, 256 * 2048 * 4);
-  const char* names[6] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_add_f32", "v_sin_f32", "v_pk_mul_f32"};
+  const char* names[9] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_add_f32", "v_sin_f32", "v_pk_mul_f32",
+                          "v_pk_fma_f32(op_sel swap src1)", "v_pk_fma_f32(op_sel_hi bcast src0)", "v_pk_fma_f32(neg)"};
   for (int w : {1, 2, 3, 4}) {
-    double r[6] = {run<0>(w, d), run<1>(w, d), run<2>(w, d), run<3>(w, d), run<4>(w, d), run<5>(w, d)};
+    double r[9] = {run<0>(w, d), run<1>(w, d), run<2>(w, d), run<3>(w, d), run<4>(w, d), run<5>(w, d),
+                   run<6>(w, d), run<7>(w, d), run<8>(w, d)};
     printf("waves/SIMD %d:", w);
-    for (int i = 0; i < 6; ++i) printf("  %s %.2f", names[i], r[i]);
+    for (int i = 0; i < 9; ++i) printf("  %s %.2f", names[i], r[i]);
     printf("   (cycles @2.4 GHz per wave-instruction per SIMD)\n");
   }
   return 0;
