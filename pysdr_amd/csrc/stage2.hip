@@ -447,8 +447,20 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
   float* ev = agc_lds + a.nchunks;     // [nchunks] envelopes
   float* sS = ev + a.nchunks;          // [256] start state each segment used, [256] end state it reached
   float* sE = sS + 256;
-  for (int c = tid; c < a.nchunks; c += 256)
-    pk[c] = __uint_as_float(a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride]);
+  // eight loads in flight per thread (a rolled loop waits for each 256-byte-strided load in turn)
+  for (int c0 = 0; c0 < a.nchunks; c0 += 8 * 256) {
+    unsigned v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u * 256 + tid;
+      v[u] = (c < a.nchunks) ? a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u * 256 + tid;
+      if (c < a.nchunks) pk[c] = __uint_as_float(v[u]);
+    }
+  }
   __syncthreads();
   const RxDevState st = a.state[r];
   // The recursion is serial, but an attack (peak > env) overwrites the state and a decay forgets it
@@ -456,7 +468,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
   // serial walk's value BIT FOR BIT in practice; lane 0 then checks that every segment's start
   // equals its predecessor's end and redoes serially what does not (so the result is the serial
   // one by construction -- the batch / chunked identity tests compare bits).
-  constexpr int kWarm = 256;
+  constexpr int kWarm = 176;             // 0.9^176 = 9e-9 < 2^-24: a decaying start value is gone from a float
   const int T = (a.nchunks + 255) / 256 < 16 ? 16 : (a.nchunks + 255) / 256;
   const int K = (a.nchunks + T - 1) / T;
   if (tid < K) {
@@ -470,7 +482,9 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
     sE[tid] = env;
   }
   __syncthreads();
-  if (tid == 0) {
+  // (all segments checked at once; the serial walk below only runs when one of them missed)
+  const bool miss = tid > 0 && tid < K && __float_as_uint(sE[tid - 1]) != __float_as_uint(sS[tid]);
+  if (__syncthreads_or(miss) && tid == 0) {
     for (int k = 1; k < K; ++k) {
       if (__float_as_uint(sE[k - 1]) == __float_as_uint(sS[k])) continue;
       float env = sE[k - 1];
@@ -524,23 +538,54 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
 }
 
 // ---- apply the block gain, emit rx.am (real, or complex in IQ mode)
+// Four consecutive outputs per thread: one pair of block_of() (two 32-bit divisions each) per four
+// outputs instead of per output -- at one output per thread the kernel was bound by those divisions
+// (21 us for 8.4 M outputs), not by its 68 MB of traffic -- and 16-byte accesses.
 __global__ __launch_bounds__(256) void apply_kernel(const Stage2Args a) {
   const int r = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= a.n_out) return;
-  const float g = a.gain[(size_t)r * a.nchunks + block_of(a, r, i)];
-  if (!a.out_complex[r] && !a.matrix[r]) {
-    // real outputs were stored densely by the FIR kernel; WFM mono takes the real part of a complex one
-    a.am[r][i] = (a.fir_complex[r] ? a.a[r][i].x : reinterpret_cast<const float*>(a.a[r])[i]) * g;
+  const int n = (a.n_out - i < 4) ? a.n_out - i : 4;
+  const float* gr = a.gain + (size_t)r * a.nchunks;
+  const uint32_t b0 = block_of(a, r, i), b3 = block_of(a, r, i + n - 1);
+  float g[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) g[j] = gr[b0];
+  if (b3 != b0) {
+#pragma unroll
+    for (int j = 1; j < 4; ++j) if (j < n) g[j] = gr[block_of(a, r, i + j)];
+  }
+  const bool real_in = !a.fir_complex[r];               // layout of a.a as the FIR kernel stored it
+  const bool cplx_out = a.out_complex[r] || a.matrix[r];
+  if (n == 4) {
+    if (real_in) {
+      // real outputs were stored densely by the FIR kernel
+      const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.a[r]) + i);
+      *reinterpret_cast<float4*>(a.am[r] + i) = make_float4(v.x * g[0], v.y * g[1], v.z * g[2], v.w * g[3]);
+      return;
+    }
+    const float4 u0 = *reinterpret_cast<const float4*>(a.a[r] + i), u1 = *reinterpret_cast<const float4*>(a.a[r] + i + 2);
+    const float2 v[4] = {{u0.x, u0.y}, {u0.z, u0.w}, {u1.x, u1.y}, {u1.z, u1.w}};
+    if (!cplx_out) {                                      // WFM mono: the real part of a complex pipeline
+      *reinterpret_cast<float4*>(a.am[r] + i) = make_float4(v[0].x * g[0], v[1].x * g[1], v[2].x * g[2], v[3].x * g[3]);
+      return;
+    }
+    float2 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = a.matrix[r] ? make_float2((v[j].x + v[j].y) * g[j], (v[j].x - v[j].y) * g[j])
+                         : make_float2(v[j].x * g[j], v[j].y * g[j]);
+    float4* d = reinterpret_cast<float4*>(reinterpret_cast<float2*>(a.am[r]) + i);
+    d[0] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+    d[1] = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
     return;
   }
-  const float2 v = a.a[r][i];
-  if (a.matrix[r]) {
-    reinterpret_cast<float2*>(a.am[r])[i] = make_float2((v.x + v.y) * g, (v.x - v.y) * g);
-  } else if (a.out_complex[r]) {
-    reinterpret_cast<float2*>(a.am[r])[i] = make_float2(v.x * g, v.y * g);
-  } else {
-    a.am[r][i] = v.x * g;
+  for (int j = 0; j < n; ++j) {                          // the ragged end of the call
+    if (real_in) { a.am[r][i + j] = reinterpret_cast<const float*>(a.a[r])[i + j] * g[j]; continue; }
+    const float2 v = a.a[r][i + j];
+    if (!cplx_out) a.am[r][i + j] = v.x * g[j];
+    else reinterpret_cast<float2*>(a.am[r])[i + j] =
+        a.matrix[r] ? make_float2((v.x + v.y) * g[j], (v.x - v.y) * g[j]) : make_float2(v.x * g[j], v.y * g[j]);
   }
 }
 
@@ -834,7 +879,7 @@ int launch_agc_scan(const Stage2Args& a, hipStream_t st) {
 
 int launch_apply(const Stage2Args& a, hipStream_t st) {
   if (a.n_out <= 0) return PYSDR_OK;
-  dim3 grid((a.n_out + 255) / 256, a.nrx);
+  dim3 grid((a.n_out + 1023) / 1024, a.nrx);
   hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
