@@ -349,9 +349,15 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   }
 
   const int ib = i0 + kW * tid;
-  float mag = 0.f;
+  // Block peaks (and the squelch's noise sums): a wave's 512 outputs lie in its first block wb0
+  // or the next one, so every lane sorts its values into those two slots, the wave reduces both
+  // and lane 0 issues at most two atomics per quantity.  (One atomic per LANE whenever a wave
+  // held a block boundary -- every other wave -- was 0.5 M atomics per call and 20 us.)  Blocks
+  // shorter than that (tiny chunk_len) fall through to per-element atomics.
+  const bool squelch = (a.sq_thresh[r] > 0.f) && (det == kDetFm);
+  const bool valid = ib < a.n_out;
   uint32_t blk_lo = 0xFFFFFFFFu, blk_hi = 0xFFFFFFFFu;
-  if (ib < a.n_out) {
+  if (valid) {
     const int last = (ib + kW - 1 < a.n_out) ? ib + kW - 1 : a.n_out - 1;
     blk_lo = block_of(a, r, ib);
     blk_hi = block_of(a, r, last);
@@ -367,6 +373,11 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
         o[1] = make_float4(acc[4].x, acc[5].x, acc[6].x, acc[7].x);
       }
     }
+  }
+  const uint32_t wb0 = __shfl(blk_lo, 0);                 // lanes ascend: lane 0 invalid = wave invalid
+  float m0 = 0.f, m1 = 0.f, nz0 = 0.f, nz1 = 0.f;
+  unsigned cnt0 = 0u, cnt1 = 0u;
+  if (valid) {
 #pragma unroll
     for (int j = 0; j < kW; ++j)
       if (ib + j < a.n_out) {
@@ -375,56 +386,40 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
           else reinterpret_cast<float*>(a.a[r])[ib + j] = acc[j].x;   // real outputs: 4 bytes each
         }
         const float m = CPLX ? sqrtf(acc[j].x * acc[j].x + acc[j].y * acc[j].y) : fabsf(acc[j].x);
-        if (blk_lo == blk_hi) mag = fmaxf(mag, m);
-        else atomicMax(a.blkpeak + ((size_t)r * a.nchunks + block_of(a, r, ib + j)) * kBlkStride, __float_as_uint(m));
-      }
-  }
-  // NFM noise squelch (sigs/squelch.m:92-145): block sum of |2nd difference| of the
-  // detector output -- out-of-band noise rises when the carrier goes away
-  const bool squelch = (a.sq_thresh[r] > 0.f) && (det == kDetFm);
-  float nz = 0.f;
-  unsigned cnt = 0u;
-  if (squelch && ib < a.n_out) {
-#pragma unroll
-    for (int j = 0; j < kW; ++j)
-      if (ib + j < a.n_out) {
-        const int e = kW * tid + H + 3 + j;               // S element of output ib+j
-        const float d0 = sre[fir_pad(e)];
-        const float d1 = sre[fir_pad(e - 1)];
-        const float d2 = sre[fir_pad(e - 2)];
-        const float hp = fabsf(d0 - 2.f * d1 + d2);
-        if (blk_lo == blk_hi) { nz += hp; cnt += 1u; }
+        const uint32_t bj = (blk_lo == blk_hi) ? blk_lo : block_of(a, r, ib + j);
+        const uint32_t slot = bj - wb0;
+        float hp = 0.f;
+        if (squelch) {
+          // NFM noise squelch (sigs/squelch.m:92-145): block sum of |2nd difference| of the
+          // detector output -- out-of-band noise rises when the carrier goes away
+          const int e = kW * tid + H + 3 + j;             // S element of output ib+j
+          hp = fabsf(sre[fir_pad(e)] - 2.f * sre[fir_pad(e - 1)] + sre[fir_pad(e - 2)]);
+        }
+        if (slot == 0u) { m0 = fmaxf(m0, m); nz0 += hp; cnt0 += 1u; }
+        else if (slot == 1u) { m1 = fmaxf(m1, m); nz1 += hp; cnt1 += 1u; }
         else {
-          const uint32_t bj = block_of(a, r, ib + j);
-          atomicAdd(a.blknoise + ((size_t)r * a.nchunks + bj) * kBlkStride, hp);
-          atomicAdd(a.blkcnt + ((size_t)r * a.nchunks + bj) * kBlkStride, 1u);
+          const size_t k = ((size_t)r * a.nchunks + bj) * kBlkStride;
+          atomicMax(a.blkpeak + k, __float_as_uint(m));
+          if (squelch) { atomicAdd(a.blknoise + k, hp); atomicAdd(a.blkcnt + k, 1u); }
         }
       }
   }
-  // block peak: one atomic per wave when the whole wave sits inside one block
-  const uint32_t b0 = __shfl(blk_lo, 0);
-  const bool uniform = __all((blk_lo == b0 && blk_hi == b0) || blk_lo == 0xFFFFFFFFu);
-  if (uniform) {
-    float m = mag;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((tid & 63) == 0 && b0 != 0xFFFFFFFFu)
-      atomicMax(a.blkpeak + ((size_t)r * a.nchunks + b0) * kBlkStride, __float_as_uint(m));
-    if (squelch) {
-      float sn = nz;
-      unsigned sc = cnt;
+  for (int o = 32; o > 0; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
+  if (squelch) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { sn += __shfl_xor(sn, o); sc += __shfl_xor(sc, o); }
-      if ((tid & 63) == 0 && b0 != 0xFFFFFFFFu) {
-        atomicAdd(a.blknoise + ((size_t)r * a.nchunks + b0) * kBlkStride, sn);
-        atomicAdd(a.blkcnt + ((size_t)r * a.nchunks + b0) * kBlkStride, sc);
-      }
+    for (int o = 32; o > 0; o >>= 1) {
+      nz0 += __shfl_xor(nz0, o); nz1 += __shfl_xor(nz1, o);
+      cnt0 += __shfl_xor(cnt0, o); cnt1 += __shfl_xor(cnt1, o);
     }
-  } else if (blk_lo != 0xFFFFFFFFu && blk_lo == blk_hi) {
-    atomicMax(a.blkpeak + ((size_t)r * a.nchunks + blk_lo) * kBlkStride, __float_as_uint(mag));
+  }
+  if ((tid & 63) == 0 && wb0 != 0xFFFFFFFFu) {
+    const size_t k0 = ((size_t)r * a.nchunks + wb0) * kBlkStride, k1 = k0 + kBlkStride;
+    if (m0 > 0.f) atomicMax(a.blkpeak + k0, __float_as_uint(m0));
+    if (m1 > 0.f) atomicMax(a.blkpeak + k1, __float_as_uint(m1));
     if (squelch) {
-      atomicAdd(a.blknoise + ((size_t)r * a.nchunks + blk_lo) * kBlkStride, nz);
-      atomicAdd(a.blkcnt + ((size_t)r * a.nchunks + blk_lo) * kBlkStride, cnt);
+      if (cnt0) { atomicAdd(a.blknoise + k0, nz0); atomicAdd(a.blkcnt + k0, cnt0); }
+      if (cnt1) { atomicAdd(a.blknoise + k1, nz1); atomicAdd(a.blkcnt + k1, cnt1); }
     }
   }
 }
