@@ -907,7 +907,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     // the call's initial state free-running, 60-270 after 32768 samples = 17.5 tau (one segment in
     // 200 beyond the 512-word tolerance: 20 tau); from the previous call's MEAN increment (the loop
     // follows a crystal, so its phase is a straight line plus a bounded wobble) 54 after 13 tau
-    w.pll = plan_pll(n1, fs1, kWfmPllBwHz, 20.0, 13.0, 2048, c->pll_kmax > 0 ? std::min(c->pll_kmax, 1024) : 1024, c->d_pllseg);
+    w.pll = plan_pll(n1, fs1, kWfmPllBwHz, 20.0, 13.0, 2048, c->pll_kmax > 0 ? std::min(c->pll_kmax, 2048) : 2048, c->d_pllseg);   // two waves per SIMD: a lone wave issues one dependent VALU op per 12 cycles
     rc = launch_wfm(w, c->stream);
     if (rc) return rc;
     const uint32_t zero = 0u;

@@ -438,22 +438,25 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
   extern __shared__ __attribute__((aligned(16))) float agc_lds[];
   const int r = blockIdx.x;
   const int tid = threadIdx.x;
+  // broadcast FM has no AGC blocks: the whole call is block 0 (walking 2047 empty blocks after it
+  // let the envelope decay through hundreds of segment joins that never meet: 140 us)
+  const int nch = a.single_block[r] ? (a.nchunks > 0 ? 1 : 0) : a.nchunks;
   float* pk = agc_lds;                 // [nchunks] block peaks
   float* ev = agc_lds + a.nchunks;     // [nchunks] envelopes
   float* sS = ev + a.nchunks;          // [256] start state each segment used, [256] end state it reached
   float* sE = sS + 256;
   // eight loads in flight per thread (a rolled loop waits for each 256-byte-strided load in turn)
-  for (int c0 = 0; c0 < a.nchunks; c0 += 8 * 256) {
+  for (int c0 = 0; c0 < nch; c0 += 8 * 256) {
     unsigned v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int c = c0 + u * 256 + tid;
-      v[u] = (c < a.nchunks) ? a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] : 0u;
+      v[u] = (c < nch) ? a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int c = c0 + u * 256 + tid;
-      if (c < a.nchunks) pk[c] = __uint_as_float(v[u]);
+      if (c < nch) pk[c] = __uint_as_float(v[u]);
     }
   }
   __syncthreads();
@@ -464,10 +467,10 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
   // equals its predecessor's end and redoes serially what does not (so the result is the serial
   // one by construction -- the batch / chunked identity tests compare bits).
   constexpr int kWarm = 176;             // 0.9^176 = 9e-9 < 2^-24: a decaying start value is gone from a float
-  const int T = (a.nchunks + 255) / 256 < 16 ? 16 : (a.nchunks + 255) / 256;
-  const int K = (a.nchunks + T - 1) / T;
+  const int T = (nch + 255) / 256 < 16 ? 16 : (nch + 255) / 256;
+  const int K = (nch + T - 1) / T;
   if (tid < K) {
-    const int s0 = tid * T, s1 = (s0 + T < a.nchunks) ? s0 + T : a.nchunks;
+    const int s0 = tid * T, s1 = (s0 + T < nch) ? s0 + T : nch;
     int wb = s0 - kWarm;
     float env = 0.f;
     if (tid == 0 || wb <= 0) { wb = 0; env = st.env; }
@@ -483,17 +486,17 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
     for (int k = 1; k < K; ++k) {
       if (__float_as_uint(sE[k - 1]) == __float_as_uint(sS[k])) continue;
       float env = sE[k - 1];
-      const int s0 = k * T, s1 = (s0 + T < a.nchunks) ? s0 + T : a.nchunks;
+      const int s0 = k * T, s1 = (s0 + T < nch) ? s0 + T : nch;
       for (int c = s0; c < s1; ++c) { env = agc_env_step(env, pk[c]); ev[c] = env; }
       sE[k] = env;
       sS[k] = sE[k - 1];
     }
   }
   __syncthreads();
-  const float last_peak = a.nchunks > 0 ? pk[a.nchunks - 1] : st.maxbuf;
-  for (int c = tid; c < a.nchunks; c += 256) pk[c] = ev[c];      // below: pk[] holds the envelopes
+  const float last_peak = nch > 0 ? pk[nch - 1] : st.maxbuf;
+  for (int c = tid; c < nch; c += 256) pk[c] = ev[c];      // below: pk[] holds the envelopes
   __syncthreads();
-  for (int c = tid; c < a.nchunks; c += 256) {
+  for (int c = tid; c < nch; c += 256) {
     const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(pk[c], 1e-12f)), 1.0e4f) : 1.f;
     a.gain[(size_t)r * a.nchunks + c] = g;
     // the raw block peaks are consumed: leave them zeroed for the next call
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
       // serial one-pole smoothing of the block noise, gate the gain (0 = squelched)
       float lvl = st.sq_level;
       int open = st.sq_open;
-      for (int c = 0; c < a.nchunks; ++c) {
+      for (int c = 0; c < nch; ++c) {
         const size_t k = (size_t)r * a.nchunks + c;
         const unsigned n = a.blkcnt[k * kBlkStride];
         if (n > 0u) {
@@ -521,8 +524,8 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
       a.state[r].sq_open = open;
     }
   }
-  if (tid == 0 && a.nchunks > 0) {
-    const float env = pk[a.nchunks - 1];
+  if (tid == 0 && nch > 0) {
+    const float env = pk[nch - 1];
     const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(env, 1e-12f)), 1.0e4f) : 1.f;
     // field-wise: the squelch block above owns sq_level / sq_open
     a.state[r].env = env;
