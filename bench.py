@@ -307,10 +307,12 @@ def measured_traffic(args, nrx, B, kernel_prefix, sources):
     """HBM bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950
     correction of MI355X_MICROARCH.md), or None: valid only for the profiled configuration AND only
     while the kernel sources still hash to what was profiled (the profile file carries the hashes)."""
-    if args.workload != "c3" or B != 2048 or nrx != 4 or args.no_psd:
+    if B != DEFAULT_CHUNKS[args.workload] or args.nrx:
         return None, None
     for tag in ("r02", "r01"):
-        p = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        # C3 (the demod kernels are the same with and without the PSD) or the workload's own passes
+        name = f"{tag}_pmc_traffic.json" if args.workload == "c3" else f"{tag}_{args.workload}_pmc_traffic.json"
+        p = os.path.join(ROOT, "profiles", name)
         try:
             doc = json.load(open(p))
         except Exception:
@@ -318,10 +320,10 @@ def measured_traffic(args, nrx, B, kernel_prefix, sources):
         rows = doc["kernels"] if isinstance(doc, dict) else doc
         stamp = doc.get("source_sha256", {}) if isinstance(doc, dict) else {}
         if any(stamp.get(s) != source_sha(s) for s in sources):
-            return None, f"profiles/{tag}_pmc_traffic.json is stale: {', '.join(sources)} changed since it was collected"
+            return None, f"profiles/{name} is stale: {', '.join(sources)} changed since it was collected"
         tot = sum(r["hbm_bytes_per_launch"] for r in rows if r["kernel"].startswith(kernel_prefix))
         if tot > 0:
-            return tot, (f"profiles/{tag}_pmc_traffic.json (git {doc.get('git_head', '?') if isinstance(doc, dict) else '?'}): "
+            return tot, (f"profiles/{name} (git {doc.get('git_head', '?') if isinstance(doc, dict) else '?'}): "
                          "2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of this same command")
     return None, None
 
