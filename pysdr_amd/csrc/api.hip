@@ -127,8 +127,6 @@ struct pysdr_ctx {
   size_t stage_cap = 0;
   unsigned* d_peak = nullptr;    // [max_chunks]
   unsigned* d_peak_scratch = nullptr;  // [1] sink for decimators whose raw peak is not wanted
-  unsigned* d_ticket = nullptr;        // [1] run counter of the front-end kernel (dynamic tile runs)
-  int mixdec_dyn = 0;
   unsigned* d_blkpeak = nullptr; // [MAX_RX][max_chunks]
   float* d_gain = nullptr;       // [MAX_RX][max_chunks]
   float* d_blknoise = nullptr;   // [MAX_RX][max_chunks]
@@ -350,12 +348,9 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   a.chunk_len = peak ? (uint32_t)chunk_len : (uint32_t)std::max<size_t>(n, 1);
   a.magic_chunk = (a.chunk_len == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned long long)a.chunk_len) + 1u;
   a.dbg = c->dbg_flags;
-  a.dyn = c->mixdec_dyn;
-  a.ticket = c->d_ticket;
-  a.nruns = (a.ntiles + a.yflush - 1) / a.yflush;
   int rc = launch_mixdec(a, c->threads, c->num_cus * wgs, c->stream);
   if (rc) return rc;
-  rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, c->d_ticket, c->stream);
+  rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, c->stream);
   if (rc) return rc;
   d.hist_cur ^= 1;
   d.s_abs = s1;
@@ -537,7 +532,6 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   // tuning / ablation switches (bench.py and DESIGN.md 4.1 use them; all default to off)
   { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) c->wgs_per_cu = atoi(e); }
   { const char* e = getenv("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0) c->yflush_cap = atoi(e); }
-  { const char* e = getenv("PYSDR_MIXDEC_DYN"); if (e && atoi(e) > 0) c->mixdec_dyn = 1; }
 #ifdef PYSDR_DIAG
   // work-skipping ablation switches exist only in a diagnostic build (python -m pysdr_amd.build --diag)
   { const char* e = getenv("PYSDR_DEBUG_FLAGS"); c->dbg_flags = e ? atoi(e) : 0; }
@@ -560,8 +554,6 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   if (rc) { pysdr_destroy(c); return rc; }
   CK(hipMalloc(&c->d_peak, (size_t)cfg->max_chunks * sizeof(unsigned)));
   CK(hipMalloc(&c->d_peak_scratch, 64 * sizeof(unsigned)));
-  CK(hipMalloc(&c->d_ticket, 64 * sizeof(unsigned)));
-  CK(hipMemsetAsync(c->d_ticket, 0, 64 * sizeof(unsigned), c->stream));
   CK(hipMalloc(&c->d_blkpeak, (size_t)PYSDR_MAX_RX * cfg->max_chunks * kBlkStride * sizeof(unsigned)));
   CK(hipMemsetAsync(c->d_blkpeak, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * kBlkStride * sizeof(unsigned), c->stream));
   CK(hipMalloc(&c->d_gain, (size_t)PYSDR_MAX_RX * cfg->max_chunks * sizeof(float)));
@@ -601,7 +593,6 @@ void pysdr_destroy(pysdr_ctx* c) {
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->d_peak) (void)hipFree(c->d_peak);
   if (c->d_peak_scratch) (void)hipFree(c->d_peak_scratch);
-  if (c->d_ticket) (void)hipFree(c->d_ticket);
   if (c->d_blkpeak) (void)hipFree(c->d_blkpeak);
   if (c->d_gain) (void)hipFree(c->d_gain);
   if (c->d_blknoise) (void)hipFree(c->d_blknoise);

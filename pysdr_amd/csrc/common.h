@@ -64,11 +64,6 @@ struct MixDecArgs {
   int dq_tile, dr_tile;   // divmod(tile_out*down, up)
   int dq_last, dr_last;   // divmod((tile_out-1)*down, up)
   int yflush, ycap;       // LDS output stage: flushed every yflush tiles; ycap = yflush*tile_out per RX
-  // tiles are dealt out in RUNS of yflush consecutive ones: run blockIdx.x first, then whatever the
-  // ticket counter gives (it starts at gridDim.x; hist_roll_kernel zeroes it after the launch)
-  unsigned* ticket;
-  int nruns;
-  int dyn;                // 0: every workgroup walks its fixed contiguous share of the tiles (no ticket)
 };
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st);
 size_t mixdec_lds_bytes(const MixDecArgs& a);
@@ -153,7 +148,7 @@ struct EpilogueArgs {
 int launch_epilogue(const EpilogueArgs& a, hipStream_t st);
 // new history = last hist_len samples of [old history | x[0..n)]
 int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len,
-                     uint32_t n_total, unsigned* ticket, hipStream_t st);
+                     uint32_t n_total, hipStream_t st);
 
 // ---- broadcast FM (WFM / WFM2) at the IF rate fs1 (stage2.hip) -------------------------
 struct WfmArgs {

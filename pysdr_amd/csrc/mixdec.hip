@@ -286,25 +286,13 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   const int lane = tid & 63;
   const int g = lane >> 4, s = lane & 15;       // DPP row, lane within the row
 
-  // Tiles of this workgroup.  Static: one contiguous share of the call.  Dynamic (a.dyn, for a
-  // launch that shares the CUs with another kernel and whose workgroups therefore start at
-  // different times): runs of yflush consecutive tiles, run blockIdx.x first, then whatever the
-  // ticket counter hands out; the ticket of the next run is drawn at the first tile of a run and
-  // its first tile is prefetched at the last, so the DMA pipeline never drains between runs.
+  // contiguous run of tiles for this workgroup
   const int ng = gridDim.x;
-  int& s_next = *reinterpret_cast<int*>(ys + R * a.ycap);   // (dynamic LDS: a static word would put the kernel over 160 KiB)
-  int t_begin, t_end;
-  if (a.dyn) {
-    if ((int)blockIdx.x >= a.nruns) return;
-    t_begin = blockIdx.x * a.yflush;
-    t_end = (t_begin + a.yflush < a.ntiles) ? t_begin + a.yflush : a.ntiles;
-  } else {
-    const int base = a.ntiles / ng, rem = a.ntiles % ng;
-    const int wb = blockIdx.x;
-    t_begin = wb * base + (wb < rem ? wb : rem);
-    t_end = t_begin + base + (wb < rem ? 1 : 0);
-    if (t_begin >= t_end) return;
-  }
+  const int base = a.ntiles / ng, rem = a.ntiles % ng;
+  const int wb = blockIdx.x;
+  const int t_begin = wb * base + (wb < rem ? wb : rem);
+  const int t_end = t_begin + base + (wb < rem ? 1 : 0);
+  if (t_begin >= t_end) return;
 
   // ---- stage the LO-modulated taps once
   if (a.aligned16) {
@@ -354,29 +342,17 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   int pk_hi = (int)(a.chunk_len < a.n_total ? a.chunk_len : a.n_total) - 1;
   if (!PYSDR_DBG(a, 2)) stage_tile(a, cur, buf0, tid, nthr);
 
-  int par = 0;                   // which buffer the current tile is in
-  int next_run = a.nruns;        // dynamic: the run after the current one
-  for (;;) {
   for (int tb = t_begin; tb < t_end; ++tb) {
-    float2* const xs = par ? buf1 : buf0;
-    float2* const xn = par ? buf0 : buf1;
-    par ^= 1;
+    float2* const xs = ((tb - t_begin) & 1) ? buf1 : buf0;
+    float2* const xn = ((tb - t_begin) & 1) ? buf0 : buf1;
     // tile tb has landed; after the barrier everybody is also done reading the other
     // buffer (tile tb-1), so it can be refilled while we compute.
     dma_wait();
     __syncthreads();
-    if (a.dyn && tb == t_begin && tid == 0) s_next = (int)atomicAdd(a.ticket, 1u) + ng;
     Tile nxt = cur;
     if (tb + 1 < t_end) {
       nxt = (tb + 2 < a.ntiles) ? tile_advance(a, cur) : tile_geometry(a, tb + 1);
       if (!PYSDR_DBG(a, 2)) stage_tile(a, nxt, xn, tid, nthr);
-    } else if (a.dyn) {
-      if (t_end - t_begin == 1) __syncthreads();        // a one-tile run: the ticket was drawn just above
-      next_run = s_next;
-      if (next_run < a.nruns) {
-        nxt = tile_geometry(a, next_run * a.yflush);
-        if (!PYSDR_DBG(a, 2)) stage_tile(a, nxt, xn, tid, nthr);
-      }
     }
 
     // ---- raw-chunk peak |x|^2 over the samples this tile owns (rx.auto_mute input).
@@ -527,12 +503,6 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   }
   pk_run = wave_max63(pk_run);
   if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
-  if (!a.dyn || next_run >= a.nruns) break;
-  pk_run = 0.f;
-  t_begin = next_run * a.yflush;
-  t_end = (t_begin + a.yflush < a.ntiles) ? t_begin + a.yflush : a.ntiles;
-  i_base = cur.i_first;
-  }
 }
 
 template <int R, int NJ>
@@ -576,7 +546,7 @@ int launch_r(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t
 }  // namespace
 
 size_t mixdec_lds_bytes(const MixDecArgs& a) {
-  return (2 * (size_t)a.tile_cap + (size_t)a.nrx * a.up * a.kpad + (size_t)a.nrx * a.ycap + 2) * sizeof(float2);
+  return (2 * (size_t)a.tile_cap + (size_t)a.nrx * a.up * a.kpad + (size_t)a.nrx * a.ycap) * sizeof(float2);
 }
 
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st) {

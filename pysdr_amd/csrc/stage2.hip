@@ -605,8 +605,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const EpilogueArgs a) {
 __global__ __launch_bounds__(256) void hist_roll_kernel(const float2* __restrict__ x,
                                                         const float2* __restrict__ hist_old,
                                                         float2* __restrict__ hist_new, int hist_len,
-                                                        uint32_t n_total, unsigned* ticket) {
-  if (threadIdx.x == 0 && ticket) *ticket = 0u;          // the decimator's run counter, for its next launch
+                                                        uint32_t n_total) {
   for (int j = threadIdx.x; j < hist_len; j += 256) {
     const long long rel = (long long)n_total - hist_len + j;
     hist_new[j] = (rel >= 0) ? x[rel] : hist_old[hist_len + rel];
@@ -895,8 +894,8 @@ int launch_epilogue(const EpilogueArgs& a, hipStream_t st) {
 }
 
 int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len,
-                     uint32_t n_total, unsigned* ticket, hipStream_t st) {
-  hipLaunchKernelGGL(hist_roll_kernel, dim3(1), dim3(256), 0, st, x, hist_old, hist_new, hist_len, n_total, ticket);
+                     uint32_t n_total, hipStream_t st) {
+  hipLaunchKernelGGL(hist_roll_kernel, dim3(1), dim3(256), 0, st, x, hist_old, hist_new, hist_len, n_total);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }
