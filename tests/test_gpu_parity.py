@@ -224,6 +224,31 @@ def test_batch_equals_chunked_bit_exact():
     assert np.allclose(pk, want, rtol=1e-6)
 
 
+@pytest.mark.parametrize("L", [20000, 3000, 170666 // 4])
+def test_batch_of_short_chunks_equals_chunked_bit_exact(L):
+    """The same identity with chunks far shorter than the kernels' tiles: an AGC block is then 18 -
+    256 outputs, a wave of the AF FIR kernel (512 outputs) spans several blocks and its block peaks
+    take the per-element path; a mix+decimate tile spans several chunks (raw peaks)."""
+    cfg = so.CONFIGS['C3']
+    B = 48
+    x = so.synth_iq(cfg, B * L, 9)
+    P1, g1 = make_gpu_receivers(cfg)
+    am1 = [[] for _ in g1]
+    for k in range(B):
+        for i, rx in enumerate(g1):
+            am1[i].append(rx.demod_data(x[k * L:(k + 1) * L]).copy())
+    P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    ctx = P2._pysdr_stream
+    ctx.process_batch(x, B, L, on_device=False)
+    for i in range(len(g2)):
+        am, iq, cn, pk = ctx.fetch(i, B)
+        assert list(cn) == [len(a) for a in am1[i]]
+        assert np.array_equal(am, np.concatenate(am1[i]))
+    want = [np.max(np.abs(x[k * L:(k + 1) * L].astype(np.complex128)) ** 2) for k in range(B)]
+    assert np.allclose(pk, want, rtol=1e-6)
+    assert g2[3].agc.gain == g1[3].agc.gain and g2[0].agc.maxbuf == g1[0].agc.maxbuf
+
+
 def test_device_resident_batch_and_untouched_input():
     from pysdr_amd import _lib
     cfg = so.CONFIGS['C2']
