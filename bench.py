@@ -67,6 +67,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive ingest-ring figure")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks timed on the CPU oracle (0 = about 10 s worth)")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=None,
+                    help="after the timed loop every rank checks the LAST step's device buffers against the float32 "
+                         "oracle (first 2 chunks per sub-receiver, PSD frame 0); default ON when --gpus > 1")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
     return ap.parse_args(argv)
 
 
@@ -296,6 +300,129 @@ def host_fed_rate(ctx, cfg, L, cps, nslots_run=24):
                     "memcpy into the slot that stands for readStream()"}
 
 
+
+# ---------------------------------------------------------------------------------------------
+# --verify: the checker of the multi-rank line.  The oracle is used here as a CHECKER only, after
+# the timed region; nothing it computes reaches `value`.
+VERIFY_TOL = 1e-5            # north_star: 1e-5 relative float32 (same bar as tests/test_gpu_parity.py)
+VERIFY_CHUNKS = 2            # chunks of the last step compared per sub-receiver
+VERIFY_PRIME = {"nb": 192, "wfm": 16}   # chunks the oracle runs in front of them (AGC: 0.9^192 = 2e-9; pilot PLL: 17.5 tau = 6 chunks)
+
+
+def step_offset(k, seam, nloop):
+    """Offset into the synthetic loop at which step k reads (the stream is continuous across steps)."""
+    return (k * seam) % nloop if seam else 0
+
+
+def stream_slice(xu, nloop, seam, nsamp, s_abs, n):
+    """n samples of this rank's stream from ABSOLUTE sample index s_abs: exactly what steps
+    0, 1, ... handed to the context (step k = xu tiled, read from step_offset(k))."""
+    out = np.empty(n, np.complex64)
+    done = 0
+    while done < n:
+        k, i = divmod(s_abs + done, nsamp)
+        j = (step_offset(k, seam, nloop) + i) % nloop
+        m = min(n - done, nsamp - i, nloop - j)
+        out[done:done + m] = xu[j:j + m]
+        done += m
+    return out
+
+
+def primed_oracle(cfg, rx_idx, s_start):
+    """Oracle receivers whose absolute counters (LO phase, resampler sample index, output index)
+    say that `s_start` samples have gone by: the contexts on the GPU have processed every step
+    since 0, the checker only the last VERIFY_PRIME chunks in front of what it compares."""
+    rxs = oracle_receivers(cfg)
+    if rx_idx is not None:
+        rxs = [rxs[i] for i in rx_idx]
+    for rx in rxs:
+        rx.lo.phase = (rx.lo.fword * s_start) % (1 << 32)
+        if 'wfm' in cfg:
+            rx.front.n_abs = s_start
+            n1 = -(-s_start // rx.d1)                       # IF samples produced before s_start
+            rx.audio.n_abs = n1
+            rx.demod.m_abs = -(-n1 * rx.up2 // rx.down2)
+        else:
+            rx.dec.n_abs = s_start
+            rx.demod.m_abs = -(-s_start * rx.up // rx.down)
+    return rxs
+
+
+def _relerr(got, want):
+    got, want = np.asarray(got), np.asarray(want)
+    if got.shape != want.shape:
+        return float('inf')
+    if want.size == 0:
+        return 0.0
+    return float(np.max(np.abs(got - want)) / max(float(np.max(np.abs(want))), 1e-30))
+
+
+def verify_rank(cfg, ctx, rxs, rx_idx, xu, nloop, seam, nsamp, L, B, steps_done, psd=None):
+    """Compare the device buffers the LAST step left behind with the oracle.  Returns
+    dict(ok, worst_rel, checks=[...]).  psd = (lib, device, d_psd) on the rank that ran the PSD."""
+    from oracle import sdr_oracle as so
+    checks, worst = [], 0.0
+    s0 = (steps_done - 1) * nsamp                           # absolute index of the last step's first sample
+    nchk = min(VERIFY_CHUNKS, B)
+    if rxs:
+        prime = min(VERIFY_PRIME["wfm" if 'wfm' in cfg else "nb"], s0 // L)
+        s_start = s0 - prime * L
+        orx = primed_oracle(cfg, rx_idx, s_start)
+        x = stream_slice(xu, nloop, seam, nsamp, s_start, (prime + nchk) * L)
+        want_am = [[] for _ in orx]
+        want_iq = [[] for _ in orx]
+        for k in range(prime + nchk):
+            xc = x[k * L:(k + 1) * L]
+            for i, o in enumerate(orx):
+                a = o.demod_data(xc)
+                if k >= prime:
+                    want_am[i].append(np.array(a))
+                    want_iq[i].append(np.array(o.iq))
+        for i, o in enumerate(orx):
+            am, iq, cn, _pk = ctx.fetch(i, B)
+            n = int(cn[:nchk].sum())
+            wa, wi = np.concatenate(want_am[i]), np.concatenate(want_iq[i])
+            skip = 0
+            if prime == 0 and (o.mode in ('NFM', 'WFM', 'WFM2')):
+                skip = min(len(wa), 300 if o.mode == 'NFM' else 1100)   # discriminator on an empty FIR (tests/test_gpu_parity.py)
+            e_am = _relerr(am[:n][skip:], wa[skip:])
+            e_iq = _relerr(iq[:n], wi)
+            counts_ok = [int(v) for v in cn[:nchk]] == [len(a) for a in want_am[i]]
+            worst = max(worst, e_am, e_iq)
+            checks.append(dict(rx=(rx_idx[i] if rx_idx is not None else i), mode=o.mode, chunks=nchk, primed_chunks=prime,
+                               am=e_am, iq=e_iq, counts_ok=counts_ok))
+    if psd is not None:
+        lib, device, d_psd = psd
+        from pysdr_amd import _lib
+        got = np.empty(PSD_NFFT, np.float32)
+        _lib.check(lib.pysdr_dev_download(device, C.c_void_p(got.ctypes.data), d_psd, got.nbytes), "download psd")
+        sp = so.Spectrum(cfg['fs'] / 1e3, PSD_CHUNK, PSD_NFFT, 0.0, np.float64)
+        # pysdr_spectrum_batch reads the batch buffer from its first sample: frame 0 = the loop's first 32768
+        ref = np.asarray(sp.periodogram(np.resize(xu, PSD_CHUNK).astype(np.complex128), True), np.float64)
+        lin, rl = 10 ** (got.astype(np.float64) / 10.0), 10 ** (ref / 10.0)
+        e = float(np.max(np.abs(lin - rl)) / rl.max())      # linear power, every bin, of the peak
+        worst = max(worst, e)
+        checks.append(dict(psd_frame=0, linear_power_err_of_peak=e))
+    ok = all((c.get("am", 0) <= VERIFY_TOL and c.get("iq", 0) <= VERIFY_TOL and c.get("counts_ok", True)
+              and c.get("linear_power_err_of_peak", 0) <= VERIFY_TOL) for c in checks)
+    return dict(ok=bool(ok), worst_rel=worst, checks=checks)
+
+
+def device_checksum(lib, device, d_ptr, nbytes, piece=256 << 20):
+    """64-bit checksum (wrapping sum and xor of the 8-byte words) of a DEVICE buffer, downloaded in
+    pieces: what --split rx compares between the root's batch and every other rank's copy."""
+    from pysdr_amd import _lib
+    host = np.empty(min(piece, nbytes) // 8, np.uint64)
+    s, x = np.uint64(0), np.uint64(0)
+    with np.errstate(over='ignore'):
+        for off in range(0, nbytes, piece):
+            n = min(piece, nbytes - off) // 8
+            _lib.check(lib.pysdr_dev_download(device, C.c_void_p(host.ctypes.data), C.c_void_p(d_ptr + off), n * 8), "download")
+            s = s + np.add.reduce(host[:n], dtype=np.uint64)
+            x = x ^ np.bitwise_xor.reduce(host[:n])
+    return int(s), int(x)
+
+
 def source_sha(name):
     try:
         return hashlib.sha256(open(os.path.join(ROOT, "pysdr_amd", "csrc", name), "rb").read()).hexdigest()[:16]
@@ -364,6 +491,7 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     split_rx = args.split == "rx"
+    do_verify = (world > 1) if args.verify is None else bool(args.verify)
     if split_rx and world > ndev:
         raise SystemExit(f"--split rx needs one GPU per rank (RCCL): {world} ranks, {ndev} device(s)")
     with_psd = (args.workload == "c3") and not args.no_psd and (not split_rx or rank == 0)
@@ -396,14 +524,26 @@ def main():
     nloop = 1700000 if 'wfm' in cfg else 8 * L
     seam = nsamp % nloop                                  # 0 for the narrow-band configurations
     nbuf = nsamp + (nloop if seam else 0)
-    d_x = C.c_void_p()
+    # The fast load path wants 16-byte aligned batches, i.e. an EVEN sample offset.  When the seam is
+    # odd, odd steps read a second copy of the buffer that is shifted by one sample, from the even
+    # offset below theirs: the stream stays exactly continuous (no sample is repeated or dropped).
+    need_shifted = bool(seam & 1)
+    d_x, d_x1 = C.c_void_p(), C.c_void_p()
     _lib.check(lib.pysdr_dev_alloc(device, nbuf * 8, C.byref(d_x)), "alloc x")
-    if not split_rx or rank == 0:
+    if need_shifted:
+        _lib.check(lib.pysdr_dev_alloc(device, nbuf * 8, C.byref(d_x1)), "alloc x (shifted copy)")
+    xu = None
+    if not split_rx or rank == 0 or do_verify:
         xu = synth_batch(cfg, nloop, seed)
-        for off in range(0, nbuf, nloop):
-            n = min(nloop, nbuf - off)
-            _lib.check(lib.pysdr_dev_upload(device, C.c_void_p(d_x.value + off * 8),
-                                            C.c_void_p(xu.ctypes.data), n * 8), "upload")
+    if not split_rx or rank == 0:
+        for dst, src in ((d_x, xu), (d_x1, np.roll(xu, -1) if need_shifted else None)):
+            if src is None:
+                continue
+            src = np.ascontiguousarray(src)
+            for off in range(0, nbuf, nloop):
+                n = min(nloop, nbuf - off)
+                _lib.check(lib.pysdr_dev_upload(device, C.c_void_p(dst.value + off * 8),
+                                                C.c_void_p(src.ctypes.data), n * 8), "upload")
     step_no = [0]
     bc = multi.RcclBroadcaster(ctx, dist) if split_rx else None
 
@@ -426,10 +566,12 @@ def main():
                 _lib.check(lib.pysdr_spectrum_order(sp, ctx.h, 1), "spectrum_order")   # PSD of the last step has read d_x
             bc.bcast(d_x.value, nsamp * 8, 0)
         if not args.no_demod and rxs:
-            off = (step_no[0] * seam) % nloop if seam else 0
-            off -= off & 1                               # keep the 16-byte alignment of the fast load path
+            off = step_offset(step_no[0], seam, nloop)
+            base = d_x.value
+            if off & 1:                                  # odd start: the copy shifted by one sample, one sample lower
+                base, off = d_x1.value, off - 1
             step_no[0] += 1
-            ctx.process_batch(d_x.value + off * 8, B, L, on_device=True)
+            ctx.process_batch(base + off * 8, B, L, on_device=True)
         if sp is not None:
             # Same order as pySDR's RX thread (demod of the chunk, then its PSD): the two are
             # both HBM-bound, so overlapping them on two streams buys nothing and only smears
@@ -490,6 +632,26 @@ def main():
         dist.all_gather(allt, torch.tensor([dt_local / args.steps * 1e3], dtype=torch.float64))
         per_rank_ms = [float(v.item()) for v in allt]
 
+    # ---- --verify: the LAST timed step's device buffers against the oracle, on every rank
+    verify = None
+    if do_verify and not args.no_demod:
+        mine = verify_rank(cfg, ctx, rxs, rx_idx, xu, nloop, seam, nsamp, L, B, step_no[0],
+                           psd=(lib, device, d_psd) if sp is not None else None)
+        mine["rank"] = rank
+        if split_rx:
+            # the only proof that RCCL moved the bytes: every rank's copy of the batch == the root's
+            mine["bcast_checksum"] = device_checksum(lib, device, d_x.value, nsamp * 8)
+        allv = [mine]
+        if dist is not None:
+            allv = [None] * world
+            dist.all_gather_object(allv, mine)
+        if split_rx:
+            for v in allv:
+                v["bcast_equals_root"] = (v["bcast_checksum"] == allv[0]["bcast_checksum"])
+                v["ok"] = bool(v["ok"] and v["bcast_equals_root"])
+        verify = dict(verified_ranks=sum(1 for v in allv if v["ok"]),
+                      worst_rel=max(v["worst_rel"] for v in allv), tol=VERIFY_TOL, ranks=allv)
+
     pll = None
     if 'wfm' in cfg and rxs:
         sg, pt = C.c_int(0), C.c_int(0)
@@ -538,7 +700,8 @@ def main():
     dominant = r_psd if (r_psd is not None and (not k1 or psd_ms >= k1_ms)) else r_front
 
     out = {
-        "metric": "complex IQ MS/s through 4-RX demod chain",
+        # BASELINE.json's metric, named for what this line really ran (RX count and workload)
+        "metric": f"complex IQ MS/s through {nrx_total}-RX demod chain" + ("" if args.workload == "c3" else f" ({args.workload})"),
         "value": job_rate / 1e6,
         "unit": "MS/s",
         "n_gpus": world,
@@ -581,6 +744,14 @@ def main():
                    "argv": " ".join(sys.argv[1:])},
         "source_sha256": {s: source_sha(s) for s in ("mixdec.hip", "psdfft.hip", "stage2.hip", "api.hip")},
     }
+    if verify is not None:
+        out["verified_ranks"] = verify["verified_ranks"]
+        out["verify_worst_rel"] = verify["worst_rel"]
+        out["verify"] = dict(tol=VERIFY_TOL, what=f"last timed step's device buffers, first {min(VERIFY_CHUNKS, B)} chunks of every "
+                             "sub-receiver (audio + baseband IQ + per-chunk counts) and PSD frame 0 against the float32 "
+                             "oracle primed over the chunks in front of them"
+                             + ("; every rank's broadcast batch against the root's by 64-bit checksum" if split_rx else ""),
+                             ranks=verify["ranks"])
     if ablated:
         out["invalid"] = "PYSDR_DEBUG_FLAGS != 0 in a diagnostic build: work was skipped, no roofline is reported"
 
@@ -596,6 +767,8 @@ def main():
             out["cpu_baseline_per_rx_process"] = cpu_baseline_per_rx(args, cfg, used, with_psd, 10)
     elif rank == 0:
         out["cpu_baseline"] = None
+        out["multi_rank_note"] = ("cpu_baseline is measured at N=1 only; kernel_ms and the roofline objects of a multi-rank line "
+                                  "are rank 0's (per_rank_ms has every rank's step time, value the whole job's)")
 
     if bc is not None:
         bc.close()
@@ -603,6 +776,8 @@ def main():
         lib.pysdr_spectrum_destroy(sp)
         lib.pysdr_dev_free(device, d_psd)
     lib.pysdr_dev_free(device, d_x)
+    if need_shifted:
+        lib.pysdr_dev_free(device, d_x1)
     ctx.close()
     if dist is not None:
         dist.barrier()
@@ -613,6 +788,10 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+    if verify is not None and verify["verified_ranks"] != world:
+        print(f"bench.py: --verify FAILED on rank {rank}: {verify['verified_ranks']} of {world} ranks match the oracle "
+              f"(worst {verify['worst_rel']:.3g}, tol {VERIFY_TOL:g})", file=sys.stderr)
+        return 3
     return 0
 
 

@@ -7,6 +7,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -75,3 +76,49 @@ def test_stale_profile_means_no_traffic_figure(tmp_path, monkeypatch):
     assert t is None and "stale" in why
     # another configuration than the profiled one never gets the figure
     assert bench.measured_traffic(bench.parse(["--workload", "c2"]), 1, 2048, "mixdec", ["mixdec.hip"]) == (None, None)
+
+
+def test_stream_slice_is_the_continuous_stream_the_steps_read():
+    """--verify rebuilds the input of any stretch of the absolute stream from the loop, the seam and
+    the step size: a slice across a step boundary equals the two steps' reads put end to end."""
+    nloop, nsamp = 1000, 2348                     # seam 348: step k reads the loop from (k * 348) % 1000
+    xu = (np.arange(nloop) + 1j * np.arange(nloop)).astype(np.complex64)
+    seam = nsamp % nloop
+
+    def step_input(k):
+        off = bench.step_offset(k, seam, nloop)
+        return np.resize(np.roll(xu, -off), nsamp)
+
+    whole = np.concatenate([step_input(k) for k in range(4)])
+    for s, n in ((0, 10), (2300, 100), (2 * nsamp - 7, 2 * nsamp), (4 * nsamp - 5, 5)):
+        assert np.array_equal(bench.stream_slice(xu, nloop, seam, nsamp, s, n), whole[s:s + n])
+    # no seam: every step reads the loop from its start
+    assert np.array_equal(bench.stream_slice(xu, nloop, 0, 3 * nloop, 3 * nloop - 2, 4), np.r_[xu[-2:], xu[:2]])
+
+
+@pytest.mark.parametrize("which", ["c2", "c3"])
+def test_primed_oracle_joins_the_stream_where_a_full_run_is(which):
+    """The checker of --verify starts its oracle a few chunks in front of what it compares, with the
+    absolute counters (LO phase, resampler index, output index / BFO phase) set as if it had run
+    from sample 0: after the filters have filled it must give what the full run gives."""
+    from oracle import sdr_oracle as so
+    args = bench.parse(["--workload", which])
+    cfg = bench.workload_cfg(args)
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    n, k0 = 6, 3
+    x = bench.synth_batch(cfg, n * L, 21)
+    full = bench.oracle_receivers(cfg)
+    late = bench.primed_oracle(cfg, None, k0 * L)
+    for k in range(n):
+        xc = x[k * L:(k + 1) * L]
+        for f, o in zip(full, late):
+            af = f.demod_data(xc)
+            if k < k0:
+                continue
+            ao = o.demod_data(xc)
+            assert len(af) == len(ao) and f.dec.n_abs == o.dec.n_abs and f.demod.m_abs == o.demod.m_abs
+            if k >= k0 + 1:                       # one chunk for the FIR histories to fill
+                assert bench._relerr(o.iq, f.iq) <= 1e-6, (which, f.mode, k)
+                # the AGC's memory is longer than this test (--verify primes 192 chunks): compare the audio per unit gain
+                gf, go = float(f.agc.gain), float(o.agc.gain)
+                assert bench._relerr(np.asarray(ao) / go, np.asarray(af) / gf) <= 2e-6, (which, f.mode, k)
