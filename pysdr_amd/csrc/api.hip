@@ -142,6 +142,7 @@ struct pysdr_ctx {
   int tile_bytes = 0, threads = 1024;  // per LDS buffer (two per workgroup); 0 = as large as fits
   int wgs_per_cu = 1, num_cus = 256;
   int dbg_flags = 0, yflush_cap = 0;      // tuning / diagnostic switches, read from the environment once
+  int skew_override = -1;                 // PYSDR_MIXDEC_SKEW=0/1: force the tap-schedule skew off / on (A/B runs)
   int pll_kmax = 0;                       // pysdr_set_pll_segments: 0 = default, 1 = serial
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
@@ -342,6 +343,16 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   a.dq_last = (int)(((tile_out - 1) * down) / up);
   a.dr_last = (int)(((tile_out - 1) * down) % up);
   a.ntiles = n_out > 0 ? (n_out + a.tile_out - 1) / a.tile_out : 1;
+  // The four rows of a wave read x `down` samples = 8*down bytes apart and the LDS serves 256 bytes
+  // per clock: when that distance is within 64 bytes of a multiple of 256 the two rows of a half-wave
+  // share more than half of their banks, and the skewed tap schedule (which moves odd outputs by 128
+  // bytes) is the better one.  DOWN % 32 == 0 (2.048, 1.024, 2.56 MS/s -> 48 kHz) is the exact case.
+  {
+    const int dist = (int)((8LL * down) % 256);
+    a.skew = (std::min(dist, 256 - dist) < 64 && tile_out % (4L * up) == 0) ? 1 : 0;
+    if (c->skew_override >= 0) a.skew = c->skew_override && tile_out % (4L * up) == 0;
+    a.m0_mod = (uint32_t)(m0 % (2ULL * (unsigned)up));
+  }
   a.taps = d.d_taps;
   for (int r = 0; r < nrx; ++r) { a.y[r] = y[r]; a.phase0[r] = phase0[r]; a.fword[r] = fword[r]; }
   a.peak = peak ? peak : c->d_peak_scratch;
@@ -532,6 +543,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   // tuning / ablation switches (bench.py and DESIGN.md 4.1 use them; all default to off)
   { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) c->wgs_per_cu = atoi(e); }
   { const char* e = getenv("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0) c->yflush_cap = atoi(e); }
+  { const char* e = getenv("PYSDR_MIXDEC_SKEW"); if (e && *e) c->skew_override = atoi(e) ? 1 : 0; }
 #ifdef PYSDR_DIAG
   // work-skipping ablation switches exist only in a diagnostic build (python -m pysdr_amd.build --diag)
   { const char* e = getenv("PYSDR_DEBUG_FLAGS"); c->dbg_flags = e ? atoi(e) : 0; }

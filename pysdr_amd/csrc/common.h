@@ -64,6 +64,8 @@ struct MixDecArgs {
   int dq_tile, dr_tile;   // divmod(tile_out*down, up)
   int dq_last, dr_last;   // divmod((tile_out-1)*down, up)
   int yflush, ycap;       // LDS output stage: flushed every yflush tiles; ycap = yflush*tile_out per RX
+  int skew;               // skewed tap schedule (mixdec.hip): rows DOWN samples apart would share LDS banks
+  uint32_t m0_mod;        // absolute index of the call's first output, mod 2*up (parity of m div up)
 };
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st);
 size_t mixdec_lds_bytes(const MixDecArgs& a);

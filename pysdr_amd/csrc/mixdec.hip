@@ -115,6 +115,22 @@ __device__ __forceinline__ void m0_restore(unsigned keep) { asm volatile("s_mov_
 __device__ __forceinline__ void glds16_m0(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
 }
+// LDS read through an explicit address-space-3 pointer + a constant element offset: the constant
+// goes into the DS instruction's offset field (through a generic pointer hipcc spent one VALU add per
+// read on the address)
+typedef float mx_v2f __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) mx_v2f* lds_cf2;
+__device__ __forceinline__ float2 lds_ld(lds_cf2 p, int i) {
+  const mx_v2f v = p[i];
+  return make_float2(v.x, v.y);
+}
+// (the empty asm keeps hipcc from folding a rebasing constant back into the offsets, which would
+//  make them negative again)
+__device__ __forceinline__ lds_cf2 to_lds(const float2* p) {
+  unsigned a = (unsigned)(size_t)(lds_cf2)p;
+  asm volatile("" : "+v"(a));
+  return (lds_cf2)(size_t)a;
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Geometry of tile b: outputs [i_first, i_first + tile_n), LDS image = samples [lo, hi]
@@ -271,8 +287,17 @@ __device__ __forceinline__ void fold_rotate_stage(const float2 (&A)[N], const fl
   }
 }
 
-// NJ = kpad/16 known at compile time (fully unrolled tap loop) or 0 for a runtime loop
-template <int R, int NJ>
+// NJ = kpad/16 known at compile time (fully unrolled tap loop) or 0 for a runtime loop.
+// SKEW: the four DPP rows of a wave read x DOWN samples apart.  When DOWN * 8 bytes is (nearly) a
+// multiple of the 256 bytes the LDS serves per clock -- DOWN = 128, 64, 160: every rate whose DOWN is
+// a multiple of 32 (Tables.py:44-45: 2.048, 1.024, 2.56 MS/s ...) -- the rows of one half-wave sit on
+// the SAME banks and every ds_read_b64 of the dot product takes twice its cycles.  Padding the tile
+// costs an address per read (it spilled).  Instead the TAP SCHEDULE is skewed: an output whose index
+// in its polyphase branch, (m div UP), is odd walks the tap groups in the order 1, 2, .., NJ-1, 0, so
+// adjacent rows read 128-byte pieces 128 bytes further apart = the other half of the banks.  The
+// rotation is a function of the ABSOLUTE output index, so an output is summed in the same order
+// whatever call or tile it falls into (batch == chunk by chunk, bit for bit).
+template <int R, int NJ, bool SKEW>
 __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   float2* const buf0 = lds;                    // [tile_cap]
@@ -325,14 +350,30 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   const int hold_step = nwaves / ngrp;                  // waves per group
   const int hold_q0 = (wave < ngrp * hold_step) ? wave / ngrp : (1 << 29);
   float2 greg[kCanHold ? RH : 1][kCanHold ? NJ : 1];
-  bool have_greg = false;
   // per-lane constants of the epilogue: lane s of every row finishes RX hold_rbase + s
+  // (kTight: instantiations whose tap registers leave no room -- 2*RH*NJ >= 40 of the 128 a
+  // 1024-thread workgroup may use -- recompute these four per task instead: a spilled one is reloaded
+  // with a scratch load, and the s_waitcnt vmcnt(0) behind it also waits for the NEXT tile's copies,
+  // i.e. serialises the DMA with the dot products: mixdec<1,21> ran at 0.36 of HBM for that reason)
+  constexpr bool kTight = kCanHold && (2 * RH * NJ >= 40) && (R != 4);
   uint32_t my_p0 = 0u, my_fw = 0u;
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-    if (hold_rbase + s == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; }
   int v_gup = g * a.up, v_gdown = g * a.down - s;
-  asm volatile("" : "+v"(my_p0), "+v"(my_fw), "+v"(v_gup), "+v"(v_gdown));
+  if (!kTight) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (hold_rbase + s == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; }
+    asm volatile("" : "+v"(my_p0), "+v"(my_fw), "+v"(v_gup), "+v"(v_gdown));
+  }
+  // skewed tap schedule: output i = i_first + c + UP*(4*qq + g) of this wave's branch c has
+  // (m div UP) = (m0 + c) div UP + i_first/UP + 4*qq + g, and i_first/UP is even (tile_out is a
+  // multiple of 4*UP): its parity is ((m0 + c) div UP + g) & 1, fixed per lane for the launch
+  int rot = 0;
+  if (SKEW) {
+    const int v = (int)a.m0_mod + hold_c;                // < 3*UP
+    rot = (((v >= a.up) ? 1 : 0) + ((v >= 2 * a.up) ? 1 : 0) + g) & 1;
+  }
+  int x_rot = -16 * rot, x_last = rot ? 0 : -16 * ((NJ > 0 ? NJ : 1) - 1);
+  if (SKEW) asm volatile("" : "+v"(x_rot), "+v"(x_last));
 
   Tile cur = tile_geometry(a, t_begin);
   int i_base = cur.i_first;      // first output held in the LDS output stage
@@ -341,6 +382,25 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   int pk_lo = 0;                 // samples [pk_lo, pk_hi] of chunk pk_chunk exist in this call
   int pk_hi = (int)(a.chunk_len < a.n_total ? a.chunk_len : a.n_total) - 1;
   if (!PYSDR_DBG(a, 2)) stage_tile(a, cur, buf0, tid, nthr);
+
+  if (kCanHold && hold) {
+    // this wave's taps: one branch (p_f is the same for every tile: tile_out*DOWN is a multiple of UP),
+    // one RX half, read from LDS once for the whole launch
+    dma_wait();
+    __syncthreads();
+    uint32_t qc0, pc0;
+    divmod_magic((uint32_t)cur.p_f + (uint32_t)hold_c * (uint32_t)a.down, (uint32_t)a.up, a.magic, qc0, pc0);
+    const int kp0 = (NJ > 0) ? 16 * NJ : a.kpad;
+    const float2* th = tl + (int)pc0 * kp0 + s + hold_rbase * a.up * kp0;
+#pragma unroll
+    for (int r = 0; r < RH; ++r)
+#pragma unroll
+      for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj) {
+        int idx = jj + (SKEW ? rot : 0);                 // the lane's jj-th tap group
+        if (SKEW && idx == NJ) idx = 0;
+        greg[r][jj] = (r < hold_rcount) ? th[r * a.up * kp0 + 16 * idx] : make_float2(0.f, 0.f);
+      }
+  }
 
   for (int tb = t_begin; tb < t_end; ++tb) {
     float2* const xs = ((tb - t_begin) & 1) ? buf1 : buf0;
@@ -366,7 +426,18 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
         // whole pairs inside the current chunk: a maximum does not mind the neighbour
         // sample being counted by two tiles
         const int p_hi = (e_hi - cur.lo) >> 1;
-        for (int pi = ((e_lo - cur.lo) >> 1) + tid; pi <= p_hi; pi += nthr) {
+        int pi = ((e_lo - cur.lo) >> 1) + tid;
+        // four reads in flight per thread: a tile is 4-5 trips of this loop, and one read per trip
+        // put 4-5 LDS latencies in front of every tile's dot products (0.04 of C1's 0.43 ms)
+        for (; pi + 3 * nthr <= p_hi; pi += 4 * nthr) {
+          const float4 v0 = xv[pi], v1 = xv[pi + nthr], v2 = xv[pi + 2 * nthr], v3 = xv[pi + 3 * nthr];
+          const float m0 = fmaxf(fmaf(v0.x, v0.x, v0.y * v0.y), fmaf(v0.z, v0.z, v0.w * v0.w));
+          const float m1 = fmaxf(fmaf(v1.x, v1.x, v1.y * v1.y), fmaf(v1.z, v1.z, v1.w * v1.w));
+          const float m2 = fmaxf(fmaf(v2.x, v2.x, v2.y * v2.y), fmaf(v2.z, v2.z, v2.w * v2.w));
+          const float m3 = fmaxf(fmaf(v3.x, v3.x, v3.y * v3.y), fmaf(v3.z, v3.z, v3.w * v3.w));
+          pk_run = fmaxf(fmaxf(pk_run, fmaxf(m0, m1)), fmaxf(m2, m3));
+        }
+        for (; pi <= p_hi; pi += nthr) {
           const float4 v = xv[pi];
           pk_run = fmaxf(pk_run, fmaxf(fmaf(v.x, v.x, v.y * v.y), fmaf(v.z, v.z, v.w * v.w)));
         }
@@ -425,6 +496,17 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
       const int qq = hold ? task : task - c * a.tpc;
       uint32_t qc, pc;
       divmod_magic((uint32_t)cur.p_f + (uint32_t)c * (uint32_t)a.down, (uint32_t)upc, a.magic, qc, pc);
+      int s_l = s;                                        // (laundered: hipcc would hoist the recomputation
+      if (kTight) {                                       //  out of the loop and spill it again)
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        s_l = lane_l & 15;
+        v_gup = (lane_l >> 4) * a.up;
+        v_gdown = (lane_l >> 4) * a.down - s_l;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (hold_rbase + s_l == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; }
+      }
       const int i = cur.i_first + c + 4 * qq * upc + v_gup;
       const bool valid = (i <= i_last);
       const int sb = cur.rel_f + (int)qc + 4 * qq * a.down - cur.lo;      // scalar
@@ -435,21 +517,17 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
       // A += g*x.re, B += g*x.im per RX (two packed FMAs per tap, no operand shuffles);
       // y = (A.re - B.im, A.im + B.re)
       if (kCanHold && hold) {
-        const float2* th = tp + hold_rbase * upc * kp;
-        if (!have_greg) {
-#pragma unroll
-          for (int r = 0; r < RH; ++r)
-#pragma unroll
-            for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj)
-              greg[r][jj] = (r < hold_rcount) ? th[r * upc * kp + 16 * jj] : make_float2(0.f, 0.f);
-          have_greg = true;
-        }
         float2 A[RH], B[RH];
 #pragma unroll
         for (int r = 0; r < RH; ++r) { A[r] = make_float2(0.f, 0.f); B[r] = make_float2(0.f, 0.f); }
+        // (reads go through the LOWEST address + a non-negative offset: a DS offset field is unsigned,
+        //  so xp[-16*jj] cost one VALU address add per read)
+        constexpr int kTop = 16 * ((NJ > 0 ? NJ : 1) - 1);
+        const lds_cf2 xr = to_lds((SKEW ? xp + x_rot : xp) - kTop);   // odd outputs start one tap group later ...
+        const lds_cf2 xl = to_lds(SKEW ? xp + x_last : xp);            // ... and finish with group 0
 #pragma unroll
         for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj) {
-          const float2 xv = xp[-16 * jj];
+          const float2 xv = (SKEW && jj == NJ - 1) ? lds_ld(xl, 0) : lds_ld(xr, kTop - 16 * jj);
 #pragma unroll
           for (int r = 0; r < RH; ++r) {
             const float2 gg = greg[r][jj];
@@ -464,8 +542,9 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
         float2 A[R], B[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { A[r] = make_float2(0.f, 0.f); B[r] = make_float2(0.f, 0.f); }
+        const lds_cf2 xlow = to_lds(xp - (kp - 16));
         auto tap_step = [&](int j) {
-          const float2 xv = xp[-j];
+          const float2 xv = lds_ld(xlow, kp - 16 - j);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const float2 gg = tp[r * upc * kp + j];
@@ -505,7 +584,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
 }
 
-template <int R, int NJ>
+template <int R, int NJ, bool SKEW>
 int launch_rj(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
   // the attribute is per (function, device): one bit per device, guarded against contexts on
   // other threads / other devices of the same process (P.GPU_DEVICE, cfg.device)
@@ -516,16 +595,16 @@ int launch_rj(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_
     PYSDR_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(attr_mu);
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mixdec_kernel<R, NJ>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mixdec_kernel<R, NJ, SKEW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) {
-        set_last_error("hipFuncSetAttribute(mixdec<%d,%d>): %s", R, NJ, hipGetErrorString(e));
+        set_last_error("hipFuncSetAttribute(mixdec<%d,%d,%d>): %s", R, NJ, (int)SKEW, hipGetErrorString(e));
         return PYSDR_ERR_HIP;
       }
       attr_done |= 1ull << (dev & 63);
     }
   }
-  hipLaunchKernelGGL((mixdec_kernel<R, NJ>), dim3(grid), dim3(threads), lds, st, a);
+  hipLaunchKernelGGL((mixdec_kernel<R, NJ, SKEW>), dim3(grid), dim3(threads), lds, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }
@@ -533,14 +612,14 @@ int launch_rj(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_
 template <int R>
 int launch_r(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
   // 255-tap prototypes at UP = 3 (the BASELINE configurations) have 96 taps per branch
-  if (a.kpad == 96) return launch_rj<R, 6>(a, threads, grid, lds, st);
+  if (a.kpad == 96) return a.skew ? launch_rj<R, 6, true>(a, threads, grid, lds, st) : launch_rj<R, 6, false>(a, threads, grid, lds, st);
   // single-RX long filters: the 255-tap video filter of the broadcast-FM front end (UP = 1, 256
   // taps in one branch) and the reference's default 1001-tap prototype at UP = 3 (336 per branch)
   if constexpr (R == 1) {
-    if (a.kpad == 256) return launch_rj<R, 16>(a, threads, grid, lds, st);
-    if (a.kpad == 336) return launch_rj<R, 21>(a, threads, grid, lds, st);
+    if (a.kpad == 256) return launch_rj<R, 16, false>(a, threads, grid, lds, st);
+    if (a.kpad == 336) return a.skew ? launch_rj<R, 21, true>(a, threads, grid, lds, st) : launch_rj<R, 21, false>(a, threads, grid, lds, st);
   }
-  return launch_rj<R, 0>(a, threads, grid, lds, st);
+  return launch_rj<R, 0, false>(a, threads, grid, lds, st);
 }
 
 }  // namespace

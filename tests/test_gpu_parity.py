@@ -133,11 +133,15 @@ def test_ragged_and_tiny_chunks(chunks):
     run_both(cfg, chunks, seed=4)
 
 
-@pytest.mark.parametrize("fs,ntaps", [(2.4e6, 255), (1.8e6, 127), (2.048e6, 1001), (10e6, 255), (6.144e6, 63)])
+@pytest.mark.parametrize("fs,ntaps", [(2.4e6, 255), (1.8e6, 127), (2.048e6, 1001), (10e6, 255), (6.144e6, 63),
+                                      (1.024e6, 255), (2.56e6, 1001), (2.56e6, 255), (2.048e6, 255)])
 def test_random_call_lengths_across_rates(fs, ntaps):
     """Tile geometry (incremental steps, whole-piece copies, chunk straddling, odd tails) under
-    call lengths drawn at random, for UP/DOWN = 1/50, 2/75, 3/128, 3/625, 1/128: the baseband IQ
-    and the raw-chunk peak must not depend on how the stream is cut."""
+    call lengths drawn at random, for UP/DOWN = 1/50, 2/75, 3/128, 3/625, 1/128, 3/64, 3/160: the
+    baseband IQ and the raw-chunk peak must not depend on how the stream is cut.  The rates of
+    Tables.py:44-45 whose DOWN is a multiple of 32 (2.048, 1.024, 2.56 MS/s) run the skewed tap
+    schedule of mixdec.hip, with the 255-tap and the reference's default 1001-tap prototype
+    (params.py:134)."""
     rng = np.random.default_rng(int(fs) % 9973)
     L = so.chunk_sizes(fs, 48e3)[3]
     cfg = dict(so.CONFIGS['C2'], fs=fs, ntaps_dec=ntaps,
@@ -222,6 +226,40 @@ def test_batch_equals_chunked_bit_exact():
     # raw-chunk peak |x|^2 (rx.auto_mute input) is exact
     want = [np.max(np.abs(x[k * L:(k + 1) * L].astype(np.complex128)) ** 2) for k in range(B)]
     assert np.allclose(pk, want, rtol=1e-6)
+
+
+@pytest.mark.parametrize("fs,ntaps", [(2.048e6, 1001), (1.024e6, 255)])
+def test_skewed_tap_schedule_does_not_depend_on_the_cut(fs, ntaps):
+    """DOWN % 32 == 0: odd outputs of a polyphase branch walk their tap groups rotated by one (LDS
+    banks, mixdec.hip).  The rotation is a function of the ABSOLUTE output index, so the baseband
+    IQ is the same bit for bit whether the stream arrives chunk by chunk, in one batch, or cut at
+    random places (which moves every output to another tile, wave and DPP row)."""
+    cfg = dict(so.CONFIGS['C1'], fs=fs, ntaps_dec=ntaps,
+               carriers=[dict(f=0.05 * fs, kind='am', amp=0.3, tone=1000.0, depth=0.5)],
+               rx=[dict(frq=0.05 * fs, mode='AM', video_bw=10e3, af_bw=5e3)])
+    L = so.chunk_sizes(fs, 48e3)[3]
+    B = 12
+    x = so.synth_iq(cfg, B * L, 31)
+    P1, g1 = make_gpu_receivers(cfg)
+    iq1 = np.concatenate([(g1[0].demod_data(x[k * L:(k + 1) * L]), g1[0].iq.copy())[1] for k in range(B)])
+    P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    P2._pysdr_stream.process_batch(x, B, L, on_device=False)
+    iq2 = P2._pysdr_stream.fetch(0, B)[1]
+    assert np.array_equal(iq1, iq2)
+    rng = np.random.default_rng(5)
+    cuts = np.sort(rng.choice(np.arange(1, B * L), 9, replace=False))
+    P3, g3 = make_gpu_receivers(cfg, max_batch_chunks=4)
+    iq3 = []
+    for a, b in zip(np.r_[0, cuts], np.r_[cuts, B * L]):
+        if b - a > 4 * L:                     # a call may not exceed the context's capacity
+            for c in range(a, b, 4 * L):
+                g3[0].demod_data(x[c:min(c + 4 * L, b)]); iq3.append(g3[0].iq.copy())
+        else:
+            g3[0].demod_data(x[a:b]); iq3.append(g3[0].iq.copy())
+    assert np.array_equal(iq1, np.concatenate(iq3))
+    o = so.make_receivers(cfg, np.float32)[0]
+    want = np.concatenate([(o.demod_data(x[k * L:(k + 1) * L]), o.iq.copy())[1] for k in range(B)])
+    assert relerr(iq1, want) <= TOL
 
 
 @pytest.mark.parametrize("L", [20000, 3000, 170666 // 4])
