@@ -436,7 +436,7 @@ def measured_traffic(args, nrx, B, kernel_prefix, sources):
     while the kernel sources still hash to what was profiled (the profile file carries the hashes)."""
     if B != DEFAULT_CHUNKS[args.workload] or args.nrx:
         return None, None
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         # C3 (the demod kernels are the same with and without the PSD) or the workload's own passes
         name = f"{tag}_pmc_traffic.json" if args.workload == "c3" else f"{tag}_{args.workload}_pmc_traffic.json"
         p = os.path.join(ROOT, "profiles", name)

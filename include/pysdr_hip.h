@@ -202,6 +202,12 @@ int  pysdr_waterfall_push(pysdr_waterfall* wf, const float* line_db, int n, int 
 int  pysdr_waterfall_roll(pysdr_waterfall* wf, int nbins);
 int  pysdr_waterfall_image(pysdr_waterfall* wf, float pan_dr, float* image_out, float* mean_out,
                            float* bkgnd_out);
+/* The same with the dynamic-range maximum taken over the rows [0, npsd) only, npsd = length of the
+ * PSD line just pushed: `zz = self.wf[0:npsd,:] - med; zmax = np.nanmax(zz)` (Plotting.py:618-619;
+ * a real-input line is half length, :536-540).  image_out stays [ncols][nfft]; the reference draws
+ * its first npsd rows. */
+int  pysdr_waterfall_image_rows(pysdr_waterfall* wf, float pan_dr, int npsd, float* image_out,
+                                float* mean_out, float* bkgnd_out);
 
 /* ---- device memory for resident streams --------------------------------------- */
 int pysdr_dev_alloc(int device, size_t bytes, void** out);

@@ -594,12 +594,13 @@ def waterfall_roll(wf, wf_fc, frq, df):
     return wf, wf_fc
 
 
-def waterfall_image(wf, wf_cnt, pan_dr):
+def waterfall_image(wf, wf_cnt, pan_dr, npsd=None):
     """``Plotting.py:583-587,618-626``: background = median over bins of the mean over
-    the valid history; image = max(wf - bkgnd, zmax - PAN_DR)."""
+    the valid history; image = max(wf[0:npsd] - bkgnd, zmax - PAN_DR), npsd = length of the
+    line pushed last (:536, :618: the image and its maximum cover those rows only)."""
     psd2 = np.mean(wf[:, -wf_cnt:], 1)
     bkgnd = np.median(psd2)
-    zz = wf - bkgnd
+    zz = wf[0:(wf.shape[0] if npsd is None else npsd), :] - bkgnd
     zmax = np.nanmax(zz)
     return np.maximum(zz, zmax - pan_dr), bkgnd, psd2
 

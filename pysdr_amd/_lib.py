@@ -93,6 +93,7 @@ PROTOTYPES = {
     "pysdr_waterfall_push": (_i, [_vp, _vp, _i, _i]),
     "pysdr_waterfall_roll": (_i, [_vp, _i]),
     "pysdr_waterfall_image": (_i, [_vp, _f, _pf, _pf, _pf]),
+    "pysdr_waterfall_image_rows": (_i, [_vp, _f, _i, _pf, _pf, _pf]),
     "pysdr_dev_alloc": (_i, [_i, _sz, C.POINTER(_vp)]),
     "pysdr_dev_free": (_i, [_i, _vp]),
     "pysdr_dev_upload": (_i, [_i, _vp, _vp, _sz]),

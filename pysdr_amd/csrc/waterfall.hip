@@ -5,8 +5,8 @@
 // produces the image that gets blitted:
 //   push   wf = concat(wf[:,1:], line)             line shorter than nfft padded with -1e38
 //   roll   wf = np.roll(wf, -nbins, axis=0)
-//   image  bkgnd = median(mean(wf[:, -cnt:], 1));  zz = wf - bkgnd;
-//          img = max(zz, nanmax(zz) - PAN_DR)
+//   image  bkgnd = median(mean(wf[:, -cnt:], 1));  zz = wf[0:npsd, :] - bkgnd  (npsd = length of the
+//          line just pushed);  img = max(zz, nanmax(zz) - PAN_DR)
 #include "common.h"
 
 struct pysdr_waterfall {
@@ -103,10 +103,17 @@ __global__ __launch_bounds__(1024) void wf_median_kernel(const float* __restrict
   if (threadIdx.x == 0) stat[0] = 0.5f * (a + b);
 }
 
-__global__ __launch_bounds__(256) void wf_max_kernel(const float* __restrict__ wf, size_t n,
-                                                     unsigned* __restrict__ out_key) {
+// max over the logical rows [0, npsd) of every column (Plotting.py:618-619: zz = wf[0:npsd,:] - med,
+// zmax = nanmax(zz) -- the rows past the CURRENT line's length are not looked at)
+__global__ __launch_bounds__(256) void wf_max_kernel(const float* __restrict__ wf, int nfft, int ncols, int shift,
+                                                     int npsd, unsigned* __restrict__ out_key) {
   float m = -3.0e38f;
-  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, wf[i]);
+  const size_t n = (size_t)nfft * ncols;
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    int l = (int)(i % (size_t)nfft) - shift;           // physical bin -> logical row
+    if (l < 0) l += nfft;
+    if (l < npsd) m = fmaxf(m, wf[i]);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) atomicMax(out_key, f2key(m));
@@ -194,9 +201,9 @@ int pysdr_waterfall_roll(pysdr_waterfall* w, int nbins) {
   return PYSDR_OK;
 }
 
-int pysdr_waterfall_image(pysdr_waterfall* w, float pan_dr, float* image_out, float* mean_out,
-                          float* bkgnd_out) {
-  if (!w) return PYSDR_ERR_ARG;
+int pysdr_waterfall_image_rows(pysdr_waterfall* w, float pan_dr, int npsd, float* image_out, float* mean_out,
+                               float* bkgnd_out) {
+  if (!w || npsd < 1 || npsd > w->nfft) return PYSDR_ERR_ARG;
   if (w->cnt < 1) { set_last_error("pysdr_waterfall_image: no line pushed yet"); return PYSDR_ERR_STATE; }
   PYSDR_HIP_CHECK(hipSetDevice(w->device));
   const int gx = (w->nfft + 255) / 256;
@@ -205,7 +212,7 @@ int pysdr_waterfall_image(pysdr_waterfall* w, float pan_dr, float* image_out, fl
                      w->cnt, w->shift, w->d_mean);
   hipLaunchKernelGGL(wf_median_kernel, dim3(1), dim3(1024), 0, w->stream, w->d_mean, w->nfft, w->d_stat);
   PYSDR_HIP_CHECK(hipMemsetAsync(w->d_stat + 1, 0, sizeof(float), w->stream));
-  hipLaunchKernelGGL(wf_max_kernel, dim3(512), dim3(256), 0, w->stream, w->d_wf, n,
+  hipLaunchKernelGGL(wf_max_kernel, dim3(512), dim3(256), 0, w->stream, w->d_wf, w->nfft, w->ncols, w->shift, npsd,
                      reinterpret_cast<unsigned*>(w->d_stat + 1));
   hipLaunchKernelGGL(wf_image_kernel, dim3(gx, w->ncols), dim3(256), 0, w->stream, w->d_wf, w->nfft, w->ncols,
                      w->head, w->shift, w->d_stat, pan_dr, w->d_image);
@@ -215,6 +222,12 @@ int pysdr_waterfall_image(pysdr_waterfall* w, float pan_dr, float* image_out, fl
   if (bkgnd_out) PYSDR_HIP_CHECK(hipMemcpyAsync(bkgnd_out, w->d_stat, sizeof(float), hipMemcpyDeviceToHost, w->stream));
   PYSDR_HIP_CHECK(hipStreamSynchronize(w->stream));
   return PYSDR_OK;
+}
+
+int pysdr_waterfall_image(pysdr_waterfall* w, float pan_dr, float* image_out, float* mean_out,
+                          float* bkgnd_out) {
+  if (!w) return PYSDR_ERR_ARG;
+  return pysdr_waterfall_image_rows(w, pan_dr, w->nfft, image_out, mean_out, bkgnd_out);
 }
 
 }  // extern "C"

@@ -55,10 +55,12 @@ def post_demod(P, x, irx, am):
     if getattr(P, 'ENABLE_AUTO_MUTE', False):           # receiver.py:238-245
         P.AUTO_MUTED = bool(rx.auto_mute(x))
 
-    mode = rx.mode if getattr(rx, 'mode', None) is not None else P.MODE
-    if mode == 'AM' or mode == 'USB':                   # receiver.py:250-252: DC removal
+    # receiver.py:250-252: DC removal, decided by the GLOBAL mode P.MODE.  As in the reference it only
+    # reaches the consumers below (AF PSD tap, SAVE_DEMOD): `am` is re-bound to a new array, `rx.am` --
+    # what audio_out plays (receiver.py:195) -- keeps what demod_data left there
+    # (tests/golden/host_loop_ref.npz: the reference's text executed)
+    if P.MODE == 'AM' or P.MODE == 'USB':
         am = am - np.mean(am)
-        rx.am = am
 
     if P.SHOW_AF_PSD and irx == P.PLOT_RX:              # receiver.py:257-274
         P.rb_af.push(rx.iq if P.PANADAPTOR else am)
@@ -81,8 +83,6 @@ def audio_out(P):
             if iplay + n2 < P.NUM_RX:
                 g2 = 0. if P.MUTED[iplay + n2] else pow(10., P.AF_GAIN) - 1
                 am2 = P.rx[iplay + n2].am.real
-                n = min(len(am1), len(am2))
-                am1, am2 = am1[:n], am2[:n]
             else:
                 g2, am2 = 0., 0
             if P.audio_playback:
@@ -335,7 +335,7 @@ def replay_batched(P, batch_chunks=64, on_batch=None, dsp=None):
     through the batched device path: ``batch_chunks`` chunks per launch sequence instead of one
     Python round trip per chunk, the results identical to ``SDR_EXECUTIVE.Run`` in REPLAY_MODE
     chunk for chunk (a chunk is still one AGC block; ``receiver.py:541-557`` for the slicing and
-    the tuning-offset mixer, ``:250-252`` for the DC removal, ``:293-297`` for the save taps).
+    the tuning-offset mixer, ``:250-252`` for the DC removal of the saved demod, ``:293-297`` for the save taps).
 
     ``on_batch(first_chunk, am, iq, chunk_nout)`` gets, per batch, lists over the sub-receivers of
     the audio / baseband IQ of the whole batch and the per-chunk output counts.  Returns the
@@ -362,20 +362,19 @@ def replay_batched(P, batch_chunks=64, on_batch=None, dsp=None):
         for irx in range(P.NUM_RX):
             rx = P.rx[irx]
             am, iq, cn, pk = ctx.fetch(rx.irx, nb)
-            mode = rx.mode if getattr(rx, 'mode', None) is not None else P.MODE
-            if mode == 'AM' or mode == 'USB':
-                am = am.copy()
-                pos = 0
-                for c in cn:
-                    am[pos:pos + c] -= np.mean(am[pos:pos + c])
-                    pos += c
-            ams.append(am)
+            ams.append(am)                             # the audio: rx.am as demod_data leaves it (receiver.py:195)
             iqs.append(iq)
             cns = cn
             if irx == 0:
                 if P.SAVE_BASEBAND:
                     P.baseband_iq_io.save_data(iq)
                 if P.SAVE_DEMOD:
+                    if P.MODE == 'AM' or P.MODE == 'USB':   # receiver.py:250-252: per chunk, the saved / PSD copy only
+                        am = am.copy()
+                        pos = 0
+                        for c in cn:
+                            am[pos:pos + c] -= np.mean(am[pos:pos + c])
+                            pos += c
                     P.demod_io.save_data(am)
         if P.SAVE_IQ:
             P.raw_iq_io.save_data(x)

@@ -42,6 +42,7 @@ class Waterfall:
         line = np.ascontiguousarray(PSD[::-1] if flip else PSD, np.float32)
         check(_lib.lib().pysdr_waterfall_push(self._h, C.c_void_p(line.ctypes.data), len(line), 0),
               "pysdr_waterfall_push")
+        self.npsd = len(line)            # Plotting.py:536
         if self.wf_cnt < self.ncols:
             self.wf_cnt += 1
 
@@ -54,13 +55,16 @@ class Waterfall:
         return nbins
 
     def image(self, pan_dr):
-        """-> (image[nfft, ncols], bkgnd, PSD2): ``Plotting.py:583-587,618-626``."""
+        """-> (image[npsd, ncols], bkgnd, PSD2): ``Plotting.py:583-587,618-626``.  As in the reference
+        the image and its dynamic-range maximum cover the rows of the line pushed last
+        (``zz = self.wf[0:npsd,:] - med``, :618): a half-length (real-input) line gives half an image."""
         img = np.empty((self.ncols, self.nfft), np.float32)
         mean = np.empty(self.nfft, np.float32)
         bk = C.c_float(0)
-        check(_lib.lib().pysdr_waterfall_image(self._h, float(pan_dr), _lib.as_pf(img), _lib.as_pf(mean),
-                                               C.byref(bk)), "pysdr_waterfall_image")
-        return img.T, bk.value, mean
+        npsd = int(getattr(self, 'npsd', self.nfft))
+        check(_lib.lib().pysdr_waterfall_image_rows(self._h, float(pan_dr), npsd, _lib.as_pf(img), _lib.as_pf(mean),
+                                                    C.byref(bk)), "pysdr_waterfall_image_rows")
+        return img.T[:npsd], bk.value, mean
 
     @staticmethod
     def peaks(psd2, bkgnd, peak_dist, df):

@@ -17,16 +17,19 @@ run_cfg() {  # name, pmc(0/1), bench args...
   if [ "$pmc" = 1 ]; then
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$name/pmc_fetch" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --steps 3 --warmup 1 > "$OUT/$name/pmc_fetch.json" 2> "$OUT/$name/pmc_fetch.err"
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$name/pmc_write" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --steps 3 --warmup 1 > "$OUT/$name/pmc_write.json" 2> "$OUT/$name/pmc_write.err"
+    # wave-level counters of the same kernels (LDS bank conflicts, VALU / LDS activity, parked cycles)
+    rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/$name/pmc_sq" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --steps 3 --warmup 1 > "$OUT/$name/pmc_sq.json" 2> "$OUT/$name/pmc_sq.err"
   fi
   # keep only the small summaries (the per-dispatch traces are tens of MB)
   find "$OUT/$name" -name "*kernel_trace.csv" -delete
+  find "$OUT/$name" -name "*counter_collection.csv" -size +8M -delete
   echo "$name: $(tail -c 300 "$OUT/$name/bench.json" | head -c 120)"
 }
 run_cfg c3 1
 [ -n "$QUICK" ] && exit 0
 run_cfg c3_nopsd 0 --no-psd --no-cpu-baseline
 run_cfg c2 1 --workload c2
-run_cfg c1 0 --workload c1
-run_cfg c4 0 --workload c4
+run_cfg c1 1 --workload c1
+run_cfg c4 1 --workload c4
 run_cfg c4mono 0 --workload c4mono --no-cpu-baseline
 run_cfg rx6 0 --nrx 6 --no-psd --no-cpu-baseline

@@ -65,8 +65,8 @@ for cfg in sorted(os.listdir(src)):
         w = [v for v in w if v >= 0.5 * max(w)] if w else w
         fm = sum(f) / len(f) if f else 0.0
         wm = sum(w) / len(w) if w else 0.0
-        m = re.search(r"(\w+_kernel)", k)
-        rows.append(dict(kernel=m.group(1) if m else k, launches_sampled=len(f),
+        m = re.search(r"(\w+_kernel)(<[^>]*>)?", k)
+        rows.append(dict(kernel=(m.group(1) + (m.group(2) or "")) if m else k, launches_sampled=len(f),
                          FETCH_SIZE_KiB=fm, WRITE_SIZE_KiB=wm,
                          read_bytes=2 * fm * 1024, write_bytes=wm * 1024,
                          hbm_bytes_per_launch=2 * fm * 1024 + wm * 1024))
@@ -78,3 +78,17 @@ for cfg in sorted(os.listdir(src)):
         name = f"{tag}_pmc_traffic.json" if cfg == "c3" else f"{tag}_{cfg}_pmc_traffic.json"
         json.dump(doc, open(os.path.join(dst, name), "w"), indent=1)
         print(cfg, json.dumps([(r["kernel"], round(r["hbm_bytes_per_launch"] / 1e6, 1)) for r in rows]))
+    sq = pmc(cfg, "pmc_sq")
+    if sq:
+        per = collections.defaultdict(dict)
+        for (k, c), v in sq.items():
+            if "pysdr" not in k:
+                continue
+            m = re.search(r"(\w+_kernel)(<[^>]*>)?", k)
+            v = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v     # the full-batch launches only
+            per[(m.group(1) + (m.group(2) or "")) if m else k][c] = sum(v) / len(v)
+        doc = dict(config=cfg, git_head=head + ("+dirty" if dirty else ""),
+                   source_sha256={s: sha(s) for s in ("mixdec.hip", "psdfft.hip", "stage2.hip", "api.hip")},
+                   note="per launch, summed over all waves (SQ_* count quad-cycles: MI355X_MICROARCH.md); one rocprofv3 --pmc pass of bench.py",
+                   kernels=[dict(kernel=k, **{c: round(x) for c, x in sorted(v.items())}) for k, v in sorted(per.items())])
+        json.dump(doc, open(os.path.join(dst, f"{tag}_{cfg}_pmc_sq.json"), "w"), indent=1)

@@ -500,13 +500,35 @@ def test_waterfall_backend_matches_plotting_py_numerics():
         w.push(line[:n])
         if k in (0, 5, 99, 129):
             img, bk, psd2 = w.image(60.0)
-            rimg, rbk, rpsd2 = so.waterfall_image(ref, cnt, 60.0)
-            assert img.shape == rimg.shape == (nfft, ncols) and w.wf_cnt == cnt
+            rimg, rbk, rpsd2 = so.waterfall_image(ref, cnt, 60.0, n)
+            assert img.shape == rimg.shape == (n, ncols) and w.wf_cnt == cnt
             assert abs(bk - rbk) <= 1e-5 * abs(rbk)
             assert np.allclose(psd2, rpsd2, rtol=1e-5)
             assert np.allclose(img, rimg, rtol=1e-5, atol=1e-3)
             assert np.array_equal(Waterfall.peaks(psd2.astype(np.float64), bk, 10.0, df),
                                   so.find_peaks_db(rpsd2, rbk, 10.0 / df)) or k != 129
+
+
+def test_waterfall_backend_equals_the_executed_reference_text():
+    """The device waterfall against tests/golden/waterfall_ref.npz (Plotting.py:385-388,536-548,
+    583-626,689-695 executed as they stand, see tests/test_oracle_pins.py): image (cropped to the
+    rows of the line pushed last, :618), background, averaged PSD, peaks."""
+    from pysdr_amd.waterfall import Waterfall
+    from tests.test_oracle_pins import _replay_waterfall_fixture
+    w = Waterfall(512, 100)
+    seen = 0
+    for k, (img, bk, psd2), g in _replay_waterfall_fixture(lambda line, flip: w.push(line, flip),
+                                                           lambda fc, df: w.shift_waterfall(fc, df),
+                                                           lambda dr, n: w.image(dr)):
+        ref = g[f"img{k}"]
+        assert w.wf_cnt == int(g[f"cnt{k}"]) and img.shape == ref.shape
+        assert abs(bk - float(g[f"bk{k}"])) <= 1e-5 * abs(float(g[f"bk{k}"]))
+        assert np.allclose(psd2, g[f"psd2_{k}"], rtol=1e-5)
+        assert np.allclose(img, ref, rtol=1e-5, atol=1e-3)
+        pk = Waterfall.peaks(psd2.astype(np.float64), bk, float(g["peak_dist"]), float(g["df"]))
+        assert np.array_equal(pk, g[f"peaks{k}"])
+        seen += 1
+    assert seen == 4
 
 
 def test_full_size_batch_is_independent_of_how_it_is_cut():

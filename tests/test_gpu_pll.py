@@ -152,3 +152,52 @@ def test_am_synch_carrier_pll_time_parallel_equals_the_serial_oracle():
     assert relerr(am[1024:], want[1024:]) <= TOL
     st = g.agc
     assert abs(st.gain - o.agc.gain) <= 1e-5 * o.agc.gain
+
+
+def test_full_size_c4_time_parallel_equals_the_serial_walk():
+    """BASELINE config #4 at the size and in the way bench.py times it: 2048 chunks x 213333 samples
+    (3.5 GB) resident in HBM, three consecutive calls of ONE continuous broadcast-FM stream (call k
+    reads the 1.7 M-sample loop from offset k * nsamp mod 1.7 M), ~2032 pilot-PLL segments per call,
+    the 13-tau warm-up from the previous call's mean phase increment from the second call on.  The
+    reference for every sample is the SAME build with the loop forced to its serial walk
+    (pysdr_set_pll_segments(ctx, 1): one wave, sample by sample) on a second context; the first two
+    chunks are also held against the serial NumPy oracle.  Order of operations: gui.py:1703-1704,
+    1759-1762."""
+    lib = _lib.lib()
+    L, B, nloop = 213333, 2048, 1700000
+    nsamp = B * L
+    seam = nsamp % nloop
+    assert seam % 2 == 0 and seam != 0
+    xu = wo.synth_wfm(10e6, nloop, 10)
+    nbuf = nsamp + nloop
+    d_x = C.c_void_p()
+    _lib.check(lib.pysdr_dev_alloc(0, nbuf * 8, C.byref(d_x)), "alloc")
+    try:
+        for off in range(0, nbuf, nloop):
+            n = min(nloop, nbuf - off)
+            _lib.check(lib.pysdr_dev_upload(0, C.c_void_p(d_x.value + off * 8), C.c_void_p(xu.ctypes.data), n * 8), "upload")
+        Pa, ga, ca = wfm_gpu(B)
+        Pb, gb, cb = wfm_gpu(B, serial=True)
+        for k in range(3):
+            off = (k * seam) % nloop
+            ca.process_batch(d_x.value + off * 8, B, L, on_device=True)
+            cb.process_batch(d_x.value + off * 8, B, L, on_device=True)
+            a, _, cna, pka = ca.fetch(0, B, want_iq=False)
+            b, _, cnb, pkb = cb.fetch(0, B, want_iq=False)
+            seg, pat = pll_stats(ca)
+            assert pll_stats(cb) == (1, 0)
+            assert seg >= 1900 and pat <= 2, (k, seg, pat)
+            assert np.array_equal(cna, cnb) and int(cna.sum()) == len(a) == len(b)
+            assert np.array_equal(pka, pkb)
+            skip = 1100 if k == 0 else 0            # discriminator start-up on an empty FIR (first chunk of the stream)
+            assert relerr(a[skip:], b[skip:]) <= TOL, (k, relerr(a[skip:], b[skip:]))
+            if k == 0:
+                o = wo.WfmReceiver(10e6, 48e3, 300e3, stereo=True, ntaps_dec=255, dtype=np.float32)
+                want = np.concatenate([o.demod_data(np.resize(xu, 2 * L)[j * L:(j + 1) * L]) for j in range(2)])
+                n2 = int(cna[:2].sum())
+                assert n2 == len(want)
+                assert relerr(a[1100:n2], want[1100:]) <= TOL
+        ca.close()
+        cb.close()
+    finally:
+        lib.pysdr_dev_free(0, d_x)

@@ -188,3 +188,45 @@ def test_waterfall_numerics_plotting_py():
     assert img.min() >= np.nanmax(wf - bk) - 60.0 - 1e-9
     rolled, fc = so.waterfall_roll(wf, 0.0, 3.2, 1.0)
     assert fc == 3.2 and np.array_equal(rolled, np.roll(wf, -3, axis=0))
+
+
+def _replay_waterfall_fixture(push, roll, image):
+    """Drive `push(line, flip)`, `roll(fc, df)`, `image(pan_dr, npsd) -> (img, bk, psd2)` through the
+    sequence of tests/golden/waterfall_ref.npz and yield (k, got, fixture) at its snapshots."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "waterfall_ref.npz"))
+    retune = dict(zip([int(k) for k in g["retune_k"]], [float(f) for f in g["retune_fc"]]))
+    snaps = set(int(k) for k in g["snap_k"])
+    df, flips = float(g["df"]), set(int(k) for k in g["flip_k"])
+    for k in range(len(g["lines"])):
+        n = int(g["lens"][k])
+        if k in retune:
+            roll(retune[k], df)
+        push(g["lines"][k][:n], k in flips)
+        if k in snaps:
+            yield k, image(float(g["pan_dr"]), n), g
+
+
+def test_oracle_waterfall_equals_the_executed_reference_text():
+    """tests/golden/waterfall_ref.npz = Plotting.py:385-388,536-548,583-626,689-695 EXECUTED as they
+    stand on 130 pushed lines (half-length lines, one RIG_IF<0 flip, two retunes, history wrapped):
+    tests/golden/make_waterfall_ref_golden.py, build container only.  The oracle's restatement gives
+    the same image, background, averaged PSD and peaks."""
+    st = dict(wf=-1e38 * np.ones((512, 100)), cnt=0, fc=0.0)
+
+    def push(line, flip):
+        line = np.asarray(line, np.float64)
+        st["wf"] = so.waterfall_push(st["wf"], line[::-1] if flip else line)
+        st["cnt"] = min(st["cnt"] + 1, 100)
+
+    def roll(fc, df):
+        st["wf"], st["fc"] = so.waterfall_roll(st["wf"], st["fc"], fc, df)
+
+    seen = 0
+    for k, (img, bk, psd2), g in _replay_waterfall_fixture(push, roll, lambda dr, n: so.waterfall_image(st["wf"], st["cnt"], dr, n)):
+        assert st["cnt"] == int(g[f"cnt{k}"])
+        assert img.shape == g[f"img{k}"].shape and np.array_equal(img.astype(np.float32), g[f"img{k}"])
+        assert bk == float(g[f"bk{k}"]) and np.array_equal(psd2, g[f"psd2_{k}"])
+        assert np.array_equal(so.find_peaks_db(psd2, bk, float(g["peak_dist"]) / float(g["df"])), g[f"peaks{k}"])
+        seen += 1
+    assert seen == 4
