@@ -382,10 +382,7 @@ def verify_rank(cfg, ctx, rxs, rx_idx, xu, nloop, seam, nsamp, L, B, steps_done,
             am, iq, cn, _pk = ctx.fetch(i, B)
             n = int(cn[:nchk].sum())
             wa, wi = np.concatenate(want_am[i]), np.concatenate(want_iq[i])
-            skip = 0
-            if prime == 0 and (o.mode in ('NFM', 'WFM', 'WFM2')):
-                skip = min(len(wa), 300 if o.mode == 'NFM' else 1100)   # discriminator on an empty FIR (tests/test_gpu_parity.py)
-            e_am = _relerr(am[:n][skip:], wa[skip:])
+            e_am = _relerr(am[:n], wa)
             e_iq = _relerr(iq[:n], wi)
             counts_ok = [int(v) for v in cn[:nchk]] == [len(a) for a in want_am[i]]
             worst = max(worst, e_am, e_iq)

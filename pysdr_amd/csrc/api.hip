@@ -44,6 +44,8 @@ PllPlan plan_pll(int n, double fs, double bw_hz, double taus, double taus_fast, 
   const double tau = fs / (kPllZetaPlan * 2.0 * M_PI * bw_hz);
   p.W = ((int)std::ceil(taus * tau) + 63) & ~63;
   p.Wfast = taus_fast > 0 ? (((int)std::ceil(taus_fast * tau) + 63) & ~63) : 0;
+  p.Wexact = 0;
+  p.coarse_sweeps = 0;
   if (n < 3 * p.W || k_max <= 1) {
     p.K = 1;
     p.T = (std::max(n, 64) + 63) & ~63;
@@ -144,6 +146,13 @@ struct pysdr_ctx {
   int dbg_flags = 0, yflush_cap = 0;      // tuning / diagnostic switches, read from the environment once
   int skew_override = -1;                 // PYSDR_MIXDEC_SKEW=0/1: force the tap-schedule skew off / on (A/B runs)
   int pll_kmax = 0;                       // pysdr_set_pll_segments: 0 = default, 1 = serial
+  // pilot-PLL segmentation (PYSDR_WFM_PLL = "taus,taus_fast,taus_exact,coarse_sweeps,kmax,tmin" overrides for A/B runs)
+  // measured on MI355X (bench.py --workload c4, scripts/diag/pll_sweep.sh; front end ms per 2048 chunks):
+  //   exact warm-ups 1.70 | 3 coarse sweeps + 6 / 5 / 4 tau exact 1.56 / 1.57 / 1.54 | 4 sweeps 1.61 | 2 sweeps: every join
+  //   misses (180 ms of serial patching) | 3 sweeps + 3 tau exact: 115 joins miss | fast warm-up 11 / 9 tau: the check pass
+  //   redoes the call (1.85 / 2.4) | 4096 / 3072 / 1024 segments with exact warm-ups 1.96 / 1.78 / 1.71 (2048: 1.70)
+  double wfm_taus = 20.0, wfm_taus_fast = 13.0, wfm_taus_exact = 5.0;
+  int wfm_coarse_sweeps = 3, wfm_kmax = 2048, wfm_tmin = 2048;
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
   hipEvent_t ev[kSlots][4] = {};
@@ -544,6 +553,18 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) c->wgs_per_cu = atoi(e); }
   { const char* e = getenv("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0) c->yflush_cap = atoi(e); }
   { const char* e = getenv("PYSDR_MIXDEC_SKEW"); if (e && *e) c->skew_override = atoi(e) ? 1 : 0; }
+  { const char* e = getenv("PYSDR_WFM_PLL");
+    if (e && *e) {
+      double a = c->wfm_taus, b = c->wfm_taus_fast, x = c->wfm_taus_exact;
+      int sw = c->wfm_coarse_sweeps, km = c->wfm_kmax, tm = c->wfm_tmin;
+      const int got = sscanf(e, "%lf,%lf,%lf,%d,%d,%d", &a, &b, &x, &sw, &km, &tm);
+      if (got >= 1 && a > 0) c->wfm_taus = a;
+      if (got >= 2 && b >= 0) c->wfm_taus_fast = b;
+      if (got >= 3 && x > 0) c->wfm_taus_exact = x;
+      if (got >= 4 && sw >= 0) c->wfm_coarse_sweeps = sw;
+      if (got >= 5 && km >= 1) c->wfm_kmax = std::min(km, kPllSegMax);
+      if (got >= 6 && tm >= 64) c->wfm_tmin = tm;
+    } }
 #ifdef PYSDR_DIAG
   // work-skipping ablation switches exist only in a diagnostic build (python -m pysdr_amd.build --diag)
   { const char* e = getenv("PYSDR_DEBUG_FLAGS"); c->dbg_flags = e ? atoi(e) : 0; }
@@ -919,7 +940,13 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     // the call's initial state free-running, 60-270 after 32768 samples = 17.5 tau (one segment in
     // 200 beyond the 512-word tolerance: 20 tau); from the previous call's MEAN increment (the loop
     // follows a crystal, so its phase is a straight line plus a bounded wobble) 54 after 13 tau
-    w.pll = plan_pll(n1, fs1, kWfmPllBwHz, 20.0, 13.0, 2048, c->pll_kmax > 0 ? std::min(c->pll_kmax, 2048) : 2048, c->d_pllseg);   // two waves per SIMD: a lone wave issues one dependent VALU op per 12 cycles
+    w.pll = plan_pll(n1, fs1, kWfmPllBwHz, c->wfm_taus, c->wfm_taus_fast, c->wfm_tmin,
+                     c->pll_kmax > 0 ? std::min(c->pll_kmax, c->wfm_kmax) : c->wfm_kmax, c->d_pllseg);
+    if (c->wfm_coarse_sweeps > 0 && w.pll.K > 1) {
+      const double tau = fs1 / (kPllZetaPlan * 2.0 * M_PI * kWfmPllBwHz);
+      w.pll.Wexact = ((int)std::ceil(c->wfm_taus_exact * tau) + 63) & ~63;
+      w.pll.coarse_sweeps = c->wfm_coarse_sweeps;
+    }
     rc = launch_wfm(w, c->stream);
     if (rc) return rc;
     const uint32_t zero = 0u;

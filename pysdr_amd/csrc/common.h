@@ -107,6 +107,9 @@ struct RxDevState {       // one per RX, lives in device memory
 struct PllPlan {
   int K, T, W;
   int Wfast;                // shorter warm-up for calls that start from the previous call's mean increment (0: none)
+  int Wexact;               // the last Wexact samples of a warm-up run to the bit-exact fixed point like the segment itself;
+                            // what lies in front of them gets `coarse_sweeps` sweeps per block (0: the whole warm-up is exact)
+  int coarse_sweeps;
   uint32_t* seg;            // [nrx][K][4]: S.phase, S.w, E.phase, E.w (float fields as bits)
 };
 

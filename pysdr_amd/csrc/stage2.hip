@@ -666,9 +666,13 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
 // broadcast FM (max 10) against 64 dependent steps of ten instructions each, 37 -> ~10 ns per sample.
 // The integrator is summed in scan order instead of sample by sample: up to ~370 words of 2^32 =
 // 5e-7 rad away from the sample-by-sample float32 walk of the oracle, inside the 1e-5 audio bar.
+// max_it < 66: a COARSE walk for the early part of a warm-up -- after s sweeps the block's phases are
+// off by about 0.06^s of the first guess's error (the loop gain over 64 samples), i.e. two sweeps leave
+// ~1e-5 rad per block, which the exact tail of the warm-up (6 loop time constants: e^-6) forgets to
+// below the 512-word join tolerance.  The patch-up pass still checks every join.
 template <bool EMIT>
 __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restrict__ o, int i_begin, int i_end,
-                                             uint32_t& ph0, float& w0, int lane) {
+                                             uint32_t& ph0, float& w0, int lane, int max_it = 66) {
   float m_next = (i_begin + lane < i_end) ? o[i_begin + lane].x : 0.f;
   for (int i0 = i_begin; i0 < i_end; i0 += 64) {
     const float m = m_next;
@@ -679,7 +683,7 @@ __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restric
     uint32_t ph = ph0 + (uint32_t)lane * inc0;             // guess: free running at the integrator's rate
     uint32_t tot = 0u;
     float wj = w0;
-    for (int it = 0; it < 66; ++it) {
+    for (int it = 0; it < max_it; ++it) {
       const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
       const float c = __builtin_amdgcn_cosf(rev);
       const float e = (lane < count) ? __fmul_rn(__fmul_rn(m, c), a.norm) : 0.f;
@@ -695,7 +699,9 @@ __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restric
     if (EMIT && lane < count) {
       const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
       const float s2 = __builtin_amdgcn_sinf(2.f * rev);
-      o[i0 + lane] = make_float2(m, __fmul_rn(m, __fmul_rn(2.f, s2)));
+      // only the carrier product is stored: .x already holds mpx (wfm_disc_kernel), and the warm-ups of
+      // neighbouring segments are reading it meanwhile -- no location is both read and written here
+      reinterpret_cast<float*>(o + i0 + lane)[1] = __fmul_rn(m, __fmul_rn(2.f, s2));
     }
     ph0 = ph0 + (uint32_t)__builtin_amdgcn_readlane((int)tot, count - 1);
     w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wj), count - 1));
@@ -709,8 +715,8 @@ __device__ __forceinline__ bool wfm_state_differs(uint32_t ph_a, float w_a, uint
   return !(d <= 512 && d >= -512 && fabsf(w_a - w_b) <= 1.0e-9f);
 }
 
-// grid (K, nrx): segment k of RX r.  The warm-up re-reads mpx values other segments are
-// rewriting in place as (mpx, carrier): the .x they read is the same bits before and after.
+// grid (K, nrx): segment k of RX r.  The warm-ups read the .x (mpx) of samples whose .y (carrier
+// product) other segments are storing: disjoint words.
 __global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
   const int r = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
   if (!a.stereo[r]) return;
@@ -739,7 +745,12 @@ __global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
   } else {
     wb = 0;
   }
-  if (wb < s0) wfm_pll_walk<false>(a, a.w[r], wb, s0, ph, w, lane);
+  if (wb < s0) {
+    // coarse sweeps first, the last Wexact samples exactly (both bounds on multiples of 64)
+    const int sx = (pl.coarse_sweeps > 0 && s0 - pl.Wexact > wb) ? s0 - pl.Wexact : wb;
+    if (wb < sx) wfm_pll_walk<false>(a, a.w[r], wb, sx, ph, w, lane, pl.coarse_sweeps);
+    wfm_pll_walk<false>(a, a.w[r], sx, s0, ph, w, lane);
+  }
   uint32_t* sg = pl.seg + ((size_t)r * pl.K + k) * 4;
   if (lane == 0) { sg[0] = ph; sg[1] = __float_as_uint(w); }
   wfm_pll_walk<true>(a, a.w[r], s0, s1, ph, w, lane);

@@ -42,8 +42,7 @@ def test_four_rx_loop_with_short_reads_and_stereo_routing():
     Po, ao = run_exec(cfg, 4, oracle_dsp, 32, audio=2)
     for a, b in zip(ag, ao):
         assert a.shape == b.shape and np.iscomplexobj(a)
-        # NFM start-up samples are ill-conditioned (see test_gpu_parity): skip them
-        assert np.max(np.abs(a[300:] - b[300:])) <= 1e-5 * np.max(np.abs(b))
+        assert np.max(np.abs(a - b)) <= 1e-5 * np.max(np.abs(b))          # every sample, start-up included
 
 
 def test_recorded_iq_replayed_in_batches_matches_the_chunked_oracle(tmp_path):
@@ -112,8 +111,7 @@ def test_recorded_iq_replayed_in_batches_matches_the_chunked_oracle(tmp_path):
     for i in range(len(rxs)):
         a, b = np.concatenate(got[i]), np.concatenate(want[i])
         assert a.shape == b.shape
-        skip = 300 if cfg['rx'][i]['mode'] == 'NFM' else 0       # see test_gpu_parity: start-up samples
-        assert np.max(np.abs(a[skip:] - b[skip:])) <= 1e-5 * np.max(np.abs(b)), i
+        assert np.max(np.abs(a - b)) <= 1e-5 * np.max(np.abs(b)), i
 
 
 def test_ingest_ring_pipelined_run_equals_the_synchronous_run():
@@ -164,4 +162,4 @@ def test_ingest_ring_pipelined_run_equals_the_synchronous_run():
     assert np.allclose(po, pb, rtol=1e-6, atol=0)
     for u, v in zip(ao, ab):
         assert u.shape == v.shape
-        assert np.max(np.abs(u[300:] - v[300:])) <= 1e-5 * np.max(np.abs(u))     # NFM start-up skipped, see test_gpu_parity
+        assert np.max(np.abs(u - v)) <= 1e-5 * np.max(np.abs(u))

@@ -67,9 +67,8 @@ got = multi.run_sharded([x], make_rx, L, nchunks, None, mode="rx", nrx=len(cfg["
 for i, rx in enumerate(so.make_receivers(cfg, np.float32)):
     want = np.concatenate([rx.demod_data(x[k * L:(k + 1) * L]) for k in range(nchunks)])
     a = got[(0, i)]
-    skip = 300 if cfg["rx"][i]["mode"] == "NFM" else 0
     assert a.shape == want.shape
-    assert np.max(np.abs(a[skip:] - want[skip:])) <= 1e-5 * np.max(np.abs(want)), cfg["rx"][i]["mode"]
+    assert np.max(np.abs(a - want)) <= 1e-5 * np.max(np.abs(want)), cfg["rx"][i]["mode"]
 print("RX_SPLIT_OK")
 """
 
