@@ -67,6 +67,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive ingest-ring figure")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks timed on the CPU oracle (0 = about 10 s worth)")
+    ap.add_argument("--psd-hz", type=float, default=20.0,
+                    help="c3, 1 GPU: also time the job with ONE 64k PSD frame per SRATE/psd_hz samples -- the reference's real "
+                         "duty (20 Hz timer, pySDR.py:252-256, gui.py:1264-1267) -- reported as `at_reference_psd_duty`, never as "
+                         "`value`; 0 = skip")
     ap.add_argument("--verify", dest="verify", action="store_true", default=None,
                     help="after the timed loop every rank checks the LAST step's device buffers against the float32 "
                          "oracle (first 2 chunks per sub-receiver, PSD frame 0); default ON when --gpus > 1")
@@ -612,6 +616,12 @@ def main():
         k1.append(ms.value)
         _lib.check(lib.pysdr_get_elapsed_ms(ctx.h, 1, back, C.byref(ms)), "elapsed")
         k2.append(ms.value)
+    # per-step spread of the timed loop (the step period on the stream: start of call k-1 -> start of call k,
+    # which includes whatever the PSD ordered behind / in front of it took)
+    periods = []
+    for back in range(max(0, min(args.steps - 1, 62)) if nev else 0):
+        if lib.pysdr_get_elapsed_ms(ctx.h, 3, back, C.byref(ms)) == 0:
+            periods.append(ms.value)
     k1_ms = float(np.mean(k1)) if k1 else float('nan')
     k2_ms = float(np.mean(k2)) if k2 else None
     psd_ms = None
@@ -648,6 +658,37 @@ def main():
                 v["ok"] = bool(v["ok"] and v["bcast_equals_root"])
         verify = dict(verified_ranks=sum(1 for v in allv if v["ok"]),
                       worst_rel=max(v["worst_rel"] for v in allv), tol=VERIFY_TOL, ranks=allv)
+
+    # ---- the reference's real PSD duty next to the headline (never `value`): the GUI's 20 Hz timer
+    # takes one 32768-sample chunk per tick and flushes the backlog (pySDR.py:252-256, gui.py:1264-1267),
+    # i.e. one 64k frame per SRATE/20 samples; everything else of the step is unchanged
+    duty = None
+    if sp is not None and world == 1 and args.psd_hz > 0 and not args.no_demod and not args.overlap_psd:
+        hop20 = int(round(cfg['fs'] / args.psd_hz))
+        nf20 = (nsamp - PSD_CHUNK) // hop20 + 1
+
+        def step20():
+            ctx.process_batch(d_x.value, B, L, on_device=True)
+            _lib.check(lib.pysdr_spectrum_order(sp, ctx.h, 0 if args.serial_psd else 2), "spectrum_order")
+            _lib.check(lib.pysdr_spectrum_batch(sp, d_x, nf20, hop20, d_psd), "spectrum_batch")
+            _lib.check(lib.pysdr_spectrum_order(sp, ctx.h, 1), "spectrum_order")
+
+        for _ in range(min(args.warmup, 3)):
+            step20()
+        sync()
+        t20 = time.perf_counter()
+        for _ in range(args.steps):
+            step20()
+        sync()
+        dt20 = (time.perf_counter() - t20) / args.steps
+        _lib.check(lib.pysdr_spectrum_elapsed_ms(sp, C.byref(ms)), "psd elapsed")
+        bps20 = 8.0 + nrx_total * (P.UP / P.DOWN) * 12.0 + 4.0 * PSD_NFFT / hop20
+        duty = {"value": nsamp / dt20 / 1e6, "unit": "MS/s", "ms_per_step": dt20 * 1e3, "psd_hz": args.psd_hz,
+                "frames_per_step": int(nf20), "hop_samples": hop20, "psd_call_ms": ms.value,
+                "roofline_job": {"bound": "hbm", "achieved": nsamp / dt20 * bps20 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": nsamp / dt20 * bps20 / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_sample": bps20},
+                "note": "same step as `value` but ONE 64k PSD frame per SRATE/psd_hz samples, the duty pySDR's 20 Hz GUI timer "
+                        "really runs at (BASELINE.md: 8.8 B/sample); `value` PSDs every sample"}
 
     pll = None
     if 'wfm' in cfg and rxs:
@@ -732,6 +773,10 @@ def main():
             "algorithmic_bytes_per_sample": bytes_per_sample_job,
             "note": "per GPU: whole-step wall clock against SURVEY 8(d)'s compulsory bytes per input sample"},
         "kernel_ms": {"front": k1_ms if k1 else None, "stage2": k2_ms, "psd_call": psd_ms},
+        "step_ms_stats": ({"min": float(np.min(periods)), "median": float(np.median(periods)), "max": float(np.max(periods)),
+                           "n": len(periods), "front_min": float(np.min(k1)), "front_max": float(np.max(k1)),
+                           "what": "HIP-event period between consecutive steps on the context's stream over the timed loop"}
+                          if periods else None),
         "pilot_pll": pll,
         "tuning": {"diag_build": int(tune[0]), "debug_flags": int(tune[1]), "mixdec_wgs_per_cu": int(tune[2]),
                    "mixdec_yflush_cap": int(tune[3]), "tile_bytes": int(tune[4]), "threads": int(tune[5]),
@@ -741,6 +786,8 @@ def main():
                    "argv": " ".join(sys.argv[1:])},
         "source_sha256": {s: source_sha(s) for s in ("mixdec.hip", "psdfft.hip", "stage2.hip", "api.hip")},
     }
+    if duty is not None:
+        out["at_reference_psd_duty"] = duty
     if verify is not None:
         out["verified_ranks"] = verify["verified_ranks"]
         out["verify_worst_rel"] = verify["worst_rel"]

@@ -132,7 +132,11 @@ int pysdr_set_agc(pysdr_ctx* ctx, int irx, int enable, float ref);
 int pysdr_process(pysdr_ctx* ctx, const float* iq_interleaved, size_t n, pysdr_out* outs);
 
 /* Same arithmetic on `nchunks` consecutive chunks of `chunk_len` samples in one
- * launch sequence; results are identical to nchunks pysdr_process() calls.
+ * launch sequence; results are identical, bit for bit, to nchunks pysdr_process() calls -- except
+ * in the two modes with a serial loop (AM-Synch carrier PLL, WFM2 pilot PLL): a long call runs the
+ * loop in segments whose joins are accepted within 2e-6 rad / 512 words of 2^32 of phase, so there
+ * the audio equals the chunk-by-chunk run within the 1e-5 parity bar, not bitwise
+ * (pysdr_set_pll_segments(ctx, 1) forces the serial walk).
  * on_device != 0: iq is a device pointer (pysdr_dev_alloc) -- the replay path
  * (receiver.py:541-559) and the throughput benchmark. */
 int pysdr_process_batch(pysdr_ctx* ctx, const void* iq, int nchunks, size_t chunk_len, int on_device);
@@ -145,7 +149,9 @@ int pysdr_sync(pysdr_ctx* ctx);
 
 /* Per-call timing with HIP events recorded on the context's stream (a ring of the last
  * 64 calls; back = 0 is the most recent call): which = 0 mix+decimate kernel,
- * 1 detector/AF/AGC kernels, 2 whole call.  Events are only recorded while enabled. */
+ * 1 detector/AF/AGC kernels, 2 whole call, 3 from the start of the call before it to the start of
+ * this one (the period of a step when calls follow each other on the stream).  Events are only
+ * recorded while enabled. */
 int pysdr_set_profile(pysdr_ctx* ctx, int enable);
 int pysdr_get_elapsed_ms(pysdr_ctx* ctx, int which, int back, float* ms);
 /* tuning knob: LDS bytes of input tile per workgroup in the mix+decimate kernel */

@@ -198,6 +198,7 @@ struct pysdr_ingest {
   std::vector<float*> h_am, h_iq;         // [nslots*MAX_RX] pinned
   std::vector<float*> h_peak;             // [nslots] pinned
   std::vector<int> n_out, in_flight, n_chunks;
+  std::vector<int> nrx;                   // [nslots] sub-receivers of the slot's submit (pysdr_rx_add may run before its collect)
   std::vector<std::vector<int>> chunk_nout;     // [nslots][chunks of the slot's last submit]
   std::vector<int> cx;                    // [nslots*MAX_RX]
   unsigned long long seq = 0;
@@ -807,8 +808,8 @@ int pysdr_set_tile(pysdr_ctx* c, int tile_bytes, int threads) {
 }
 
 int pysdr_get_elapsed_ms(pysdr_ctx* c, int which, int back, float* ms) {
-  if (!c || !ms || which < 0 || which > 2 || back < 0 || back >= pysdr_ctx::kSlots) return PYSDR_ERR_ARG;
-  if ((unsigned long long)back >= c->ncalls) { set_last_error("pysdr_get_elapsed_ms: no such call"); return PYSDR_ERR_STATE; }
+  if (!c || !ms || which < 0 || which > 3 || back < 0 || back >= pysdr_ctx::kSlots - (which == 3 ? 1 : 0)) return PYSDR_ERR_ARG;
+  if ((unsigned long long)back + (which == 3 ? 1u : 0u) >= c->ncalls) { set_last_error("pysdr_get_elapsed_ms: no such call"); return PYSDR_ERR_STATE; }
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   hipEvent_t* ev = c->ev[(c->ncalls - 1 - back) % pysdr_ctx::kSlots];
@@ -816,6 +817,10 @@ int pysdr_get_elapsed_ms(pysdr_ctx* c, int which, int back, float* ms) {
   hipEvent_t a = ev[0], b = ev[1];
   if (which == 1) { a = ev[1]; b = ev[2]; }
   if (which == 2) { a = ev[0]; b = ev[3]; }
+  if (which == 3) {              // start of the previous call -> start of this one: the period of a step
+    a = c->ev[(c->ncalls - 2 - back) % pysdr_ctx::kSlots][0];
+    b = ev[0];
+  }
   PYSDR_HIP_CHECK(hipEventElapsedTime(ms, a, b));
   return PYSDR_OK;
 }
@@ -1404,6 +1409,7 @@ int pysdr_ingest_create_batched(pysdr_ctx* c, int nslots, int chunks_per_slot, p
   g->n_out.assign(nslots, 0);
   g->in_flight.assign(nslots, 0);
   g->n_chunks.assign(nslots, 0);
+  g->nrx.assign(nslots, 0);
   g->chunk_nout.assign(nslots, std::vector<int>());
   g->cx.assign((size_t)nslots * PYSDR_MAX_RX, 0);
   for (int s = 0; s < nslots; ++s) {
@@ -1456,6 +1462,7 @@ int pysdr_ingest_submit(pysdr_ingest* g, int slot, size_t n) {
   const int nout = c->last_nout;
   if (nout > g->ocap) { set_last_error("pysdr_ingest_submit: %d outputs > capacity %d", nout, g->ocap); return PYSDR_ERR_STATE; }
   g->n_out[slot] = nout;
+  g->nrx[slot] = c->last_nrx;
   for (int r = 0; r < c->last_nrx; ++r) {
     const int cx = c->last_complex[r];
     g->cx[(size_t)slot * PYSDR_MAX_RX + r] = cx;
@@ -1498,7 +1505,7 @@ int pysdr_ingest_collect(pysdr_ingest* g, int slot, pysdr_out* outs) {
   int rc = use_device(g->c->cfg.device);
   if (rc) return rc;
   PYSDR_HIP_CHECK(hipEventSynchronize(g->ev_done[slot]));
-  for (int r = 0; r < g->c->last_nrx; ++r) {
+  for (int r = 0; r < g->nrx[slot]; ++r) {        // the RX set of THIS slot's submit, not of the latest call
     outs[r].am = g->h_am[(size_t)slot * PYSDR_MAX_RX + r];
     outs[r].iq = g->h_iq[(size_t)slot * PYSDR_MAX_RX + r];
     outs[r].cap = g->ocap;

@@ -866,6 +866,23 @@ int launch_demod_fir(const Stage2Args& a, hipStream_t st) {
   const int H = fir_taps_padded(a.ntaps);
   const int EP = (fir_pad(kFirOut + H + 12) + 3) & ~3;
   const size_t lds = (size_t)(2 * EP + 4 * H) * sizeof(float);
+  // pysdr_create accepts ntaps_af <= 2048: from 1993 taps on the staged detector output + the four tap
+  // arrays pass the 64 KB a kernel gets without asking (66.8 KB at 2048).  The attribute is per
+  // (function, device), as in launch_rj (mixdec.hip).
+  if (lds > 48 * 1024) {
+    static std::mutex attr_mu;
+    static uint64_t attr_done = 0;
+    int dev = 0;
+    PYSDR_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(attr_mu);
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+      PYSDR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(demod_fir_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      PYSDR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(demod_fir_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done |= 1ull << (dev & 63);
+    }
+  }
   for (int cplx = 0; cplx < 2; ++cplx) {
     Stage2Args b = a;
     int n = 0;

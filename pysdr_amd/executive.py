@@ -231,6 +231,9 @@ class SDR_EXECUTIVE:
             P.RX_DONE = P.RX_DONE or t >= P.DURATION
         self.quit_rx()
 
+    # NOTE (AM-Synch / WFM2): a slot of several chunks runs the serial PLL in segments with joins accepted
+    # within a tolerance (include/pysdr_hip.h, pysdr_process_batch): batched == chunk by chunk within the
+    # 1e-5 parity bar there, bit for bit in every other mode.
     def Run_pipelined(self, on_chunk=None, nslots=3, batch_chunks=1):
         """``Run`` with the ingest ring (N4): ``self.x`` is (a chunk of) a pinned ring slot, the slot
         is submitted asynchronously and its audio is post-processed one slot later, while the next

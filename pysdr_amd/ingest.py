@@ -31,6 +31,7 @@ class IngestRing:
         if not hasattr(ctx, '_rings'):
             ctx._rings = []
         ctx._rings.append(self)
+        self._nrx = {}               # slot -> sub-receivers at its submit
         self._bufs = []
         for s in range(self.nslots):
             p = C.POINTER(C.c_float)()
@@ -48,6 +49,7 @@ class IngestRing:
         for rx in self.ctx.receivers:
             rx._sync_controls()
         check(self.L.pysdr_ingest_submit(self.h, slot, n), "pysdr_ingest_submit")
+        self._nrx[slot] = len(self.ctx.receivers)
         self.ctx.seq += max(1, n // max(1, int(self.ctx.cfg.in_chunk)))
 
     def chunks(self, slot):
@@ -61,8 +63,9 @@ class IngestRing:
 
     def collect(self, slot):
         """-> [(am, iq, peak_in)] per sub-receiver (copies: the slot may be reused at once)."""
-        nrx = len(self.ctx.receivers)
-        outs = (_lib.Out * nrx)()
+        # the sub-receivers the slot was SUBMITTED with (a receiver added since then has no result in it)
+        nrx = self._nrx.get(slot, len(self.ctx.receivers))
+        outs = (_lib.Out * max(nrx, 1))()
         check(self.L.pysdr_ingest_collect(self.h, slot, outs), "pysdr_ingest_collect")
         res = []
         for r in range(nrx):

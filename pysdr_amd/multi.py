@@ -129,7 +129,10 @@ class DeviceRxSplit:
         L = self._lib.lib()
         if self.rank == self.root:
             x = np.ascontiguousarray(x, np.complex64)
-            # a blocking copy: the kernels of the previous step were synchronised by fetch()
+            # the context's stream is non-blocking, so the (null-stream) upload is not ordered against the
+            # kernels of the previous step that still read d_buf: wait for them here rather than rely on
+            # the caller having fetched (a root without local receivers, a PSD consumer, ...)
+            self._lib.check(L.pysdr_sync(self.ctx.h), "pysdr_sync")
             self._lib.check(L.pysdr_dev_upload(self.device, self.d_buf, C.c_void_p(x.ctypes.data), n * 8),
                             "pysdr_dev_upload")
         self.bc.bcast(self.d_buf.value, n * 8, self.root)

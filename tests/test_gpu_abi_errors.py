@@ -225,3 +225,28 @@ def test_batched_ingest_ring_misuse():
     _lib.check(lib.pysdr_ingest_collect(ing, 1, outs), "collect")
     lib.pysdr_ingest_destroy(ing)
     lib.pysdr_destroy(h)
+
+
+@pytest.mark.parametrize("ntaps_af", [2048, 1993, 1000])
+def test_af_filter_length_up_to_the_bound_pysdr_create_accepts(ntaps_af):
+    """pysdr_create takes ntaps_af <= 2048, and from 1993 taps on the AF FIR kernel asks for
+    more than 64 KB of dynamic LDS (66.8 KB at 2048): every length the context accepts must run, and
+    give the oracle's audio."""
+    import numpy as np
+    from oracle import sdr_oracle as so
+    from tests.test_gpu_parity import make_gpu_receivers, relerr
+    cfg = dict(so.CONFIGS['C1'], ntaps_dec=255,
+               rx=[dict(frq=100e3, mode='AM', video_bw=10e3, af_bw=5e3), dict(frq=100e3, mode='IQ', video_bw=10e3, af_bw=5e3)])
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    x = so.synth_iq(cfg, 4 * L, 3)
+    P, g = make_gpu_receivers(cfg, af_filt_len=ntaps_af)
+    o = so.make_receivers(cfg, np.float32, ntaps_af=ntaps_af)
+    for k in range(4):
+        for rg, ro in zip(g, o):
+            a, b = rg.demod_data(x[k * L:(k + 1) * L]), ro.demod_data(x[k * L:(k + 1) * L])
+            assert relerr(a, b) <= 1e-5, (ntaps_af, ro.mode, k)
+    # one past the bound is refused at creation, with a message
+    from pysdr_amd import _lib
+    cfgc = _lib.Cfg(2.048e6, 3, 128, L, 1, 255, 2049, 0, 0)
+    h = C.c_void_p()
+    assert _lib.lib().pysdr_create(C.byref(cfgc), C.byref(h)) != 0

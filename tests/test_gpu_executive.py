@@ -163,3 +163,31 @@ def test_ingest_ring_pipelined_run_equals_the_synchronous_run():
     for u, v in zip(ao, ab):
         assert u.shape == v.shape
         assert np.max(np.abs(u - v)) <= 1e-5 * np.max(np.abs(u))
+
+
+def test_am_synch_batched_slots_equal_the_chunked_run_within_the_parity_bar():
+    """with a serial loop in the chain (AM-Synch carrier PLL) a slot of several chunks runs it
+    in segments whose joins are accepted within a tolerance, so Run_pipelined(batch_chunks > 1) equals
+    the chunk-by-chunk Run within the 1e-5 bar (not bitwise, unlike the other modes) -- and the oracle's
+    serial loop within the same bar."""
+    cfg = dict(so.CONFIGS['C1'], ntaps_dec=255, rx=[dict(frq=100e3 - 5.0, mode='AM-Synch', video_bw=10e3, af_bw=5e3)])
+    nchunks = 32
+
+    def run(pipelined, dsp=None, batch=1):
+        P = make_P(cfg, nchunks, max_batch_chunks=max(batch, 1))
+        L = P.IN_CHUNK_SIZE
+        P.sdr = stream.SynthSDR(cfg, seed=61, nsamp=(nchunks + 1) * L, read_pattern=(1.0,))
+        ex = executive.SDR_EXECUTIVE(P, dsp=dsp)
+        P.rx[0].mode, P.rx[0].af_bw = 'AM-Synch', 5e3
+        if pipelined:
+            ex.Run_pipelined(batch_chunks=batch)
+        else:
+            ex.Run()
+        return P.players[0].rb.pull(P.players[0].rb.nsamps)
+
+    a = run(False)
+    b = run(True, batch=32)
+    o = run(False, dsp=oracle_dsp)
+    assert a.shape == b.shape == o.shape and len(a) >= nchunks * 1023
+    assert np.max(np.abs(a - b)) <= 1e-5 * np.max(np.abs(a))
+    assert np.max(np.abs(b - o)) <= 1e-5 * np.max(np.abs(o))

@@ -71,6 +71,28 @@ def make_gpu_receivers(cfg, **kw):
     return P, rxs
 
 
+def nfm_rounding_allowance(ro, iq_all):
+    """What the NFM audio may differ by, per sample, beyond TOL * peak: zero, except where the AF
+    filter's window holds a discriminator output that is ILL-CONDITIONED -- and then exactly its
+    condition number's worth.  fm[n] = Im(conj(y[n]) (y[n+1] - y[n-1])) / (2 |y[n]|^2) (sigs/nfm.m:
+    124-127): a relative rounding eps of the three inputs moves it by eps (|y[n+1]| + |y[n-1]|) / |y[n]|.
+    That ratio is 2 on a steady carrier and 2000 at n = 0 of a stream whose decimator is still filling
+    (the reference's default 1001-tap prototype, params.py:134: |y[0]|^2 = 1.4e-7 of the steady power,
+    y[0] and y[1] nearly parallel) -- measured there: the kernels' d[0] is 1.2e-5 of itself away from the
+    float32 oracle's, whose own y[1] happens to be ten times closer to the float64 one.  Samples on a
+    step of more than 4x in amplitude (ratio > 8) are allowed 4 eps32 x ratio through |taps|; all others
+    get nothing, so the steady-state bar stays 1e-5.  Rounds 1-2 skipped the first 271 outputs
+    wholesale; here EVERY sample is compared."""
+    ntaps = ro.demod.ntaps
+    ybuf = np.abs(np.concatenate((np.zeros(ntaps + 1, np.complex128), np.asarray(iq_all, np.complex128))))
+    ya, y1, yb = ybuf[:-2], ybuf[1:-1], ybuf[2:]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ratio = np.where(y1 > 0, (ya + yb) / y1, 0.0)
+    scale = ro.demod.fs_out / (2 * np.pi * so.NFM_FULL_SCALE_DEV)
+    a = np.where(ratio > 8.0, scale * 4 * 2.0 ** -24 * ratio, 0.0)
+    return np.convolve(a, np.abs(np.asarray(ro.demod.taps, np.complex128)), mode='valid')
+
+
 def run_both(cfg, chunks, seed, check_every=True):
     x = so.synth_iq(cfg, sum(chunks), seed)
     L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
@@ -78,6 +100,7 @@ def run_both(cfg, chunks, seed, check_every=True):
     o = so.make_receivers(cfg, np.float32)
     pos = 0
     worst = {}
+    iq_seen, pk = [[] for _ in g], {}
     for c in chunks:
         xc = x[pos:pos + c]
         pos += c
@@ -85,7 +108,17 @@ def run_both(cfg, chunks, seed, check_every=True):
             am_g = rg.demod_data(xc)
             am_o = ro.demod_data(xc)
             e_iq = relerr(rg.iq, ro.iq)
-            e_am = relerr(am_g, am_o)                   # every sample of every chunk, start-up included
+            # every sample of every chunk, start-up included
+            assert am_g.shape == am_o.shape
+            if ro.mode == 'NFM' and len(am_o):
+                iq_seen[i].append(np.array(ro.iq))
+                allow = nfm_rounding_allowance(ro, np.concatenate(iq_seen[i]))[-len(am_o):]
+                # peak of the legitimate audio (the transient itself is hundreds of full scales)
+                pk[i] = max(pk.get(i, 0.0), float(np.max(np.abs(am_o[allow == 0]))) if np.any(allow == 0) else 0.0)
+                excess = np.maximum(np.abs(am_g - am_o) - allow, 0.0)
+                e_am = float(np.max(excess) / (pk[i] if pk[i] > 0 else 1.0))      # full scale = 1.0 until real audio has been seen
+            else:
+                e_am = relerr(am_g, am_o)
             worst[i] = max(worst.get(i, 0.0), e_iq, e_am)
             assert e_iq <= TOL, (i, ro.mode, 'iq', e_iq)
             assert e_am <= TOL, (i, ro.mode, 'am', e_am)
