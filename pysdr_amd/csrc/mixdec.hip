@@ -27,6 +27,7 @@
 //                so their tap reads are one broadcast address and the x reads of the four
 //                rows (DOWN samples apart) overlap on few banks.
 #include "common.h"
+#include "mixdec_geom.h"
 
 namespace pysdr {
 
@@ -59,20 +60,6 @@ __device__ __forceinline__ float row_sum(float v) {
   v += dpp_half_mirror(v);
   v += dpp_mirror(v);
   return v;
-}
-
-// t / d and t % d with the host's magic = floor(2^32/d)+1 (exact for any 32-bit t: the
-// multiply-high estimate is q or q+1); d == 1 has magic 0
-__device__ __forceinline__ void divmod_magic(uint32_t t, uint32_t d, uint32_t magic, uint32_t& q,
-                                             uint32_t& r) {
-  q = (d == 1u) ? t : __umulhi(t, magic);
-  r = t - q * d;
-  if (r >= d) { q -= 1u; r += d; }
-}
-__device__ __forceinline__ uint32_t div_magic(uint32_t t, uint32_t d, uint32_t magic) {
-  uint32_t q, r;
-  divmod_magic(t, d, magic, q, r);
-  return q;
 }
 
 // max over the 64 lanes (DPP only); result valid in lane 63
@@ -132,69 +119,6 @@ __device__ __forceinline__ lds_cf2 to_lds(const float2* p) {
   return (lds_cf2)(size_t)a;
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// Geometry of tile b: outputs [i_first, i_first + tile_n), LDS image = samples [lo, hi]
-// (relative to the first sample of the call; negative = history), samples [own_lo, own_hi]
-// are the ones this tile contributes to the raw-chunk peak.  (rel_f, p_f) = divmod(t0 +
-// i_first*DOWN, UP) and rel_l = floor((t0 + i_last*DOWN)/UP) seed the per-task index
-// arithmetic and the incremental step to the next tile.
-struct Tile {
-  int i_first, tile_n;
-  int rel_f, p_f, rel_l;
-  int lo, hi, own_lo, own_hi, npairs;
-};
-
-__device__ __forceinline__ Tile tile_geometry(const MixDecArgs& a, int b) {
-  Tile t;
-  t.i_first = b * a.tile_out;
-  int n = a.n_out - t.i_first;
-  if (n > a.tile_out) n = a.tile_out;
-  if (n < 0) n = 0;
-  t.tile_n = n;
-  int need_lo, need_hi;
-  uint32_t q, r;
-  divmod_magic(a.t0 + (uint32_t)t.i_first * (uint32_t)a.down, (uint32_t)a.up, a.magic, q, r);
-  t.rel_f = (int)q;
-  t.p_f = (int)r;
-  if (n > 0) {
-    need_hi = (int)div_magic(a.t0 + (uint32_t)(t.i_first + n - 1) * (uint32_t)a.down, (uint32_t)a.up, a.magic);
-    need_lo = t.rel_f - (a.kpad - 1);
-    t.own_hi = need_hi;
-  } else {
-    need_hi = -1; need_lo = 0; t.own_hi = -1;
-  }
-  t.rel_l = need_hi;
-  t.own_lo = (b == 0) ? 0
-                      : (int)div_magic(a.t0 + (uint32_t)(t.i_first - 1) * (uint32_t)a.down, (uint32_t)a.up, a.magic) + 1;
-  if (b == a.ntiles - 1) t.own_hi = (int)a.n_total - 1;
-  int lo = need_lo < t.own_lo ? need_lo : t.own_lo;
-  if (n == 0) lo = t.own_lo;
-  t.lo = lo & ~1;
-  t.hi = need_hi > t.own_hi ? need_hi : t.own_hi;
-  t.npairs = (t.hi - t.lo + 2) >> 1;
-  return t;
-}
-
-// The same for the tile after the FULL tile `c` when that next tile is full and not the
-// last one: additions only (dq/dr = divmod(tile_out*DOWN, UP) and divmod((tile_out-1)*DOWN,
-// UP) come from the host), about 20 scalar instructions instead of three divisions.
-__device__ __forceinline__ Tile tile_advance(const MixDecArgs& a, const Tile& c) {
-  Tile t;
-  t.i_first = c.i_first + a.tile_out;
-  t.tile_n = a.tile_out;
-  int p = c.p_f + a.dr_tile, q = c.rel_f + a.dq_tile;
-  if (p >= a.up) { p -= a.up; q += 1; }
-  t.rel_f = q;
-  t.p_f = p;
-  t.rel_l = q + a.dq_last + ((p + a.dr_last >= a.up) ? 1 : 0);
-  t.own_lo = c.rel_l + 1;
-  t.own_hi = t.rel_l;
-  const int need_lo = q - (a.kpad - 1);
-  t.lo = (need_lo < t.own_lo ? need_lo : t.own_lo) & ~1;
-  t.hi = t.rel_l;
-  t.npairs = (t.hi - t.lo + 2) >> 1;
-  return t;
-}
 
 // Start the copy of tile `t` into `xs` (does not wait).
 __device__ __forceinline__ void stage_tile(const MixDecArgs& a, const Tile& t, float2* xs, int tid,

@@ -1,0 +1,222 @@
+// The launch layer of libpysdr_hip.so for the sanitizer build of its HOST half (tests/host_san):
+// every launch_* that api.hip calls, as a host function that
+//   * reads every input element and writes every output element the real kernel is entitled to touch
+//     (the "device" memory is malloc'ed by the fake HIP runtime, so AddressSanitizer checks the sizes and
+//     offsets the host code computed: capacities, history prefixes, strides of the per-block arrays);
+//   * for the mix + decimate kernel walks ALL tiles of the launch with the kernel's own geometry code
+//     (pysdr_amd/csrc/mixdec_geom.h): the incremental step must equal the division, the LDS image must
+//     fit the tile buffer and stay inside history + call, outputs and owned samples must partition the
+//     call exactly.
+// No DSP is computed: parity is the GPU tests' business.  Not part of the product.
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+
+#include "common.h"
+#include "mixdec_geom.h"
+
+namespace pysdr {
+
+namespace {
+
+#define SAN_CHECK(cond, ...)                                              \
+  do {                                                                    \
+    if (!(cond)) {                                                        \
+      std::fprintf(stderr, "host_san: %s:%d: %s -- ", __FILE__, __LINE__, #cond); \
+      std::fprintf(stderr, __VA_ARGS__);                                  \
+      std::fputc('\n', stderr);                                           \
+      std::abort();                                                       \
+    }                                                                     \
+  } while (0)
+
+volatile float g_sink;
+
+template <class T> void read_all(const T* p, size_t n) {
+  const volatile unsigned char* b = reinterpret_cast<const volatile unsigned char*>(p);
+  unsigned acc = 0;
+  for (size_t i = 0; i < n * sizeof(T); i += 1) acc += b[i];
+  g_sink = (float)acc;
+}
+template <class T> void write_all(T* p, size_t n) { std::memset(p, 0, n * sizeof(T)); }
+
+bool same_tile(const Tile& a, const Tile& b) {
+  return a.i_first == b.i_first && a.tile_n == b.tile_n && a.rel_f == b.rel_f && a.p_f == b.p_f && a.rel_l == b.rel_l &&
+         a.lo == b.lo && a.hi == b.hi && a.own_lo == b.own_lo && a.own_hi == b.own_hi && a.npairs == b.npairs;
+}
+
+}  // namespace
+
+size_t mixdec_lds_bytes(const MixDecArgs& a) {
+  return (2 * (size_t)a.tile_cap + (size_t)a.nrx * a.up * a.kpad + (size_t)a.nrx * a.ycap) * sizeof(float2);
+}
+
+int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t) {
+  SAN_CHECK(threads >= 64 && threads <= 1024 && (threads & 63) == 0, "threads %d", threads);
+  SAN_CHECK(grid >= 1, "grid %d", grid);
+  SAN_CHECK(mixdec_lds_bytes(a) <= 160 * 1024, "LDS %zu", mixdec_lds_bytes(a));
+  SAN_CHECK(a.nrx >= 1 && a.nrx <= PYSDR_MAX_RX && a.up >= 1 && a.down >= 1 && a.kpad % 16 == 0, "shape");
+  SAN_CHECK(a.hist_len >= a.kpad + 2 && (a.hist_len & 1) == 0, "hist_len %d kpad %d", a.hist_len, a.kpad);
+  SAN_CHECK(a.tile_out >= 2 && (a.tile_out & 1) == 0 && a.ycap == a.yflush * a.tile_out && a.yflush >= 1, "tile_out %d", a.tile_out);
+  SAN_CHECK(a.ntiles >= 1 && (long long)a.ntiles * a.tile_out >= a.n_out && (long long)(a.ntiles - 1) * a.tile_out <= std::max(a.n_out, 1), "ntiles");
+  SAN_CHECK(a.dq_tile == (int)(((long long)a.tile_out * a.down) / a.up) && a.dr_tile == (int)(((long long)a.tile_out * a.down) % a.up), "tile step");
+  SAN_CHECK(a.m0_mod < 2u * (unsigned)a.up, "m0_mod");
+  if (a.skew) SAN_CHECK(a.tile_out % (4 * a.up) == 0, "skew needs whole quads of every branch per tile");
+  // every byte the kernel may read or write exists
+  read_all(a.x, a.n_total);
+  read_all(a.hist, (size_t)a.hist_len);
+  read_all(a.taps, (size_t)a.nrx * a.up * a.kpad);
+  const uint32_t nchunks = (a.n_total + a.chunk_len - 1) / a.chunk_len;
+  write_all(a.peak, nchunks);
+  for (int r = 0; r < a.nrx; ++r) write_all(a.y[r], (size_t)a.n_out);
+  // the tile walk
+  long long outs = 0, own_next = 0;
+  Tile prev{};
+  for (int b = 0; b < a.ntiles; ++b) {
+    const Tile t = tile_geometry(a, b);
+    if (b > 0 && b + 1 < a.ntiles && prev.tile_n == a.tile_out) {
+      const Tile s = tile_advance(a, prev);
+      SAN_CHECK(same_tile(s, t), "tile %d: incremental step != division (i_first %d/%d lo %d/%d hi %d/%d p_f %d/%d)", b,
+                s.i_first, t.i_first, s.lo, t.lo, s.hi, t.hi, s.p_f, t.p_f);
+    }
+    SAN_CHECK(t.i_first == outs && t.tile_n >= 0 && t.tile_n <= a.tile_out, "tile %d outputs", b);
+    outs += t.tile_n;
+    SAN_CHECK(t.own_lo == own_next, "tile %d owns from %d, expected %lld", b, t.own_lo, own_next);
+    own_next = (long long)t.own_hi + 1;
+    SAN_CHECK((t.lo & 1) == 0 && t.lo >= -a.hist_len, "tile %d image starts at %d (history %d)", b, t.lo, a.hist_len);
+    SAN_CHECK(t.hi < (int)a.n_total || t.tile_n == 0, "tile %d image ends at %d (call %u)", b, t.hi, a.n_total);
+    SAN_CHECK(2 * t.npairs <= a.tile_cap, "tile %d: %d samples > tile_cap %d", b, 2 * t.npairs, a.tile_cap);
+    if (t.tile_n > 0) {
+      // first tap of the first output and last tap of ... lie inside the image
+      SAN_CHECK(t.rel_f - (a.kpad - 1) >= t.lo && t.rel_l <= t.hi, "tile %d: taps outside the image", b);
+      // whole-piece DMA of interior tiles may read up to 63 pairs past `hi`: still inside the tile buffer
+      const int npieces = (t.npairs + 63) >> 6;
+      if (a.aligned16 && t.lo >= 0 && (uint32_t)(t.lo + 128 * npieces) <= a.n_total)
+        SAN_CHECK(128 * npieces <= a.tile_cap + 128, "tile %d: whole pieces (%d samples) overrun tile_cap %d", b, 128 * npieces, a.tile_cap);
+    }
+    prev = t;
+  }
+  SAN_CHECK(outs == a.n_out, "tiles hold %lld outputs, call has %d", outs, a.n_out);
+  SAN_CHECK(own_next == (long long)a.n_total, "tiles own %lld samples, call has %u", own_next, a.n_total);
+  return PYSDR_OK;
+}
+
+int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len, uint32_t n_total, hipStream_t) {
+  for (int j = 0; j < hist_len; ++j) {
+    const long long rel = (long long)n_total - hist_len + j;
+    hist_new[j] = (rel >= 0) ? x[rel] : hist_old[hist_len + rel];
+  }
+  return PYSDR_OK;
+}
+
+static void check_plan(const PllPlan& p, int n, int nrx) {
+  SAN_CHECK(p.K >= 1 && p.T >= 64 && (long long)p.K * p.T >= n && (long long)(p.K - 1) * p.T < std::max(n, 1), "PLL plan K %d T %d n %d", p.K, p.T, n);
+  SAN_CHECK(p.W % 64 == 0 && p.Wfast % 64 == 0 && p.Wexact % 64 == 0 && p.T % 64 == 0, "PLL plan alignment");
+  write_all(p.seg, (size_t)nrx * p.K * 4);
+}
+
+int launch_pll(const Stage2Args& a, hipStream_t) {
+  check_plan(a.pll, a.n_out, a.nrx);
+  for (int r = 0; r < a.nrx; ++r)
+    if (a.det[r] == kDetPll) {
+      SAN_CHECK(a.ypll[r] != nullptr, "AM-Synch rx %d has no PLL buffer", r);
+      read_all(a.y[r], (size_t)a.n_out);
+      write_all(a.ypll[r], (size_t)a.n_out);
+    }
+  read_all(a.state, (size_t)a.nrx);
+  return PYSDR_OK;
+}
+
+int launch_demod_fir(const Stage2Args& a, hipStream_t) {
+  for (int r = 0; r < a.nrx; ++r) {
+    const float2* src = (a.det[r] == kDetPll) ? a.ypll[r] : a.y[r];
+    read_all(src - a.hy, (size_t)a.hy + a.n_out);                  // history prefix + the call
+    read_all(a.aftaps[r], (size_t)((a.ntaps + 3) & ~3));
+    write_all(a.a[r], (size_t)a.n_out);
+    for (int k = 0; k < a.nchunks; ++k) {                           // per-block accumulators, kBlkStride words apart
+      a.blkpeak[((size_t)r * a.nchunks + k) * kBlkStride] = 0u;
+      a.blknoise[((size_t)r * a.nchunks + k) * kBlkStride] = 0.f;
+      a.blkcnt[((size_t)r * a.nchunks + k) * kBlkStride] = 0u;
+    }
+  }
+  return PYSDR_OK;
+}
+
+int launch_agc_scan(const Stage2Args& a, hipStream_t) {
+  for (int r = 0; r < a.nrx; ++r) {
+    for (int k = 0; k < a.nchunks; ++k) g_sink = (float)a.blkpeak[((size_t)r * a.nchunks + k) * kBlkStride];
+    write_all(a.gain + (size_t)r * a.nchunks, (size_t)a.nchunks);
+  }
+  read_all(a.state, (size_t)a.nrx);
+  return PYSDR_OK;
+}
+
+int launch_apply(const Stage2Args& a, hipStream_t) {
+  for (int r = 0; r < a.nrx; ++r) {
+    read_all(a.a[r], (size_t)a.n_out);
+    write_all(a.am[r], (size_t)a.n_out * (a.out_complex[r] ? 2 : 1));
+  }
+  return PYSDR_OK;
+}
+
+int launch_epilogue(const EpilogueArgs& a, hipStream_t) {
+  SAN_CHECK(a.hy <= 4096, "hy %d", a.hy);
+  for (int r = 0; r < a.nrx; ++r)
+    for (float2* base : {a.ybase[r], a.ypllbase[r]})
+      if (base) {
+        read_all(base, (size_t)a.hy + a.n_out);
+        std::memmove(base, base + a.n_out, (size_t)a.hy * sizeof(float2));
+      }
+  return PYSDR_OK;
+}
+
+int launch_wfm(const WfmArgs& a, hipStream_t) {
+  check_plan(a.pll, a.n1, a.nrx);
+  for (int r = 0; r < a.nrx; ++r) {
+    SAN_CHECK(a.y1[r] == a.y1base[r] + 2, "IF buffer layout");
+    read_all(a.y1[r] - 1, (size_t)a.n1 + 1);
+    write_all(a.w[r], (size_t)a.n1);
+    if (a.n1 > 0) a.y1base[r][1] = a.y1[r][a.n1 - 1];
+  }
+  read_all(a.state, (size_t)a.nrx);
+  return PYSDR_OK;
+}
+
+int launch_quad_mixer(const float2* x, float2* y, size_t n, uint32_t, uint32_t, hipStream_t) {
+  read_all(x, n);
+  write_all(y, n);
+  return PYSDR_OK;
+}
+
+int launch_fir_real(const float* xx, const float* h, int nt, float* y, int n, hipStream_t) {
+  read_all(xx, (size_t)n + nt - 1);
+  read_all(h, (size_t)nt);
+  write_all(y, (size_t)n);
+  return PYSDR_OK;
+}
+
+int launch_psd_pre(const float2* x, size_t hop, int nframes, int chunk, int nfft, const float* win, float2* work, int is_complex,
+                   hipStream_t) {
+  read_all(win, (size_t)chunk);
+  for (int f = 0; f < nframes; ++f) {
+    if (is_complex) read_all(x + (size_t)f * hop, (size_t)chunk);
+    else read_all(reinterpret_cast<const float*>(x) + (size_t)f * hop, (size_t)chunk);
+  }
+  write_all(work, (size_t)nframes * nfft);
+  return PYSDR_OK;
+}
+
+int launch_psd_post(const float2* work, int nframes, int nfft, int half, int, float* out, hipStream_t) {
+  read_all(work, (size_t)nframes * nfft);
+  write_all(out, (size_t)nframes * (half ? nfft / 2 : nfft));
+  return PYSDR_OK;
+}
+
+int launch_psd64k(const float2* x, size_t hop, int nframes, const float* win, float2* work, float* out, int, hipStream_t) {
+  read_all(win, 32768);
+  for (int f = 0; f < nframes; ++f) read_all(x + (size_t)f * hop, 32768);
+  write_all(work, (size_t)nframes * 65536);
+  write_all(out, (size_t)nframes * 65536);
+  return PYSDR_OK;
+}
+
+}  // namespace pysdr
