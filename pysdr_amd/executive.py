@@ -199,8 +199,9 @@ class SDR_EXECUTIVE:
                 P.NEW_MODE = 'NFM'
             if P.MODE != P.NEW_MODE:
                 P.MODE = P.NEW_MODE
-                P.rx[0].agc.reset()
-                P.rx[0].demod.am_pll.reset()
+                if getattr(P, 'MP_SCHEME', 1) in (1, 2):    # receiver.py:646-648: in scheme 3 the workers own the receivers
+                    P.rx[0].agc.reset()
+                    P.rx[0].demod.am_pll.reset()
             P.MODE_CHANGE = False
 
     # -- receiver.py:684-773
