@@ -97,6 +97,59 @@ __global__ __launch_bounds__(512) void rows_C(const float4* __restrict__ work, f
   for (int i = 0; i < 4; ++i) st4<NTOUT>(o + i * 512 + tid, u[i] + u[i + 4]);
 }
 
+// ---- mixed: which side of each kernel carries the difference between P and C?
+__global__ __launch_bounds__(256) void cols_PinCout(const float2* __restrict__ x, size_t hop, const float* __restrict__ win,
+                                                    float4* __restrict__ work) {
+  const int f = blockIdx.y, cb = blockIdx.x, tid = threadIdx.x;
+  const int b = tid & 15, hi = tid >> 4, bb = cb * 16 + b;
+  const float2* xf = x + (size_t)f * hop;
+  v2f u[8];
+#pragma unroll
+  for (int a1 = 0; a1 < 8; ++a1) {
+    const int n = 256 * (hi + 16 * a1) + bb;
+    u[a1] = ld2<true>(xf + n) * win[n];
+  }
+  float4* o = work + (size_t)f * (kN / 2) + cb * 2048;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v4f w = {u[i].x, u[i].y, u[(i + 1) & 7].x, u[(i + 1) & 7].y}; st4<false>(o + i * 256 + tid, w); }
+}
+__global__ __launch_bounds__(256) void cols_CinPout(const float4* __restrict__ x, size_t hop4, float2* __restrict__ work) {
+  const int f = blockIdx.y, cb = blockIdx.x, tid = threadIdx.x;
+  const float4* xf = x + (size_t)f * hop4 + cb * 1024;
+  v4f u[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = ld4<true>(xf + i * 256 + tid);
+  float2* o = work + (size_t)f * kN + (size_t)cb * 4096 + (tid >> 4) * 16 + (tid & 15);
+#pragma unroll
+  for (int p0 = 0; p0 < 16; ++p0) { v2f w = {u[p0 & 3].x, u[p0 & 3].y + (float)p0}; st2(o + p0 * 256, w); }
+}
+__global__ __launch_bounds__(512) void rows_PinCout(const float2* __restrict__ work, float4* __restrict__ out) {
+  const int f = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x;
+  const int c0 = tid & 15, pl = tid >> 4;
+  const float2* src = work + (size_t)f * kN + (size_t)(rb * 32 + pl) * 16 + c0;
+  v2f u[16];
+#pragma unroll
+  for (int c1 = 0; c1 < 16; ++c1) u[c1] = ld2<false>(src + 4096 * c1);
+  float4* o = out + (size_t)f * (kN / 4) + rb * 2048;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v4f w = {u[4 * i].x, u[4 * i + 1].x, u[4 * i + 2].y, u[4 * i + 3].y}; st4<true>(o + i * 512 + tid, w); }
+}
+__global__ __launch_bounds__(512) void rows_CinPout(const float4* __restrict__ work, float* __restrict__ out) {
+  const int f = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x;
+  const float4* src = work + (size_t)f * (kN / 2) + rb * 4096;
+  v4f u[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) u[i] = ld4<false>(src + i * 512 + tid);
+  const int pl2 = tid & 31, q1 = tid >> 5;
+  const int kb = rb * 32 + pl2 + 256 * q1;
+  float* of = out + (size_t)f * kN;
+#pragma unroll
+  for (int q0 = 0; q0 < 16; ++q0) {
+    const int k = kb + 4096 * q0;
+    st1<true>(of + ((k + kM) & (kN - 1)), u[q0 & 7].x + u[q0 & 7].y + (float)q0);
+  }
+}
+
 // ---- plain streams
 template <bool NT> __global__ __launch_bounds__(256) void rd_stream(const float4* __restrict__ p, size_t n, float* sink) {
   v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -187,6 +240,12 @@ int main(int argc, char** argv) {
   run_pair("C_16B_nt_everywhere",
            [&](int f0, int nf) { cols_C<true, true><<<dim3(16, nf), 256>>>((const float4*)(x + (size_t)f0 * hop), hop / 2, (float4*)work); },
            [&](int f0, int nf) { rows_C<true, true><<<dim3(8, nf), 512>>>((const float4*)work, (float4*)(out + (size_t)f0 * kN)); });
+  run_pair("mixed_colsPinCout_rowsPinCout",
+           [&](int f0, int nf) { cols_PinCout<<<dim3(16, nf), 256>>>(x + (size_t)f0 * hop, hop, win, (float4*)work); },
+           [&](int f0, int nf) { rows_PinCout<<<dim3(8, nf), 512>>>(work, (float4*)(out + (size_t)f0 * kN)); });
+  run_pair("mixed_colsCinPout_rowsCinPout",
+           [&](int f0, int nf) { cols_CinPout<<<dim3(16, nf), 256>>>((const float4*)(x + (size_t)f0 * hop), hop / 2, work); },
+           [&](int f0, int nf) { rows_CinPout<<<dim3(8, nf), 512>>>((const float4*)work, out + (size_t)f0 * kN); });
   snprintf(buf, sizeof buf, " \"nframes\": %d, \"group\": %d, \"reps\": %d, \"timing\": \"best of reps, hipEvents\"\n}\n", nframes, group, reps);
   js += buf;
   fputs(js.c_str(), stdout);
