@@ -356,11 +356,14 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   // The four rows of a wave read x `down` samples = 8*down bytes apart and the LDS serves 256 bytes
   // per clock: when that distance is within 64 bytes of a multiple of 256 the two rows of a half-wave
   // share more than half of their banks, and the skewed tap schedule (which moves odd outputs by 128
-  // bytes) is the better one.  DOWN % 32 == 0 (2.048, 1.024, 2.56 MS/s -> 48 kHz) is the exact case.
+  // bytes) was the better one with ds_read_b64 reads (DOWN % 32 == 0: 2.048, 1.024, 2.56 MS/s -> 48 kHz).
+  // ... was: since the x reads carry immediate DS offsets hipcc fuses them in pairs into ds_read2_b64, which the
+  // LDS serves in groups of 16 lanes = ONE row, so rows no longer meet on a bank at all (SQ_LDS_BANK_CONFLICT 2.1 M per
+  // launch with the skew off as with it on) and the skew's two extra address registers cost 2 % (C1 0.446 vs 0.436 of
+  // HBM, same box, profiles/r03_c1_mixdec_skew{0,1}_pmc.json).  It stays available (PYSDR_MIXDEC_SKEW=1, and the tests
+  // run it) for a compiler that keeps ds_read_b64; the default is off.
   {
-    const int dist = (int)((8LL * down) % 256);
-    a.skew = (std::min(dist, 256 - dist) < 64 && tile_out % (4L * up) == 0) ? 1 : 0;
-    if (c->skew_override >= 0) a.skew = c->skew_override && tile_out % (4L * up) == 0;
+    a.skew = (c->skew_override > 0 && tile_out % (4L * up) == 0) ? 1 : 0;
     a.m0_mod = (uint32_t)(m0 % (2ULL * (unsigned)up));
   }
   a.taps = d.d_taps;

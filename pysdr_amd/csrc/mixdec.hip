@@ -540,6 +540,9 @@ int launch_r(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t
   // single-RX long filters: the 255-tap video filter of the broadcast-FM front end (UP = 1, 256
   // taps in one branch) and the reference's default 1001-tap prototype at UP = 3 (336 per branch)
   if constexpr (R == 1) {
+    // the fs1 -> FS_OUT resampler of broadcast FM: 24/125 with 64 taps per branch (more branches than waves: generic
+    // task order, but a compile-time tap loop)
+    if (a.kpad == 64) return launch_rj<R, 4, false>(a, threads, grid, lds, st);
     if (a.kpad == 256) return launch_rj<R, 16, false>(a, threads, grid, lds, st);
     if (a.kpad == 336) return a.skew ? launch_rj<R, 21, true>(a, threads, grid, lds, st) : launch_rj<R, 21, false>(a, threads, grid, lds, st);
   }

@@ -257,7 +257,7 @@ def test_batch_equals_chunked_bit_exact():
 
 
 @pytest.mark.parametrize("fs,ntaps", [(2.048e6, 1001), (1.024e6, 255)])
-def test_skewed_tap_schedule_does_not_depend_on_the_cut(fs, ntaps):
+def test_skewed_tap_schedule_does_not_depend_on_the_cut(fs, ntaps, monkeypatch):
     """DOWN % 32 == 0: odd outputs of a polyphase branch walk their tap groups rotated by one (LDS
     banks, mixdec.hip).  The rotation is a function of the ABSOLUTE output index, so the baseband
     IQ is the same bit for bit whether the stream arrives chunk by chunk, in one batch, or cut at
@@ -265,6 +265,7 @@ def test_skewed_tap_schedule_does_not_depend_on_the_cut(fs, ntaps):
     cfg = dict(so.CONFIGS['C1'], fs=fs, ntaps_dec=ntaps,
                carriers=[dict(f=0.05 * fs, kind='am', amp=0.3, tone=1000.0, depth=0.5)],
                rx=[dict(frq=0.05 * fs, mode='AM', video_bw=10e3, af_bw=5e3)])
+    monkeypatch.setenv("PYSDR_MIXDEC_SKEW", "1")      # read by pysdr_create; off by default since round 3 (api.hip)
     L = so.chunk_sizes(fs, 48e3)[3]
     B = 12
     x = so.synth_iq(cfg, B * L, 31)
