@@ -21,7 +21,13 @@ SOURCES = ["api.hip", "mixdec.hip", "stage2.hip", "misc.hip", "psdfft.hip", "wat
 EXTRA_FLAGS = {"mixdec.hip": os.environ.get("PYSDR_MIXDEC_FLAGS", "").split(),
                # packed-f32 pairs built by the SLP vectoriser run at half rate on gfx950 and are fed by
                # v_mov shuffles: the AF FIR is written for plain FMAs
-               "stage2.hip": ["-fno-slp-vectorize"]}
+               "stage2.hip": ["-fno-slp-vectorize"],
+               # FFT butterflies are adds: v_pk_add_f32 issues at 5.6 cycles against 2 x 3.1 for two plain adds and
+               # hipcc pays for the pairing with v_mov shuffles and 17 more registers (A/B: PYSDR_PSD_FLAGS)
+               # measured on C3, PSD ms per 10666 frames: default 2.752 / 2.774, -fno-slp-vectorize 2.731 / 2.731,
+               # + -fno-signed-zeros (lets the zero-padded half of the first DFT16 fold away) 2.721: the pair is
+               # fabric-bound, 17 % fewer issue cycles buy 1.5 %
+               "psdfft.hip": os.environ.get("PYSDR_PSD_FLAGS", "-fno-slp-vectorize -fno-signed-zeros").split()}
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 
