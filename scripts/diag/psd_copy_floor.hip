@@ -150,6 +150,33 @@ __global__ __launch_bounds__(512) void rows_CinPout(const float4* __restrict__ w
   }
 }
 
+// ---- what in the columns kernel's LOAD side costs: the 4-byte window loads, or the 128-byte row pieces?
+//   WIN: 0 = no window, 1 = eight 4-byte loads per thread (product), 2 = two 16-byte loads from a table laid out per thread
+//   COLS: columns per workgroup (16 = 128-byte pieces, 32 = 256-byte pieces); threads = 16 * COLS
+template <int WIN, int COLS>
+__global__ __launch_bounds__(16 * COLS) void cols_V(const float2* __restrict__ x, size_t hop, const float* __restrict__ win,
+                                                     float2* __restrict__ work) {
+  const int f = blockIdx.y, cb = blockIdx.x, tid = threadIdx.x;
+  const int b = tid % COLS, hi = tid / COLS, bb = cb * COLS + b;
+  const float2* xf = x + (size_t)f * hop;
+  float w[8];
+  if (WIN == 2) {
+    const v4f w0 = *(const AS1 v4f*)(win + ((size_t)cb * (16 * COLS) + tid) * 8), w1 = *(const AS1 v4f*)(win + ((size_t)cb * (16 * COLS) + tid) * 8 + 4);
+    w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+  }
+  v2f u[8];
+#pragma unroll
+  for (int a1 = 0; a1 < 8; ++a1) {
+    const int n = 256 * (hi + 16 * a1) + bb;
+    u[a1] = ld2<true>(xf + n);
+    if (WIN == 1) u[a1] *= win[n];
+    if (WIN == 2) u[a1] *= w[a1];
+  }
+  float2* o = work + (size_t)f * kN + (size_t)cb * (256 * COLS) + tid;
+#pragma unroll
+  for (int p0 = 0; p0 < 16; ++p0) st2(o + p0 * (16 * COLS), u[p0 & 7]);
+}
+
 // ---- plain streams
 template <bool NT> __global__ __launch_bounds__(256) void rd_stream(const float4* __restrict__ p, size_t n, float* sink) {
   v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -246,6 +273,20 @@ int main(int argc, char** argv) {
   run_pair("mixed_colsCinPout_rowsCinPout",
            [&](int f0, int nf) { cols_CinPout<<<dim3(16, nf), 256>>>((const float4*)(x + (size_t)f0 * hop), hop / 2, work); },
            [&](int f0, int nf) { rows_CinPout<<<dim3(8, nf), 512>>>((const float4*)work, out + (size_t)f0 * kN); });
+  {
+    // columns-kernel load side: per-frame ns of the cols kernel alone
+    auto cols_only = [&](auto&& lc) { return best([&] { for (int f0 = 0; f0 < nframes; f0 += group) lc(f0, std::min(group, nframes - f0)); }) * 1e6 / nframes; };
+    const double v00 = cols_only([&](int f0, int nf) { cols_V<0, 16><<<dim3(16, nf), 256>>>(x + (size_t)f0 * hop, hop, win, work); });
+    const double v10 = cols_only([&](int f0, int nf) { cols_V<1, 16><<<dim3(16, nf), 256>>>(x + (size_t)f0 * hop, hop, win, work); });
+    const double v20 = cols_only([&](int f0, int nf) { cols_V<2, 16><<<dim3(16, nf), 256>>>(x + (size_t)f0 * hop, hop, win, work); });
+    const double v01 = cols_only([&](int f0, int nf) { cols_V<0, 32><<<dim3(8, nf), 512>>>(x + (size_t)f0 * hop, hop, win, work); });
+    const double v11 = cols_only([&](int f0, int nf) { cols_V<1, 32><<<dim3(8, nf), 512>>>(x + (size_t)f0 * hop, hop, win, work); });
+    const double v21 = cols_only([&](int f0, int nf) { cols_V<2, 32><<<dim3(8, nf), 512>>>(x + (size_t)f0 * hop, hop, win, work); });
+    snprintf(buf, sizeof buf,
+             " \"cols_load_side_ns_per_frame\": {\"16cols_no_window\": %.1f, \"16cols_window_8x4B\": %.1f, \"16cols_window_2x16B\": %.1f, "
+             "\"32cols_no_window\": %.1f, \"32cols_window_8x4B\": %.1f, \"32cols_window_2x16B\": %.1f},\n", v00, v10, v20, v01, v11, v21);
+    js += buf;
+  }
   snprintf(buf, sizeof buf, " \"nframes\": %d, \"group\": %d, \"reps\": %d, \"timing\": \"best of reps, hipEvents\"\n}\n", nframes, group, reps);
   js += buf;
   fputs(js.c_str(), stdout);
