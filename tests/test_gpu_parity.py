@@ -558,13 +558,18 @@ def test_waterfall_backend_equals_the_executed_reference_text():
     assert seen == 4
 
 
-def test_full_size_batch_is_independent_of_how_it_is_cut():
-    """BASELINE full size (the bench's 2048 chunks x 170666 samples = 2.8 GB resident in HBM, 4 RX):
-    one launch sequence over the whole batch = two over its halves, bit for bit (audio, baseband
-    IQ, per-chunk output counts and raw peaks), and the first chunks equal the oracle."""
+@pytest.mark.parametrize("name,B", [("C3", 2048), ("C2", 2048), ("C1", 4096)])
+def test_full_size_batch_is_independent_of_how_it_is_cut(name, B):
+    """BASELINE full size, every narrow-band configuration at the batch bench.py times (C3: 2048 chunks x
+    170666 samples = 2.8 GB resident in HBM, 4 RX; C2: the same stream, 1 RX NBFM; C1: 4096 chunks x 43690
+    at 2.048 MS/s with the reference's default 1001-tap prototype): one launch sequence over the whole batch
+    = two over its halves, bit for bit (audio, baseband IQ, per-chunk output counts and raw peaks), the
+    last chunks of the batch equal its first ones' continuation (the input repeats every 8 chunks), and the
+    first chunks equal the oracle."""
     from pysdr_amd import _lib
-    cfg = so.CONFIGS['C3']
-    L, B, uniq = 170666, 2048, 8
+    cfg = so.CONFIGS[name]
+    up, down, _, L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])
+    uniq = 8
     xu = so.synth_iq(cfg, uniq * L, 10)
     lib = _lib.lib()
     d_x = C.c_void_p()
@@ -589,7 +594,7 @@ def test_full_size_batch_is_independent_of_how_it_is_cut():
         lib.pysdr_dev_free(0, d_x)
     for i in range(len(ga)):
         am, iq, cn, pk = whole[i]
-        assert len(am) == B * L * 3 // 500 or len(am) == B * L * 3 // 500 + 1
+        assert len(am) in (B * L * up // down, B * L * up // down + 1)
         assert np.array_equal(am, np.concatenate([halves[0][i][0], halves[1][i][0]]))
         assert np.array_equal(iq, np.concatenate([halves[0][i][1], halves[1][i][1]]))
         assert np.array_equal(cn, np.concatenate([halves[0][i][2], halves[1][i][2]])) and cn.sum() == len(am)
