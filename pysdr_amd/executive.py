@@ -217,8 +217,10 @@ class SDR_EXECUTIVE:
                 P.RX_DONE = True
                 break
             self.read_chunk()
-            if P.RX_DONE:
-                break
+            if P.RX_DONE and not P.REPLAY_MODE:
+                break                                  # the synthetic live source ran dry: self.x is only partly new
+            # (a replay that runs out sets RX_DONE in read_chunk and leaves self.x as it was; like the reference
+            #  -- receiver.py:543-557,715-740 -- the loop body still runs once more on that stale chunk)
             self.mode_freq_change()
             for irx in range(P.NUM_RX):
                 demodulate_data(P, self.x, irx)
@@ -355,12 +357,10 @@ def replay_batched(P, batch_chunks=64, on_batch=None, dsp=None):
         total = min(total, int(np.ceil(P.DURATION * P.SRATE / L)))
     lo = getattr(P, 'lo', None)
     done = 0
+    x_last = None
     P.sdr.rewind()
-    while done < total:
-        nb = min(batch_chunks, total - done)
-        x = P.sdr.read_chunk(nb * L)
-        if lo is not None and lo.fo != 0:
-            x = lo.quad_mixer(x)
+
+    def run_batch(x, nb):
         ctx.process_batch(x, nb, L)
         ams, iqs, cns = [], [], None
         for irx in range(P.NUM_RX):
@@ -384,7 +384,22 @@ def replay_batched(P, batch_chunks=64, on_batch=None, dsp=None):
             P.raw_iq_io.save_data(x)
         if on_batch is not None:
             on_batch(done, ams, iqs, cns)
+
+    while done < total:
+        nb = min(batch_chunks, total - done)
+        x = P.sdr.read_chunk(nb * L)
+        if lo is not None and lo.fo != 0:
+            x = lo.quad_mixer(x)
+        run_batch(x, nb)
         done += nb
         P.nchunks += nb
+        x_last = np.array(x[(nb - 1) * L:nb * L])
+    if done > 0 and done == (P.sdr.nsamples - 1) // L:
+        # the recording ran out (not P.DURATION): SDR_EXECUTIVE.Run of the reference runs its loop body once more
+        # on the stale last chunk in the pass that discovers it (receiver.py:543-557,715-740: demodulated, played,
+        # tapped and saved again); so does Run above, so does this path
+        run_batch(x_last, 1)
+        done += 1
+        P.nchunks += 1
     ex.quit_rx()
     return done

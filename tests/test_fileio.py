@@ -67,7 +67,9 @@ def test_record_then_replay_reproduces_the_live_run(tmp_path):
     bb = file_io.sdr_fileio(P.baseband_iq_io.fname, 'r')
     assert bb.srate == P.FS_OUT and bb.nsamples == len(demod)
 
-    # replay: one chunk fewer than recorded (strict '<' of receiver.py:543)
+    # replay: one chunk fewer than recorded is READ (strict '<' of receiver.py:543) -- and, as in the reference's
+    # Run loop (receiver.py:715-740), the pass in which read_chunk finds the recording exhausted still
+    # demodulates the stale buffer once more before the loop ends
     P2 = make_P(cfg, nchunks)
     P2.REPLAY = P.raw_iq_io.fname
     file_io.open_replay(P2, dsp=type('D', (), {'signal_generator': lambda *a: type('L', (), {'fo': 0.0})()}))
@@ -75,5 +77,6 @@ def test_record_then_replay_reproduces_the_live_run(tmp_path):
     rep = []
     ex2 = executive.SDR_EXECUTIVE(P2, dsp=oracle_dsp)
     ex2.Run(on_chunk=lambda e: rep.append(np.array(P2.rx[0].am)))
-    assert len(rep) == nchunks - 1
-    assert np.array_equal(np.concatenate(rep), np.concatenate(live[:nchunks - 1]))
+    assert len(rep) == nchunks
+    assert np.array_equal(np.concatenate(rep[:nchunks - 1]), np.concatenate(live[:nchunks - 1]))
+    assert P2.RX_DONE and not np.array_equal(rep[-1], live[nchunks - 1])      # chunk 2 again, not chunk 3
