@@ -352,9 +352,10 @@ def replay_batched(P, batch_chunks=64, on_batch=None, dsp=None):
     ex = SDR_EXECUTIVE(P, dsp=dsp)
     ctx = P._pysdr_stream
     L = P.IN_CHUNK_SIZE
-    total = (P.sdr.nsamples - 1) // L                  # strict '<' of receiver.py:543
-    if getattr(P, 'DURATION', None):
-        total = min(total, int(np.ceil(P.DURATION * P.SRATE / L)))
+    file_total = (P.sdr.nsamples - 1) // L             # strict '<' of receiver.py:543
+    dur_total = int(np.ceil(P.DURATION * P.SRATE / L)) if getattr(P, 'DURATION', None) else None   # t >= DURATION ends Run
+    total = file_total if dur_total is None else min(file_total, dur_total)
+    ran_out = dur_total is None or dur_total > file_total   # Run would start one more pass and find the file exhausted
     lo = getattr(P, 'lo', None)
     done = 0
     x_last = None
@@ -394,7 +395,7 @@ def replay_batched(P, batch_chunks=64, on_batch=None, dsp=None):
         done += nb
         P.nchunks += nb
         x_last = np.array(x[(nb - 1) * L:nb * L])
-    if done > 0 and done == (P.sdr.nsamples - 1) // L:
+    if done > 0 and ran_out:
         # the recording ran out (not P.DURATION): SDR_EXECUTIVE.Run of the reference runs its loop body once more
         # on the stale last chunk in the pass that discovers it (receiver.py:543-557,715-740: demodulated, played,
         # tapped and saved again); so does Run above, so does this path
