@@ -645,6 +645,7 @@ def main():
         mine = verify_rank(cfg, ctx, rxs, rx_idx, xu, nloop, seam, nsamp, L, B, step_no[0],
                            psd=(lib, device, d_psd) if sp is not None else None)
         mine["rank"] = rank
+        mine["stream_seed"] = seed
         if split_rx:
             # the only proof that RCCL moved the bytes: every rank's copy of the batch == the root's
             mine["bcast_checksum"] = device_checksum(lib, device, d_x.value, nsamp * 8)
