@@ -43,7 +43,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PSD_CHUNK, PSD_NFFT = 32768, 65536
 DEFAULT_CHUNKS = {"c1": 4096, "c2": 2048, "c3": 2048, "c4": 2048, "c4mono": 2048}
 TUNING_ENV = ("PYSDR_MIXDEC_WGS", "PYSDR_MIXDEC_YFLUSH", "PYSDR_DEBUG_FLAGS", "PYSDR_PSD_GROUP",
-              "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS")
+              "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_PSD_STREAMS", "PYSDR_WFM_PLL", "PYSDR_MIXDEC_SKEW", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS")
 
 
 def parse(argv=None):
@@ -732,7 +732,8 @@ def main():
     psd_tr = measured_traffic(args, nrx, B, "psd", ["psdfft.hip"])
     if psd_tr[0] is not None and sp is not None and sp_tune[0] > 0:
         # the profile's figure is per launch pair of one group of frames; one call = nframes / group of them
-        psd_tr = (psd_tr[0] * nframes / float(sp_tune[0]), psd_tr[1] + f"; per group of {int(sp_tune[0])} frames, scaled to the call")
+        per_launch = -(-int(sp_tune[0]) // max(1, int(sp_tune[2])))          # frames of one cols + rows launch pair
+        psd_tr = (psd_tr[0] * nframes / float(per_launch), psd_tr[1] + f"; per launch pair of {per_launch} frames, scaled to the call")
     r_psd = roof("psd kernels (window, zero-pad, 64k FFT, |.|^2, dB, fftshift)", psd_bytes, psd_ms, psd_tr,
                  note="one call = all frames of the batch; per launch figures are per call")
     # the kernel (group) that dominates the timed region carries the headline roofline object
@@ -783,6 +784,7 @@ def main():
                    "mixdec_yflush_cap": int(tune[3]), "tile_bytes": int(tune[4]), "threads": int(tune[5]),
                    "psd_group": int(sp_tune[0]) if sp is not None else None,
                    "psd_rocfft": int(sp_tune[1]) if sp is not None else None,
+                   "psd_streams": int(sp_tune[2]) if sp is not None else None,
                    "env": {k: os.environ[k] for k in TUNING_ENV if k in os.environ},
                    "argv": " ".join(sys.argv[1:])},
         "source_sha256": {s: source_sha(s) for s in ("mixdec.hip", "psdfft.hip", "stage2.hip", "api.hip")},

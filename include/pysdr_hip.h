@@ -184,7 +184,7 @@ int pysdr_spectrum_frame(pysdr_spectrum* sp, const float* x, int is_complex, int
 int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size_t hop,
                          void* d_out);
 int pysdr_spectrum_sync(pysdr_spectrum* sp);
-/* out = {frames per launch group of the fused 64k path, rocFFT forced 0/1, 0, 0} */
+/* out = {frames per launch group of the fused 64k path, rocFFT forced 0/1, streams the groups are dealt over, 0} */
 int pysdr_spectrum_get_tuning(pysdr_spectrum* sp, int32_t out[4]);
 int pysdr_spectrum_elapsed_ms(pysdr_spectrum* sp, float* ms);
 /* Ordering between the spectrum's stream and a receiver context's stream (both read the same

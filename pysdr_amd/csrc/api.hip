@@ -179,6 +179,15 @@ struct pysdr_spectrum {
   hipEvent_t ev_order = nullptr;
   bool force_rocfft = false;  // PYSDR_PSD_ROCFFT: rocFFT even for the 32768 -> 65536 size
   int group = 448;            // frames per launch pair of the four-step path (PYSDR_PSD_GROUP)
+  // PYSDR_PSD_STREAMS=2: the groups alternate between two streams, each with its own half-size intermediate
+  // (2 x group/2 frames = the same Infinity Cache footprint), so that the columns of one group run beside
+  // the rows of the other and the kernel boundaries of one stream hide behind the other's kernels
+  static constexpr int kMaxStreams = 4;
+  int nstreams = 2;
+  hipStream_t xstream[kMaxStreams] = {};     // [0] unused (= stream)
+  float2* xwork[kMaxStreams] = {};           // [0] unused (= d_work)
+  size_t xwork_frames = 0;
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {};
 };
 
 // N4: ingest ring.  Pinned host chunk buffers the device reads directly over PCIe (async H2D on
@@ -1172,6 +1181,7 @@ int pysdr_spectrum_create(int device, int chunk_size, int nfft, int max_frames, 
   sp->device = device; sp->chunk = chunk_size; sp->nfft = nfft; sp->max_frames = max_frames;
   sp->force_rocfft = getenv("PYSDR_PSD_ROCFFT") != nullptr;
   { const char* e = getenv("PYSDR_PSD_GROUP"); if (e && atoi(e) > 0) sp->group = atoi(e); }
+  { const char* e = getenv("PYSDR_PSD_STREAMS"); if (e && atoi(e) >= 1 && atoi(e) <= pysdr_spectrum::kMaxStreams) sp->nstreams = atoi(e); }
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_error("pysdr_spectrum_create: %s -> %s", #e, hipGetErrorString(_e)); pysdr_spectrum_destroy(sp); return PYSDR_ERR_HIP; } } while (0)
   CK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
   CK(hipMalloc(&sp->d_win, (size_t)chunk_size * sizeof(float)));
@@ -1199,6 +1209,12 @@ void pysdr_spectrum_destroy(pysdr_spectrum* sp) {
   if (sp->info) rocfft_execution_info_destroy(sp->info);
   if (sp->d_win) (void)hipFree(sp->d_win);
   if (sp->d_work) (void)hipFree(sp->d_work);
+  for (int i = 1; i < pysdr_spectrum::kMaxStreams; ++i) {
+    if (sp->xstream[i]) { (void)hipStreamSynchronize(sp->xstream[i]); (void)hipStreamDestroy(sp->xstream[i]); }
+    if (sp->xwork[i]) (void)hipFree(sp->xwork[i]);
+    if (sp->ev_join[i]) (void)hipEventDestroy(sp->ev_join[i]);
+  }
+  if (sp->ev_fork) (void)hipEventDestroy(sp->ev_fork);
   if (sp->d_in) (void)hipFree(sp->d_in);
   if (sp->d_out) (void)hipFree(sp->d_out);
   if (sp->d_fftwork) (void)hipFree(sp->d_fftwork);
@@ -1231,10 +1247,53 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
     // kernels (the input and the PSD stream past it with non-temporal accesses).  Measured per
     // 10666 frames: 3.45 ms for groups of 4096, 3.02 ms at 320 and 2.96 ms at 448-512 with the
     // streaming hints, 3.6 ms at 576 (no longer fits); below 128 frames launch gaps dominate.
-    // Running the rows of group g beside the columns of group g+1 on a second stream was
-    // tried and is slower (3.9 ms): the two working sets evict each other.
+    // Running the rows of group g beside the columns of group g+1 on a second stream with two FULL groups
+    // of intermediate is slower (3.9 ms, round 1: the two working sets evict each other); with HALF a group per
+    // stream it is 5 % faster (round 3, below).
     int group = sp->group;
     if (group < 1) group = 1;
+    if (sp->nstreams > 1 && nframes > group) {
+      // The groups are dealt out over `nstreams` streams, each with its own intermediate of group / nstreams
+      // frames (together the same Infinity Cache footprint as one group): the columns of one sub-group run
+      // beside the rows of another, and the kernel boundaries of one stream hide behind the other's kernels.
+      // Measured on C3 (PSD ms per 10666 frames): 1 stream 2.77-2.78, 2 streams x 224 frames 2.63-2.67.
+      // (Round 1 tried two streams with FULL 448-frame groups each: 448 MB of intermediate, slower.)
+      const int ns = sp->nstreams;
+      const int part = (group + ns - 1) / ns;
+      rc = ensure_work(sp, (size_t)part);
+      if (rc) return rc;
+      if (sp->xwork_frames < (size_t)part) {
+        for (int i = 1; i < ns; ++i) {
+          if (!sp->xstream[i]) {
+            PYSDR_HIP_CHECK(hipStreamCreateWithFlags(&sp->xstream[i], hipStreamNonBlocking));
+            PYSDR_HIP_CHECK(hipEventCreateWithFlags(&sp->ev_join[i], hipEventDisableTiming));
+          }
+          PYSDR_HIP_CHECK(hipStreamSynchronize(sp->xstream[i]));
+          if (sp->xwork[i]) PYSDR_HIP_CHECK(hipFree(sp->xwork[i]));
+          sp->xwork[i] = nullptr;
+          PYSDR_HIP_CHECK(hipMalloc(&sp->xwork[i], (size_t)part * sp->nfft * sizeof(float2)));
+        }
+        if (!sp->ev_fork) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&sp->ev_fork, hipEventDisableTiming));
+        sp->xwork_frames = (size_t)part;
+      }
+      PYSDR_HIP_CHECK(hipEventRecord(sp->ev[0], sp->stream));
+      PYSDR_HIP_CHECK(hipEventRecord(sp->ev_fork, sp->stream));          // the side streams start behind whatever sp->stream waited for
+      for (int i = 1; i < ns; ++i) PYSDR_HIP_CHECK(hipStreamWaitEvent(sp->xstream[i], sp->ev_fork, 0));
+      int k = 0;
+      for (int f0 = 0; f0 < nframes; f0 += part, ++k) {
+        const int nf = (nframes - f0 < part) ? nframes - f0 : part;
+        const int w = k % ns;
+        rc = launch_psd64k(d_x + (size_t)f0 * hop, hop, nf, sp->d_win, w ? sp->xwork[w] : sp->d_work,
+                           d_out + (size_t)f0 * sp->nfft, db, w ? sp->xstream[w] : sp->stream);
+        if (rc) return rc;
+      }
+      for (int i = 1; i < ns; ++i) {
+        PYSDR_HIP_CHECK(hipEventRecord(sp->ev_join[i], sp->xstream[i]));
+        PYSDR_HIP_CHECK(hipStreamWaitEvent(sp->stream, sp->ev_join[i], 0));
+      }
+      PYSDR_HIP_CHECK(hipEventRecord(sp->ev[1], sp->stream));
+      return PYSDR_OK;
+    }
     rc = ensure_work(sp, (size_t)std::min(group, nframes));
     if (rc) return rc;
     PYSDR_HIP_CHECK(hipEventRecord(sp->ev[0], sp->stream));
@@ -1290,7 +1349,7 @@ int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size
 
 int pysdr_spectrum_get_tuning(pysdr_spectrum* sp, int32_t out[4]) {
   if (!sp || !out) return PYSDR_ERR_ARG;
-  out[0] = sp->group; out[1] = sp->force_rocfft ? 1 : 0; out[2] = 0; out[3] = 0;
+  out[0] = sp->group; out[1] = sp->force_rocfft ? 1 : 0; out[2] = sp->nstreams; out[3] = 0;
   return PYSDR_OK;
 }
 

@@ -287,6 +287,44 @@ int main(int argc, char** argv) {
              "\"32cols_no_window\": %.1f, \"32cols_window_8x4B\": %.1f, \"32cols_window_2x16B\": %.1f},\n", v00, v10, v20, v01, v11, v21);
     js += buf;
   }
+  {
+    // the same copies with the groups dealt over TWO streams, each with half a group of intermediate (what the
+    // product does since round 3): columns of one half-group beside the rows of the other
+    hipStream_t s2[2];
+    hipEvent_t fork, join;
+    CK(hipStreamCreateWithFlags(&s2[0], hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2[1], hipStreamNonBlocking));
+    CK(hipEventCreate(&fork)); CK(hipEventCreate(&join));
+    const int half = group / 2;
+    float2* wk[2] = {work, work + (size_t)half * kN};
+    auto two = [&](bool cpat) {
+      double m = 1e30;
+      for (int r = 0; r < reps + 1; ++r) {
+        CK(hipEventRecord(t.a, s2[0]));
+        CK(hipEventRecord(fork, s2[0])); CK(hipStreamWaitEvent(s2[1], fork, 0));
+        int k = 0;
+        for (int f0 = 0; f0 < nframes; f0 += half, ++k) {
+          const int nf = std::min(half, nframes - f0), w = k & 1;
+          if (cpat) {
+            cols_C<true, false><<<dim3(16, nf), 256, 0, s2[w]>>>((const float4*)(x + (size_t)f0 * hop), hop / 2, (float4*)wk[w]);
+            rows_C<false, true><<<dim3(8, nf), 512, 0, s2[w]>>>((const float4*)wk[w], (float4*)(out + (size_t)f0 * kN));
+          } else {
+            cols_P<<<dim3(16, nf), 256, 0, s2[w]>>>(x + (size_t)f0 * hop, hop, win, wk[w]);
+            rows_P<<<dim3(8, nf), 512, 0, s2[w]>>>(wk[w], out + (size_t)f0 * kN);
+          }
+        }
+        CK(hipEventRecord(join, s2[1])); CK(hipStreamWaitEvent(s2[0], join, 0));
+        CK(hipEventRecord(t.b, s2[0])); CK(hipEventSynchronize(t.b));
+        float ms; CK(hipEventElapsedTime(&ms, t.a, t.b));
+        if (r) m = std::min(m, (double)ms);
+      }
+      return m * 1e6 / nframes;
+    };
+    const double p2 = two(false), c2 = two(true);
+    snprintf(buf, sizeof buf, " \"two_streams_half_groups_pair_ns_per_frame\": {\"P_product_pattern\": %.1f, \"C_16B_nt_streams\": %.1f, "
+             "\"frac_of_8TBps_on_512KB_P\": %.3f, \"frac_of_8TBps_on_512KB_C\": %.3f},\n", p2, c2,
+             0.5 * 1048576 / p2 / 1e3 / 8.0, 0.5 * 1048576 / c2 / 1e3 / 8.0);
+    js += buf;
+  }
   snprintf(buf, sizeof buf, " \"nframes\": %d, \"group\": %d, \"reps\": %d, \"timing\": \"best of reps, hipEvents\"\n}\n", nframes, group, reps);
   js += buf;
   fputs(js.c_str(), stdout);
