@@ -4,4 +4,4 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from pysdr_amd.fileio import open_replay, open_writers, sdr_fileio  # noqa: E402,F401
+from pysdr_amd.fileio import SDR_FILEIO, open_replay, open_writers, sdr_fileio  # noqa: E402,F401

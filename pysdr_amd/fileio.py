@@ -162,6 +162,9 @@ class sdr_fileio:
         self.close()
 
 
+SDR_FILEIO = sdr_fileio          # the name sigs/iq.py:11,59 imports
+
+
 def open_writers(P, out_dir=None):
     """``pySDR.py:118-123``: the three writers hang off P."""
     P.raw_iq_io = sdr_fileio('raw_iq', 'w', P, 2, 'RAW_IQ', out_dir)
