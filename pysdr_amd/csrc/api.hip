@@ -144,6 +144,7 @@ struct pysdr_ctx {
   int tile_bytes = 0, threads = 1024;  // per LDS buffer (two per workgroup); 0 = as large as fits
   int wgs_per_cu = 1, num_cus = 256;
   int dbg_flags = 0, yflush_cap = 0;      // tuning / diagnostic switches, read from the environment once
+  int am_pll_waves = -1;                  // PYSDR_AM_PLL_WAVES=1 / 0: force the wave- / lane-per-segment carrier loop (A/B runs); -1 = by size
   int skew_override = -1;                 // PYSDR_MIXDEC_SKEW=0/1: force the tap-schedule skew off / on (A/B runs)
   int pll_kmax = 0;                       // pysdr_set_pll_segments: 0 = default, 1 = serial
   // pilot-PLL segmentation (PYSDR_WFM_PLL = "taus,taus_fast,taus_exact,coarse_sweeps,kmax,tmin" overrides for A/B runs)
@@ -565,6 +566,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   // tuning / ablation switches (bench.py and DESIGN.md 4.1 use them; all default to off)
   { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) c->wgs_per_cu = atoi(e); }
   { const char* e = getenv("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0) c->yflush_cap = atoi(e); }
+  { const char* e = getenv("PYSDR_AM_PLL_WAVES"); if (e && *e) c->am_pll_waves = atoi(e) > 0 ? 1 : 0; }
   { const char* e = getenv("PYSDR_MIXDEC_SKEW"); if (e && *e) c->skew_override = atoi(e) ? 1 : 0; }
   { const char* e = getenv("PYSDR_WFM_PLL");
     if (e && *e) {
@@ -1014,6 +1016,12 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   if (any_pll && n_out > 0) {
     // measured: identical floats after 4096 samples = 19 tau of the 50 Hz loop at 48 kHz
     s.pll = plan_pll(n_out, fs_out, kPllBwHz, 19.0, 0.0, 512, c->pll_kmax > 0 ? std::min(c->pll_kmax, kPllSegMax) : kPllSegMax, c->d_pllseg);
+    // One wave per segment runs the recursion 64 times over but keeps loads and stores off the chain (0.98 vs 1.36 ms
+    // for 512 segments: both are the latency of ONE segment's W + T dependent steps); beyond two waves per SIMD the
+    // redundant arithmetic is what takes the time and one LANE per segment wins (4096 segments: 1.92 vs 2.88 ms).
+    int npll = 0;
+    for (int r = 0; r < nrx; ++r) npll += (s.det[r] == kDetPll) ? 1 : 0;
+    s.pll_wave_segments = c->am_pll_waves >= 0 ? c->am_pll_waves : ((long)s.pll.K * npll <= 2048 ? 1 : 0);
     rc = launch_pll(s, c->stream);
     if (rc) return rc;
   }

@@ -119,6 +119,7 @@ struct Stage2Args {
   uint32_t m0_lo;                     // low 32 bits of the absolute index of output 0
   float fm_scale;
   float pll_kp, pll_ki;
+  int pll_wave_segments;              // A/B: one WAVE per carrier-loop segment (round 2) instead of one lane
   const float2* y[PYSDR_MAX_RX];      // points at element for output 0 (prefix before it)
   float2* ypll[PYSDR_MAX_RX];         // same layout, only for AM-Synch
   const float2* aftaps[PYSDR_MAX_RX]; // [4*ceil(ntaps/4)], zero padded

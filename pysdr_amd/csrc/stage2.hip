@@ -30,6 +30,22 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 // lane j keeps v = y*exp(-j*theta) of sample j for the detector stage, stored coalesced.
 // Nothing but arithmetic sits on the critical path (sin/cos by v_sin/v_cos on theta/2pi).
 // Parallelism comes from time: segments with warm-up + a patch-up pass (PllPlan, common.h).
+// one sample of the carrier loop: v = y exp(-j theta) (kept for the detector stage), then the loop update
+__device__ __forceinline__ float2 am_pll_step(float yr, float yi, float& th, float& w, float kp, float ki) {
+  const float pi = 3.14159265358979323846f, twopi = 6.28318530717958647692f;
+  const float inv2pi = 0.15915494309189533577f;
+  const float rev = th * inv2pi;
+  const float s = __builtin_amdgcn_sinf(rev), c = __builtin_amdgcn_cosf(rev);
+  const float vr = yr * c + yi * s;
+  const float vi = yi * c - yr * s;
+  const float e = atan2f(vi, vr);
+  w = w + ki * e;
+  th = th + (w + kp * e);
+  if (th >= pi) th -= twopi;
+  else if (th < -pi) th += twopi;
+  return make_float2(vr, vi);
+}
+
 template <bool EMIT>
 __device__ __forceinline__ void am_pll_walk(const Stage2Args& a, const float2* __restrict__ y,
                                             float2* __restrict__ o, int i_begin, int i_end, float& th,
@@ -46,6 +62,7 @@ __device__ __forceinline__ void am_pll_walk(const Stage2Args& a, const float2* _
     const int count = (i_end - i0 < 64) ? i_end - i0 : 64;
 #pragma unroll 4
     for (int j = 0; j < count; ++j) {
+      // (am_pll_step written out: through the call hipcc no longer unrolls this loop by 4)
       const float yr = lane_bcast(yv.x, j), yi = lane_bcast(yv.y, j);
       const float rev = th * inv2pi;
       const float s = __builtin_amdgcn_sinf(rev), c = __builtin_amdgcn_cosf(rev);
@@ -93,6 +110,53 @@ __global__ __launch_bounds__(64) void am_pll_seg_kernel(const Stage2Args a) {
   if (lane == 0) { sg[0] = __float_as_uint(th); sg[1] = __float_as_uint(w); }
   am_pll_walk<true>(a, a.y[r], a.ypll[r], s0, s1, th, w, lane);
   if (lane == 0) { sg[2] = __float_as_uint(th); sg[3] = __float_as_uint(w); }
+}
+
+// grid (ceil(K / 64), nrx): ONE LANE per segment.  The wave-per-segment kernel above runs the recursion 64 times over
+// (every lane the same), so with thousands of segments the time-parallel loop was bound by VALU throughput (4096
+// segments x 4672 samples x ~100 instructions: 7 ms per RX); here a wave carries 64 segments, the chain of one segment
+// is as long as before (W + T steps of ~190 ns) and the machine is nearly idle beside it.  Same steps in the same
+// order per segment: bit for bit the result of am_pll_seg_kernel.  Every lane reads and writes its own run of samples
+// (64 contiguous bytes per 8 steps, the next 8 samples in flight during the current 8).
+__global__ __launch_bounds__(64) void am_pll_lanes_kernel(const Stage2Args a) {
+  const int r = blockIdx.y, lane = threadIdx.x, k = blockIdx.x * 64 + lane;
+  if (a.det[r] != kDetPll) return;
+  const PllPlan& pl = a.pll;
+  const RxDevState* st = a.state + r;
+  const int n = a.n_out, T = pl.T, W = pl.W;
+  const bool live = k < pl.K;
+  const int s0 = k * T, s1 = live ? ((s0 + T < n) ? s0 + T : n) : s0;
+  const float kp = a.pll_kp, ki = a.pll_ki;
+  float th = st->pll_theta, w = st->pll_w;
+  if (k > 0 && s0 - W > 0) th = 0.f;         // guessed state W samples ahead; otherwise the walk starts at sample 0 from the true one
+  const float2* __restrict__ y = a.y[r];
+  float2* __restrict__ o = a.ypll[r];
+  uint32_t* sg = pl.seg + ((size_t)r * pl.K + (live ? k : 0)) * 4;
+  float2 cur[8], nxt[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = s0 - W + q;
+    cur[q] = (i >= 0 && i < s1) ? y[i] : make_float2(0.f, 0.f);
+  }
+  for (int t = -W; t < T; t += 8) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = s0 + t + 8 + q;
+      nxt[q] = (t + 8 < T && i >= 0 && i < s1) ? y[i] : make_float2(0.f, 0.f);
+    }
+    if (t == 0 && live) { sg[0] = __float_as_uint(th); sg[1] = __float_as_uint(w); }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = s0 + t + q;
+      if (i >= 0 && i < s1) {
+        const float2 v = am_pll_step(cur[q].x, cur[q].y, th, w, kp, ki);
+        if (t >= 0) o[i] = v;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+  }
+  if (live) { sg[2] = __float_as_uint(th); sg[3] = __float_as_uint(w); }
 }
 
 // grid (nrx): walk the chain of segments, redo what does not join up
@@ -854,7 +918,11 @@ __global__ __launch_bounds__(64) void wfm_pll_patch_kernel(const WfmArgs a) {
 }  // namespace
 
 int launch_pll(const Stage2Args& a, hipStream_t st) {
-  hipLaunchKernelGGL(am_pll_seg_kernel, dim3(a.pll.K, a.nrx), dim3(64), 0, st, a);
+  // one segment (every live call): the wave-wide walk with coalesced loads; more: one lane per segment
+  if (a.pll.K > 1 && !a.pll_wave_segments)
+    hipLaunchKernelGGL(am_pll_lanes_kernel, dim3((a.pll.K + 63) / 64, a.nrx), dim3(64), 0, st, a);
+  else
+    hipLaunchKernelGGL(am_pll_seg_kernel, dim3(a.pll.K, a.nrx), dim3(64), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(am_pll_patch_kernel, dim3(a.nrx), dim3(64), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());

@@ -153,6 +153,42 @@ def test_am_synch_carrier_pll_time_parallel_equals_the_serial_oracle():
     assert abs(st.gain - o.agc.gain) <= 1e-5 * o.agc.gain
 
 
+def _am_synch_batch(x, B, L, cfg):
+    P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[7e6], mode='AM-Synch', nfilt=255, max_batch_chunks=B)
+    P.VIDEO_BW = 10e3
+    g = sig_proc.Receiver(P, 100e3 - 7.0, 0, '1')
+    g.mode, g.af_bw = 'AM-Synch', 5e3
+    ctx = P._pysdr_stream
+    ctx.process_batch(x, B, L, on_device=False)
+    am = ctx.fetch(0, B)[0].copy()
+    seg, pat = pll_stats(ctx)
+    ctx.process_batch(x, B, L, on_device=False)          # second call: starts from the carried loop state
+    am2 = ctx.fetch(0, B)[0].copy()
+    return am, am2, seg, pat, (g.agc.gain, g.agc.maxbuf)
+
+
+def test_am_synch_one_lane_per_segment_equals_one_wave_per_segment(monkeypatch):
+    """The carrier loop with one LANE per segment (am_pll_lanes_kernel: 64 segments per wave, the default beyond
+    2048 segments per call, forced here with PYSDR_AM_PLL_WAVES=0) against the round-2 kernel that spends a whole wave on every segment (PYSDR_AM_PLL_WAVES=1): the same
+    steps in the same order per segment, so the audio must be equal bit for bit -- 150 chunks = 153.6k outputs =
+    300 segments (four full waves and a ragged fifth, a last segment shorter than T), two calls in a row."""
+    cfg = dict(so.CONFIGS['C1'])
+    cfg['ntaps_dec'] = 255
+    cfg['rx'] = [dict(frq=100e3 - 7.0, mode='AM-Synch', video_bw=10e3, af_bw=5e3)]
+    B = 150
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    x = so.synth_iq(cfg, B * L, 5)
+    monkeypatch.setenv("PYSDR_AM_PLL_WAVES", "0")
+    a1, a2, seg, pat, agc = _am_synch_batch(x, B, L, cfg)
+    monkeypatch.setenv("PYSDR_AM_PLL_WAVES", "1")
+    b1, b2, seg_w, pat_w, agc_w = _am_synch_batch(x, B, L, cfg)
+    assert seg == seg_w and seg >= 290, (seg, seg_w)
+    assert pat == pat_w and pat <= 2, (pat, pat_w)
+    assert np.array_equal(a1, b1) and np.array_equal(a2, b2)
+    assert agc == agc_w
+    assert np.max(np.abs(a1[2048:])) > 0.1 and not np.array_equal(a1, a2)
+
+
 def test_full_size_c4_time_parallel_equals_the_serial_walk():
     """BASELINE config #4 at the size and in the way bench.py times it: 2048 chunks x 213333 samples
     (3.5 GB) resident in HBM, three consecutive calls of ONE continuous broadcast-FM stream (call k
