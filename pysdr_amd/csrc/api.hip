@@ -128,6 +128,9 @@ struct pysdr_ctx {
   float2* d_stage = nullptr;
   size_t stage_cap = 0;
   unsigned* d_peak = nullptr;    // [max_chunks]
+#ifdef PYSDR_DIAG
+  unsigned long long* d_stamps = nullptr;   // mixdec phase stamps (PYSDR_DEBUG_FLAGS & 256)
+#endif
   unsigned* d_peak_scratch = nullptr;  // [1] sink for decimators whose raw peak is not wanted
   unsigned* d_blkpeak = nullptr; // [MAX_RX][max_chunks]
   float* d_gain = nullptr;       // [MAX_RX][max_chunks]
@@ -382,6 +385,13 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   a.chunk_len = peak ? (uint32_t)chunk_len : (uint32_t)std::max<size_t>(n, 1);
   a.magic_chunk = (a.chunk_len == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned long long)a.chunk_len) + 1u;
   a.dbg = c->dbg_flags;
+#ifdef PYSDR_DIAG
+  if ((c->dbg_flags & 256) && !c->d_stamps) {
+    PYSDR_HIP_CHECK(hipMalloc(&c->d_stamps, 2 * 16 * 24 * 8 * sizeof(unsigned long long)));
+    PYSDR_HIP_CHECK(hipMemset(c->d_stamps, 0, 2 * 16 * 24 * 8 * sizeof(unsigned long long)));
+  }
+  a.stamps = (c->dbg_flags & 256) ? c->d_stamps : nullptr;
+#endif
   int rc = launch_mixdec(a, c->threads, c->num_cus * wgs, c->stream);
   if (rc) return rc;
   rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, c->stream);
@@ -793,6 +803,16 @@ int pysdr_agc_get(pysdr_ctx* c, int irx, pysdr_agc_state* st) {
   st->agc = d.env; st->gain = d.gain; st->maxbuf = d.maxbuf; st->ref = d.ref; st->err = d.err;
   return PYSDR_OK;
 }
+
+#ifdef PYSDR_DIAG
+// diagnostic build only: the last launch's mixdec phase stamps, [2][16][24][8] uint64
+extern "C" int pysdr_diag_stamps(pysdr_ctx* c, unsigned long long* host) {
+  if (!c || !host || !c->d_stamps) return PYSDR_ERR_ARG;
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  PYSDR_HIP_CHECK(hipMemcpy(host, c->d_stamps, 2 * 16 * 24 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return PYSDR_OK;
+}
+#endif
 
 int pysdr_get_tuning(pysdr_ctx* c, int32_t out[8]) {
   if (!c || !out) return PYSDR_ERR_ARG;

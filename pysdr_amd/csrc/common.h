@@ -58,6 +58,9 @@ struct MixDecArgs {
   uint32_t chunk_len;
   uint32_t magic_chunk;   // floor(2^32/chunk_len)+1
   int dbg;                // diagnostic build switches (PYSDR_DEBUG_FLAGS); 0 in production
+#ifdef PYSDR_DIAG
+  unsigned long long* stamps;   // [2 workgroups][16 waves][24 tiles][8] s_memtime stamps of the tile loop's phases (or null)
+#endif
   // host-precomputed loop constants (the kernel's scalar unit is its scarcest resource)
   int tpc, ntasks;        // tasks (quads of outputs) per polyphase branch; up*tpc
   uint32_t magic_tpc;     // floor(2^32/tpc)+1

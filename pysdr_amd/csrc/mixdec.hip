@@ -37,8 +37,16 @@ namespace {
 // only in a diagnostic build (-DPYSDR_DIAG); the shipped kernel has no such branches.
 #ifdef PYSDR_DIAG
 #define PYSDR_DBG(a, bit) ((a).dbg & (bit))
+// phase stamps of the tile loop (scripts/diag/mixdec_stamps.py): workgroups 3 and 131, every wave, first 24 tiles
+#define PYSDR_STAMP(k)                                                                                              \
+  do {                                                                                                              \
+    if (a.stamps && lane == 0 && (tb - t_begin) < 24 && (blockIdx.x == 3 || blockIdx.x == 131))                      \
+      a.stamps[(((size_t)((blockIdx.x == 3 ? 0 : 1) * 16 + wave) * 24) + (tb - t_begin)) * 8 + (k)] =               \
+          __builtin_readcyclecounter();                                                                             \
+  } while (0)
 #else
 #define PYSDR_DBG(a, bit) 0
+#define PYSDR_STAMP(k) do {} while (0)
 #endif
 
 __device__ __forceinline__ float dpp_quad_xor1(float v) {
@@ -331,13 +339,17 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
     float2* const xn = ((tb - t_begin) & 1) ? buf0 : buf1;
     // tile tb has landed; after the barrier everybody is also done reading the other
     // buffer (tile tb-1), so it can be refilled while we compute.
+    PYSDR_STAMP(0);
     dma_wait();
+    PYSDR_STAMP(1);
     __syncthreads();
+    PYSDR_STAMP(2);
     Tile nxt = cur;
     if (tb + 1 < t_end) {
       nxt = (tb + 2 < a.ntiles) ? tile_advance(a, cur) : tile_geometry(a, tb + 1);
       if (!PYSDR_DBG(a, 2)) stage_tile(a, nxt, xn, tid, nthr);
     }
+    PYSDR_STAMP(3);
 
     // ---- raw-chunk peak |x|^2 over the samples this tile owns (rx.auto_mute input).
     // The running maximum of a chunk stays in a register across tiles; the atomic is only
@@ -403,6 +415,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
       }
     }
 
+    PYSDR_STAMP(4);
     // ---- polyphase dot products: one output per DPP row (16 lanes), four outputs of the
     // same polyphase branch per wave.  Task = (branch c, quad qq): outputs
     // i = i_first + c + UP*(4*qq + g), whose input index is rel_c + DOWN*(4*qq + g) with
@@ -488,6 +501,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
         fold_rotate_stage<R>(A, B, R, 0, s, valid, rel, my_p0, my_fw, ys, a.ycap, i - i_base);
       }
     }
+    PYSDR_STAMP(5);
     // ---- flush the output stage: RX r, 64 outputs per wave-store (512 contiguous bytes)
     if (tb + 1 == t_end || (tb - t_begin + 1) % a.yflush == 0) {
       __syncthreads();
@@ -502,6 +516,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
         }
       i_base = cur.i_first + cur.tile_n;
     }
+    PYSDR_STAMP(6);
     cur = nxt;
   }
   pk_run = wave_max63(pk_run);
