@@ -187,6 +187,12 @@ def test_am_synch_one_lane_per_segment_equals_one_wave_per_segment(monkeypatch):
     assert np.array_equal(a1, b1) and np.array_equal(a2, b2)
     assert agc == agc_w
     assert np.max(np.abs(a1[2048:])) > 0.1 and not np.array_equal(a1, a2)
+    # ... and both are the serial CarrierPLL of the oracle, chunk by chunk, over the two calls
+    o = so.make_receivers(cfg, np.float32)[0]
+    want = np.concatenate([o.demod_data(x[(k % B) * L:(k % B + 1) * L]) for k in range(2 * B)])
+    assert len(want) == len(a1) + len(a2)
+    assert relerr(a1[1024:], want[1024:len(a1)]) <= TOL
+    assert relerr(a2, want[len(a1):]) <= TOL
 
 
 def test_full_size_c4_time_parallel_equals_the_serial_walk():
