@@ -1036,12 +1036,12 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   if (any_pll && n_out > 0) {
     // measured: identical floats after 4096 samples = 19 tau of the 50 Hz loop at 48 kHz
     s.pll = plan_pll(n_out, fs_out, kPllBwHz, 19.0, 0.0, 512, c->pll_kmax > 0 ? std::min(c->pll_kmax, kPllSegMax) : kPllSegMax, c->d_pllseg);
-    // One wave per segment runs the recursion 64 times over but keeps loads and stores off the chain (0.98 vs 1.36 ms
-    // for 512 segments: both are the latency of ONE segment's W + T dependent steps); beyond two waves per SIMD the
-    // redundant arithmetic is what takes the time and one LANE per segment wins (4096 segments: 1.92 vs 2.88 ms).
+    // One wave per segment runs the recursion 64 times over but has the simplest chain (0.98 vs 1.16 ms for 512
+    // segments: both are the latency of ONE segment's W + T dependent steps); from two waves per SIMD on the redundant
+    // arithmetic is what takes the time and one LANE per segment wins (2048 segments: 1.23 vs 1.30 ms, 4096: 1.64 vs 2.87).
     int npll = 0;
     for (int r = 0; r < nrx; ++r) npll += (s.det[r] == kDetPll) ? 1 : 0;
-    s.pll_wave_segments = c->am_pll_waves >= 0 ? c->am_pll_waves : ((long)s.pll.K * npll <= 2048 ? 1 : 0);
+    s.pll_wave_segments = c->am_pll_waves >= 0 ? c->am_pll_waves : ((long)s.pll.K * npll < 2048 ? 1 : 0);
     rc = launch_pll(s, c->stream);
     if (rc) return rc;
   }

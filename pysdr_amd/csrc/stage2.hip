@@ -132,17 +132,24 @@ __global__ __launch_bounds__(64) void am_pll_lanes_kernel(const Stage2Args a) {
   const float2* __restrict__ y = a.y[r];
   float2* __restrict__ o = a.ypll[r];
   uint32_t* sg = pl.seg + ((size_t)r * pl.K + (live ? k : 0)) * 4;
-  float2 cur[8], nxt[8];
+  // The next block's samples are loaded from inline asm and waited for by hand at the END of the block: loads that
+  // hipcc knows about cost an s_waitcnt vmcnt(0) in front of every step (it cannot count across the loop's back edge),
+  // i.e. one memory latency per 8 steps on the chain.
+  typedef float pl_v2f __attribute__((ext_vector_type(2)));
+  pl_v2f cur[8], nxt[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int i = s0 - W + q;
-    cur[q] = (i >= 0 && i < s1) ? y[i] : make_float2(0.f, 0.f);
+    const float2 v = (i >= 0 && i < s1) ? y[i] : make_float2(0.f, 0.f);
+    cur[q] = (pl_v2f){v.x, v.y};
   }
   for (int t = -W; t < T; t += 8) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int i = s0 + t + 8 + q;
-      nxt[q] = (t + 8 < T && i >= 0 && i < s1) ? y[i] : make_float2(0.f, 0.f);
+      nxt[q] = (pl_v2f){0.f, 0.f};
+      if (t + 8 < T && i >= 0 && i < s1)
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(nxt[q]) : "v"(y + i) : "memory");
     }
     if (t == 0 && live) { sg[0] = __float_as_uint(th); sg[1] = __float_as_uint(w); }
 #pragma unroll
@@ -150,9 +157,19 @@ __global__ __launch_bounds__(64) void am_pll_lanes_kernel(const Stage2Args a) {
       const int i = s0 + t + q;
       if (i >= 0 && i < s1) {
         const float2 v = am_pll_step(cur[q].x, cur[q].y, th, w, kp, ki);
-        if (t >= 0) o[i] = v;
+        cur[q] = (pl_v2f){v.x, v.y};
       }
     }
+    if (t >= 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = s0 + t + q;
+        if (i < s1) o[i] = make_float2(cur[q].x, cur[q].y);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]), "+v"(nxt[5]), "+v"(nxt[6]), "+v"(nxt[7])
+                 :: "memory");
 #pragma unroll
     for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
   }
