@@ -754,11 +754,18 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
 template <bool EMIT>
 __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restrict__ o, int i_begin, int i_end,
                                              uint32_t& ph0, float& w0, int lane, int max_it = 66) {
-  float m_next = (i_begin + lane < i_end) ? o[i_begin + lane].x : 0.f;
+  // The block's mpx samples are loaded from inline asm one block ahead and waited for by hand at the END of the
+  // previous block: a prefetch hipcc knows about costs s_waitcnt vmcnt(0) in front of the first sweep of every block
+  // (it cannot count across the back edge), i.e. the NEXT block's memory latency on the chain of this one.
+  float m_next = 0.f;
+  if (i_begin + lane < i_end)
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(m_next) : "v"(&o[i_begin + lane].x) : "memory");
   for (int i0 = i_begin; i0 < i_end; i0 += 64) {
     const float m = m_next;
     const int nidx = i0 + 64 + lane;
-    m_next = (nidx < i_end) ? o[nidx].x : 0.f;             // in flight during the sweeps below
+    m_next = 0.f;
+    if (nidx < i_end)                                      // in flight during the sweeps below
+      asm volatile("global_load_dword %0, %1, off" : "=v"(m_next) : "v"(&o[nidx].x) : "memory");
     const int count = (i_end - i0 < 64) ? i_end - i0 : 64;
     const uint32_t inc0 = a.fword0 + (uint32_t)__float2int_rn(__fmul_rn(w0, a.rad2word));
     uint32_t ph = ph0 + (uint32_t)lane * inc0;             // guess: free running at the integrator's rate
@@ -777,6 +784,8 @@ __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restric
       ph = phn;
       if (same) break;
     }
+    // the next block's samples (issued a block of sweeps ago) and the previous block's store
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(m_next) :: "memory");
     if (EMIT && lane < count) {
       const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
       const float s2 = __builtin_amdgcn_sinf(2.f * rev);
