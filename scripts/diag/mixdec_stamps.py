@@ -1,6 +1,6 @@
 """Where a tile period of the mix+decimate kernel goes: s_memtime stamps of the tile loop's phases from the
 DIAGNOSTIC build (python -m pysdr_amd.build --diag; PYSDR_USE_DIAG_LIB=1 PYSDR_DEBUG_FLAGS=256).
-    PYSDR_USE_DIAG_LIB=1 PYSDR_DEBUG_FLAGS=256 python scripts/diag/mixdec_stamps.py [c1|c2] [chunks]
+    PYSDR_USE_DIAG_LIB=1 PYSDR_DEBUG_FLAGS=256 python scripts/diag/mixdec_stamps.py [c1|c2|c3] [chunks]
 Stamps (lane 0 of every wave of workgroups 3 and 131, first 24 tiles): 0 loop top, 1 after the wait for the tile's
 copies, 2 after the barrier, 3 after issuing the next tile's copies, 4 after the raw-peak scan, 5 after the dot
 products, 6 after the (occasional) flush of the output stage."""
@@ -17,6 +17,13 @@ if wl == 'c1':
     cfg = CONFIGS['C1']
     P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[7e6], mode='AM', nfilt=cfg['ntaps_dec'], max_batch_chunks=B)
     g = sig_proc.Receiver(P, 100e3, 0, '1')
+elif wl == 'c3':
+    cfg = CONFIGS['C3']
+    P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[146e6], mode='USB', nfilt=255, max_batch_chunks=B)
+    gs = [sig_proc.Receiver(P, f, i, str(i + 1)) for i, f in enumerate((200e3, -310e3, 455e3, -1.2e6))]
+    for g_, m in zip(gs, ('USB', 'CW', 'NFM', 'AM')):
+        g_.mode = m
+    g = gs[0]
 else:
     cfg = CONFIGS['C2']
     P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[146e6], mode='NFM', nfilt=255, max_batch_chunks=B)
