@@ -645,6 +645,61 @@ def test_full_size_psd_frames_do_not_depend_on_the_batch():
             lib.pysdr_dev_free(0, d)
 
 
+def test_psd_batch_is_the_same_on_any_number_of_streams_and_any_group(monkeypatch):
+    """The 64k PSD deals half-groups of frames over two HIP streams by default, each with its own intermediate, chained
+    by events (`pysdr_spectrum::nstreams`).  EVERY frame of a 3000-frame call (6.7 groups of 448) must be bit for bit
+    what one stream with one intermediate gives, whatever the number of streams (1, 2, 3) and the group size (448, 64 --
+    94 hand-overs) -- an event missing between the rows of one part and the columns that reuse its intermediate would show
+    here and nowhere in the sampled-frame test above."""
+    from pysdr_amd import _lib, design
+    cfg = so.CONFIGS['C3']
+    CH, NF, nframes = 32768, 65536, 3000
+    rng = np.random.default_rng(77)
+    base = so.synth_iq(cfg, 64 * CH, 12)
+    # 3000 frames out of 64 distinct ones, each scaled differently so that no two frames are equal
+    lib = _lib.lib()
+    d_x, d_o = C.c_void_p(), C.c_void_p()
+    _lib.check(lib.pysdr_dev_alloc(0, nframes * CH * 8, C.byref(d_x)), "alloc")
+    _lib.check(lib.pysdr_dev_alloc(0, nframes * NF * 4, C.byref(d_o)), "alloc")
+    win = np.ascontiguousarray(design.psd_window(CH), np.float32)
+    try:
+        scale = (0.25 + 0.75 * rng.random(nframes)).astype(np.float32)
+        for f0 in range(0, nframes, 64):
+            n = min(64, nframes - f0)
+            blk = (base[:n * CH].reshape(n, CH) * scale[f0:f0 + n, None]).astype(np.complex64)
+            _lib.check(lib.pysdr_dev_upload(0, C.c_void_p(d_x.value + f0 * CH * 8), C.c_void_p(blk.ctypes.data), n * CH * 8), "upload")
+        outs = {}
+        for streams, group in ((1, 448), (2, 448), (3, 448), (2, 64), (1, 2000)):
+            monkeypatch.setenv("PYSDR_PSD_STREAMS", str(streams))
+            monkeypatch.setenv("PYSDR_PSD_GROUP", str(group))
+            sp = C.c_void_p()
+            _lib.check(lib.pysdr_spectrum_create(0, CH, NF, nframes, _lib.as_pf(win), C.byref(sp)), "create")
+            try:
+                _lib.check(lib.pysdr_spectrum_batch(sp, d_x, nframes, CH, d_o), "batch")
+                _lib.check(lib.pysdr_spectrum_sync(sp), "sync")
+                got = np.empty(nframes * NF, np.float32)
+                _lib.check(lib.pysdr_dev_download(0, C.c_void_p(got.ctypes.data), d_o, got.nbytes), "dl")
+                # second call on the same object: the intermediates and events are reused
+                _lib.check(lib.pysdr_spectrum_batch(sp, d_x, nframes, CH, d_o), "batch")
+                _lib.check(lib.pysdr_spectrum_sync(sp), "sync")
+                again = np.empty(nframes * NF, np.float32)
+                _lib.check(lib.pysdr_dev_download(0, C.c_void_p(again.ctypes.data), d_o, again.nbytes), "dl")
+                assert np.array_equal(got, again), (streams, group)
+                outs[(streams, group)] = got
+            finally:
+                lib.pysdr_spectrum_destroy(sp)
+        ref = outs[(1, 448)]
+        for key, got in outs.items():
+            assert np.array_equal(got, ref), key
+        # ... and the frames are what the oracle says (three of them; frames differ by their scale: 20 log10)
+        for f in (0, 1777, nframes - 1):
+            x = (base[(f % 64) * CH:(f % 64 + 1) * CH] * scale[f]).astype(np.complex64)
+            psd_check(ref[f * NF:(f + 1) * NF], so.Spectrum(8000.0, CH, NF, 0.0, np.float64).periodogram(x, True))
+    finally:
+        for d in (d_x, d_o):
+            lib.pysdr_dev_free(0, d)
+
+
 def test_mix_decimate_is_linear_at_batch_size():
     """Size-independent property of the front end (LO mix + polyphase decimation is linear):
     iq(x1 + 2*x2) = iq(x1) + 2*iq(x2) over a 64-chunk batch, for every sub-receiver."""
