@@ -11,6 +11,7 @@
 #include <map>
 
 #include "common.h"
+#include "mixdec_mfma_geom.h"
 
 namespace pysdr {
 
@@ -146,9 +147,10 @@ struct pysdr_ctx {
   // tuning / profiling
   int tile_bytes = 0, threads = 1024;  // per LDS buffer (two per workgroup); 0 = as large as fits
   int wgs_per_cu = 1, num_cus = 256;
+  int grid_override = 0;               // PYSDR_MIXDEC_GRID: workgroups of the mix+decimate launches (tests: many tiles per workgroup in a small call)
+  int mfma_enable = 1;                 // long single-RX prototypes on the matrix cores (mixdec_mfma.hip); 0: VALU form (A/B)
   int dbg_flags = 0, yflush_cap = 0;      // tuning / diagnostic switches, read from the environment once
   int am_pll_waves = -1;                  // PYSDR_AM_PLL_WAVES=1 / 0: force the wave- / lane-per-segment carrier loop (A/B runs); -1 = by size
-  int skew_override = -1;                 // PYSDR_MIXDEC_SKEW=0/1: force the tap-schedule skew off / on (A/B runs)
   int pll_kmax = 0;                       // pysdr_set_pll_segments: 0 = default, 1 = serial
   // pilot-PLL segmentation (PYSDR_WFM_PLL = "taus,taus_fast,taus_exact,coarse_sweeps,kmax,tmin" overrides for A/B runs)
   // measured on MI355X (bench.py --workload c4, scripts/diag/pll_sweep.sh; front end ms per 2048 chunks):
@@ -231,6 +233,14 @@ int use_device(int dev) {
   return PYSDR_OK;
 }
 
+// The A/B and tuning switches of INTEGRATION.md ("tuning environment") are read ONLY when PYSDR_TUNING=1 is set as
+// well: a drop-in library must not change kernels because of a variable that happens to be in the environment.
+const char* tuning_env(const char* name) {
+  const char* on = getenv("PYSDR_TUNING");
+  if (!on || atoi(on) <= 0) return nullptr;
+  return getenv(name);
+}
+
 // g[p][k] = h[p + up*k] * exp(-j*w*k), w = 2*pi*fword/2^32
 void build_taps(const Decim& d, const double* h, int nt, uint32_t fword, float2* out) {
   for (int p = 0; p < d.up; ++p) {
@@ -305,6 +315,44 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   const int n_out = (int)(m1 - m0);
   if (n_out > y_cap) { set_last_error("decimator: n_out %d > capacity %d", n_out, y_cap); return PYSDR_ERR_STATE; }
   if ((double)n * up + down >= 2147483647.0) { set_last_error("decimator: call too long for 31-bit indices"); return PYSDR_ERR_ARG; }
+  // One RX with a long prototype at a rate that has an instantiation: the matrix-core form (mixdec_mfma.hip).  The
+  // choice depends on the decimator's shape only -- never on the call -- so every call of a stream sums in the
+  // same order (batch == chunk by chunk bit for bit), whatever the alignment of the caller's device pointer (the
+  // LDS-DMA takes any 4-byte aligned source: scripts/diag/glds_align_test.hip).
+  const int mshape = (nrx == 1 && c->mfma_enable) ? mixdec_mfma_shape(up, down, d.kdec) : -1;
+  MfmaPlan plan;
+  if (mshape >= 0 && mixdec_mfma_plan(mshape, s0, m0, n, &plan)) {
+    MixMfmaArgs b;
+    memset(&b, 0, sizeof(b));
+    b.x = d_x;
+    b.hist = d.d_hist[d.hist_cur];
+    b.hist_len = d.hist_len;
+    b.n_total = (uint32_t)n;
+    b.n_out = n_out;
+    b.origin_rel0 = plan.origin_rel0; b.d = plan.d; b.nrel0 = plan.nrel0; b.mrel0 = plan.mrel0; b.ntiles = plan.ntiles;
+    b.kpad = d.kpad;
+    b.taps = d.d_taps;
+    b.y = y[0];
+    b.phase0 = phase0[0]; b.fword = fword[0];
+    b.peak = peak ? peak : c->d_peak_scratch;
+    b.chunk_len = peak ? (uint32_t)chunk_len : (uint32_t)std::max<size_t>(n, 1);
+    b.magic_chunk = (b.chunk_len == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned long long)b.chunk_len) + 1u;
+#ifdef PYSDR_DIAG
+    if ((c->dbg_flags & 256) && !c->d_stamps) {
+      PYSDR_HIP_CHECK(hipMalloc(&c->d_stamps, 2 * 16 * 24 * 8 * sizeof(unsigned long long)));
+      PYSDR_HIP_CHECK(hipMemset(c->d_stamps, 0, 2 * 16 * 24 * 8 * sizeof(unsigned long long)));
+    }
+    b.stamps = (c->dbg_flags & 256) ? c->d_stamps : nullptr;
+#endif
+    int rc = launch_mixdec_mfma(mshape, b, c->grid_override > 0 ? c->grid_override : c->num_cus, c->stream);
+    if (rc) return rc;
+    rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, c->stream);
+    if (rc) return rc;
+    d.hist_cur ^= 1;
+    d.s_abs = s1;
+    if (res) { res->n_out = n_out; res->t0 = (uint32_t)(m0 * down - s0 * up); res->m0 = m0; }
+    return PYSDR_OK;
+  }
   MixDecArgs a;
   memset(&a, 0, sizeof(a));
   a.x = d_x;
@@ -366,19 +414,6 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   a.dq_last = (int)(((tile_out - 1) * down) / up);
   a.dr_last = (int)(((tile_out - 1) * down) % up);
   a.ntiles = n_out > 0 ? (n_out + a.tile_out - 1) / a.tile_out : 1;
-  // The four rows of a wave read x `down` samples = 8*down bytes apart and the LDS serves 256 bytes
-  // per clock: when that distance is within 64 bytes of a multiple of 256 the two rows of a half-wave
-  // share more than half of their banks, and the skewed tap schedule (which moves odd outputs by 128
-  // bytes) was the better one with ds_read_b64 reads (DOWN % 32 == 0: 2.048, 1.024, 2.56 MS/s -> 48 kHz).
-  // ... was: since the x reads carry immediate DS offsets hipcc fuses them in pairs into ds_read2_b64, which the
-  // LDS serves in groups of 16 lanes = ONE row, so rows no longer meet on a bank at all (SQ_LDS_BANK_CONFLICT 2.1 M per
-  // launch with the skew off as with it on) and the skew's two extra address registers cost 2 % (C1 0.446 vs 0.436 of
-  // HBM, same box, profiles/r03_c1_mixdec_skew{0,1}_pmc.json).  It stays available (PYSDR_MIXDEC_SKEW=1, and the tests
-  // run it) for a compiler that keeps ds_read_b64; the default is off.
-  {
-    a.skew = (c->skew_override > 0 && tile_out % (4L * up) == 0) ? 1 : 0;
-    a.m0_mod = (uint32_t)(m0 % (2ULL * (unsigned)up));
-  }
   a.taps = d.d_taps;
   for (int r = 0; r < nrx; ++r) { a.y[r] = y[r]; a.phase0[r] = phase0[r]; a.fword[r] = fword[r]; }
   a.peak = peak ? peak : c->d_peak_scratch;
@@ -392,7 +427,7 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   }
   a.stamps = (c->dbg_flags & 256) ? c->d_stamps : nullptr;
 #endif
-  int rc = launch_mixdec(a, c->threads, c->num_cus * wgs, c->stream);
+  int rc = launch_mixdec(a, c->threads, c->grid_override > 0 ? c->grid_override : c->num_cus * wgs, c->stream);
   if (rc) return rc;
   rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, c->stream);
   if (rc) return rc;
@@ -573,12 +608,13 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   // lines (partial lines are written through as masked writes = read-modify-write at the DRAM)
   c->hy = ((((cfg->ntaps_af + 7) & ~7) + 4 + 1) + 15) & ~15;
   c->cap_samples = (size_t)cfg->max_chunks * (size_t)cfg->in_chunk;
-  // tuning / ablation switches (bench.py and DESIGN.md 4.1 use them; all default to off)
-  { const char* e = getenv("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) c->wgs_per_cu = atoi(e); }
-  { const char* e = getenv("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0) c->yflush_cap = atoi(e); }
-  { const char* e = getenv("PYSDR_AM_PLL_WAVES"); if (e && *e) c->am_pll_waves = atoi(e) > 0 ? 1 : 0; }
-  { const char* e = getenv("PYSDR_MIXDEC_SKEW"); if (e && *e) c->skew_override = atoi(e) ? 1 : 0; }
-  { const char* e = getenv("PYSDR_WFM_PLL");
+  // tuning / ablation switches (bench.py and DESIGN.md 4.1 use them; all default to off, read only under PYSDR_TUNING=1)
+  { const char* e = tuning_env("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) c->wgs_per_cu = atoi(e); }
+  { const char* e = tuning_env("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0) c->yflush_cap = atoi(e); }
+  { const char* e = tuning_env("PYSDR_AM_PLL_WAVES"); if (e && *e) c->am_pll_waves = atoi(e) > 0 ? 1 : 0; }
+  { const char* e = tuning_env("PYSDR_MIXDEC_MFMA"); if (e && *e) c->mfma_enable = atoi(e) ? 1 : 0; }
+  { const char* e = tuning_env("PYSDR_MIXDEC_GRID"); if (e && atoi(e) > 0) c->grid_override = atoi(e); }
+  { const char* e = tuning_env("PYSDR_WFM_PLL");
     if (e && *e) {
       double a = c->wfm_taus, b = c->wfm_taus_fast, x = c->wfm_taus_exact;
       int sw = c->wfm_coarse_sweeps, km = c->wfm_kmax, tm = c->wfm_tmin;
@@ -822,7 +858,7 @@ int pysdr_get_tuning(pysdr_ctx* c, int32_t out[8]) {
   out[0] = 0;
 #endif
   out[1] = c->dbg_flags; out[2] = c->wgs_per_cu; out[3] = c->yflush_cap;
-  out[4] = c->tile_bytes; out[5] = c->threads; out[6] = c->num_cus; out[7] = 0;
+  out[4] = c->tile_bytes; out[5] = c->threads; out[6] = c->num_cus; out[7] = c->mfma_enable;
   return PYSDR_OK;
 }
 
@@ -1207,9 +1243,9 @@ int pysdr_spectrum_create(int device, int chunk_size, int nfft, int max_frames, 
   }
   pysdr_spectrum* sp = new pysdr_spectrum();
   sp->device = device; sp->chunk = chunk_size; sp->nfft = nfft; sp->max_frames = max_frames;
-  sp->force_rocfft = getenv("PYSDR_PSD_ROCFFT") != nullptr;
-  { const char* e = getenv("PYSDR_PSD_GROUP"); if (e && atoi(e) > 0) sp->group = atoi(e); }
-  { const char* e = getenv("PYSDR_PSD_STREAMS"); if (e && atoi(e) >= 1 && atoi(e) <= pysdr_spectrum::kMaxStreams) sp->nstreams = atoi(e); }
+  sp->force_rocfft = tuning_env("PYSDR_PSD_ROCFFT") != nullptr;
+  { const char* e = tuning_env("PYSDR_PSD_GROUP"); if (e && atoi(e) > 0) sp->group = atoi(e); }
+  { const char* e = tuning_env("PYSDR_PSD_STREAMS"); if (e && atoi(e) >= 1 && atoi(e) <= pysdr_spectrum::kMaxStreams) sp->nstreams = atoi(e); }
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_error("pysdr_spectrum_create: %s -> %s", #e, hipGetErrorString(_e)); pysdr_spectrum_destroy(sp); return PYSDR_ERR_HIP; } } while (0)
   CK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
   CK(hipMalloc(&sp->d_win, (size_t)chunk_size * sizeof(float)));

@@ -67,11 +67,38 @@ struct MixDecArgs {
   int dq_tile, dr_tile;   // divmod(tile_out*down, up)
   int dq_last, dr_last;   // divmod((tile_out-1)*down, up)
   int yflush, ycap;       // LDS output stage: flushed every yflush tiles; ycap = yflush*tile_out per RX
-  int skew;               // skewed tap schedule (mixdec.hip): rows DOWN samples apart would share LDS banks
-  uint32_t m0_mod;        // absolute index of the call's first output, mod 2*up (parity of m div up)
 };
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st);
 size_t mixdec_lds_bytes(const MixDecArgs& a);
+
+// ---- mix + decimate on the matrix cores, one RX with a long prototype (mixdec_mfma.hip) ----
+struct MfmaPlan;
+struct MixMfmaArgs {
+  const float2* x;        // this call's samples (16-byte aligned), x[0] = absolute sample S0
+  const float2* hist;     // hist[hist_len]: samples S0-hist_len .. S0-1
+  int hist_len;           // even
+  uint32_t n_total;
+  int n_out;
+  int origin_rel0, d, nrel0, mrel0, ntiles;   // MfmaPlan (mixdec_mfma_geom.h)
+  int kpad;               // row pitch of `taps`
+  const float2* taps;     // [up][kpad] LO-modulated polyphase taps of this RX
+  float2* y;              // y[i], i = 0 .. n_out-1
+  uint32_t phase0, fword;
+  unsigned* peak;         // [nchunks] max |x|^2 as float bits (atomicMax)
+  uint32_t chunk_len, magic_chunk;
+#ifdef PYSDR_DIAG
+  unsigned long long* stamps;   // [2 workgroups][16 waves][24 tiles][8] s_memtime stamps of the tile loop's phases (or null)
+#endif
+};
+// instantiations: X(id, UP, DOWN, S shifts, taps per branch, NB row blocks per tile, WK window slices, producer waves, LDS images)
+//   0: 2.048 MS/s -> 48 kHz with the reference's default 1001-tap prototype (params.py:134; am.py path, BASELINE C1)
+//   1: the 255-tap video filter of the broadcast-FM front end at 10 MS/s / 40 (BASELINE C4)
+#define PYSDR_MFMA_SHAPES(X) \
+  X(0, 3, 128, 2, 334, 1, 8, 8, 4) \
+  X(1, 1, 40, 8, 255, 1, 8, 8, 3)
+int mixdec_mfma_shape(int up, int down, int kdec);   // -1: none
+bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, unsigned long long n, MfmaPlan* p);
+int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t st);
 
 // ---- stage 2 at FS_OUT (stage2.hip) --------------------------------------------------
 #ifndef PYSDR_BLK_STRIDE

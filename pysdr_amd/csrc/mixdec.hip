@@ -220,16 +220,7 @@ __device__ __forceinline__ void fold_rotate_stage(const float2 (&A)[N], const fl
 }
 
 // NJ = kpad/16 known at compile time (fully unrolled tap loop) or 0 for a runtime loop.
-// SKEW: the four DPP rows of a wave read x DOWN samples apart.  When DOWN * 8 bytes is (nearly) a
-// multiple of the 256 bytes the LDS serves per clock -- DOWN = 128, 64, 160: every rate whose DOWN is
-// a multiple of 32 (Tables.py:44-45: 2.048, 1.024, 2.56 MS/s ...) -- the rows of one half-wave sit on
-// the SAME banks and every ds_read_b64 of the dot product takes twice its cycles.  Padding the tile
-// costs an address per read (it spilled).  Instead the TAP SCHEDULE is skewed: an output whose index
-// in its polyphase branch, (m div UP), is odd walks the tap groups in the order 1, 2, .., NJ-1, 0, so
-// adjacent rows read 128-byte pieces 128 bytes further apart = the other half of the banks.  The
-// rotation is a function of the ABSOLUTE output index, so an output is summed in the same order
-// whatever call or tile it falls into (batch == chunk by chunk, bit for bit).
-template <int R, int NJ, bool SKEW>
+template <int R, int NJ>
 __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   float2* const buf0 = lds;                    // [tile_cap]
@@ -296,17 +287,6 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
       if (hold_rbase + s == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; }
     asm volatile("" : "+v"(my_p0), "+v"(my_fw), "+v"(v_gup), "+v"(v_gdown));
   }
-  // skewed tap schedule: output i = i_first + c + UP*(4*qq + g) of this wave's branch c has
-  // (m div UP) = (m0 + c) div UP + i_first/UP + 4*qq + g, and i_first/UP is even (tile_out is a
-  // multiple of 4*UP): its parity is ((m0 + c) div UP + g) & 1, fixed per lane for the launch
-  int rot = 0;
-  if (SKEW) {
-    const int v = (int)a.m0_mod + hold_c;                // < 3*UP
-    rot = (((v >= a.up) ? 1 : 0) + ((v >= 2 * a.up) ? 1 : 0) + g) & 1;
-  }
-  int x_rot = -16 * rot, x_last = rot ? 0 : -16 * ((NJ > 0 ? NJ : 1) - 1);
-  if (SKEW) asm volatile("" : "+v"(x_rot), "+v"(x_last));
-
   Tile cur = tile_geometry(a, t_begin);
   int i_base = cur.i_first;      // first output held in the LDS output stage
   float pk_run = 0.f;            // running raw-chunk peak of chunk pk_chunk (per lane)
@@ -328,9 +308,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
     for (int r = 0; r < RH; ++r)
 #pragma unroll
       for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj) {
-        int idx = jj + (SKEW ? rot : 0);                 // the lane's jj-th tap group
-        if (SKEW && idx == NJ) idx = 0;
-        greg[r][jj] = (r < hold_rcount) ? th[r * a.up * kp0 + 16 * idx] : make_float2(0.f, 0.f);
+        greg[r][jj] = (r < hold_rcount) ? th[r * a.up * kp0 + 16 * jj] : make_float2(0.f, 0.f);
       }
   }
 
@@ -460,11 +438,10 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
         // (reads go through the LOWEST address + a non-negative offset: a DS offset field is unsigned,
         //  so xp[-16*jj] cost one VALU address add per read)
         constexpr int kTop = 16 * ((NJ > 0 ? NJ : 1) - 1);
-        const lds_cf2 xr = to_lds((SKEW ? xp + x_rot : xp) - kTop);   // odd outputs start one tap group later ...
-        const lds_cf2 xl = to_lds(SKEW ? xp + x_last : xp);            // ... and finish with group 0
+        const lds_cf2 xr = to_lds(xp - kTop);
 #pragma unroll
         for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj) {
-          const float2 xv = (SKEW && jj == NJ - 1) ? lds_ld(xl, 0) : lds_ld(xr, kTop - 16 * jj);
+          const float2 xv = lds_ld(xr, kTop - 16 * jj);
 #pragma unroll
           for (int r = 0; r < RH; ++r) {
             const float2 gg = greg[r][jj];
@@ -523,7 +500,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
 }
 
-template <int R, int NJ, bool SKEW>
+template <int R, int NJ>
 int launch_rj(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
   // the attribute is per (function, device): one bit per device, guarded against contexts on
   // other threads / other devices of the same process (P.GPU_DEVICE, cfg.device)
@@ -534,16 +511,16 @@ int launch_rj(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_
     PYSDR_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(attr_mu);
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mixdec_kernel<R, NJ, SKEW>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mixdec_kernel<R, NJ>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) {
-        set_last_error("hipFuncSetAttribute(mixdec<%d,%d,%d>): %s", R, NJ, (int)SKEW, hipGetErrorString(e));
+        set_last_error("hipFuncSetAttribute(mixdec<%d,%d>): %s", R, NJ, hipGetErrorString(e));
         return PYSDR_ERR_HIP;
       }
       attr_done |= 1ull << (dev & 63);
     }
   }
-  hipLaunchKernelGGL((mixdec_kernel<R, NJ, SKEW>), dim3(grid), dim3(threads), lds, st, a);
+  hipLaunchKernelGGL((mixdec_kernel<R, NJ>), dim3(grid), dim3(threads), lds, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }
@@ -551,17 +528,17 @@ int launch_rj(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_
 template <int R>
 int launch_r(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
   // 255-tap prototypes at UP = 3 (the BASELINE configurations) have 96 taps per branch
-  if (a.kpad == 96) return a.skew ? launch_rj<R, 6, true>(a, threads, grid, lds, st) : launch_rj<R, 6, false>(a, threads, grid, lds, st);
+  if (a.kpad == 96) return launch_rj<R, 6>(a, threads, grid, lds, st);
   // single-RX long filters: the 255-tap video filter of the broadcast-FM front end (UP = 1, 256
   // taps in one branch) and the reference's default 1001-tap prototype at UP = 3 (336 per branch)
   if constexpr (R == 1) {
     // the fs1 -> FS_OUT resampler of broadcast FM: 24/125 with 64 taps per branch (more branches than waves: generic
     // task order, but a compile-time tap loop)
-    if (a.kpad == 64) return launch_rj<R, 4, false>(a, threads, grid, lds, st);
-    if (a.kpad == 256) return launch_rj<R, 16, false>(a, threads, grid, lds, st);
-    if (a.kpad == 336) return a.skew ? launch_rj<R, 21, true>(a, threads, grid, lds, st) : launch_rj<R, 21, false>(a, threads, grid, lds, st);
+    if (a.kpad == 64) return launch_rj<R, 4>(a, threads, grid, lds, st);
+    if (a.kpad == 256) return launch_rj<R, 16>(a, threads, grid, lds, st);
+    if (a.kpad == 336) return launch_rj<R, 21>(a, threads, grid, lds, st);
   }
-  return launch_rj<R, 0, false>(a, threads, grid, lds, st);
+  return launch_rj<R, 0>(a, threads, grid, lds, st);
 }
 
 }  // namespace

@@ -125,7 +125,9 @@ __global__ __launch_bounds__(64) void am_pll_lanes_kernel(const Stage2Args a) {
   const RxDevState* st = a.state + r;
   const int n = a.n_out, T = pl.T, W = pl.W;
   const bool live = k < pl.K;
-  const int s0 = k * T, s1 = live ? ((s0 + T < n) ? s0 + T : n) : s0;
+  // (a lane beyond the last segment gets an EMPTY range, s1 = 0: every `i >= 0 && i < s1` below is then false, so it
+  //  neither loads -- its warm-up range would reach up to 63 segments past the end of y -- nor walks)
+  const int s0 = k * T, s1 = live ? ((s0 + T < n) ? s0 + T : n) : 0;
   const float kp = a.pll_kp, ki = a.pll_ki;
   float th = st->pll_theta, w = st->pll_w;
   if (k > 0 && s0 - W > 0) th = 0.f;         // guessed state W samples ahead; otherwise the walk starts at sample 0 from the true one
@@ -147,9 +149,11 @@ __global__ __launch_bounds__(64) void am_pll_lanes_kernel(const Stage2Args a) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int i = s0 + t + 8 + q;
+      // "+v": the register is zeroed BEFORE the asm and the load overwrites it in place, so no copy that merges a
+      // loaded and a zero value can land between the load and the hand-placed wait (the hardware does not interlock)
       nxt[q] = (pl_v2f){0.f, 0.f};
       if (t + 8 < T && i >= 0 && i < s1)
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(nxt[q]) : "v"(y + i) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(nxt[q]) : "v"(y + i) : "memory");
     }
     if (t == 0 && live) { sg[0] = __float_as_uint(th); sg[1] = __float_as_uint(w); }
 #pragma unroll
@@ -764,8 +768,8 @@ __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restric
     const float m = m_next;
     const int nidx = i0 + 64 + lane;
     m_next = 0.f;
-    if (nidx < i_end)                                      // in flight during the sweeps below
-      asm volatile("global_load_dword %0, %1, off" : "=v"(m_next) : "v"(&o[nidx].x) : "memory");
+    if (nidx < i_end)                                      // in flight during the sweeps below ("+v": see am_pll_lanes_kernel)
+      asm volatile("global_load_dword %0, %1, off" : "+v"(m_next) : "v"(&o[nidx].x) : "memory");
     const int count = (i_end - i0 < 64) ? i_end - i0 : 64;
     const uint32_t inc0 = a.fword0 + (uint32_t)__float2int_rn(__fmul_rn(w0, a.rad2word));
     uint32_t ph = ph0 + (uint32_t)lane * inc0;             // guess: free running at the integrator's rate

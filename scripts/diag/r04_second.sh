@@ -1,0 +1,18 @@
+# targeted tests (small-grid variants included), then ablation builds of mixdec_mfma.hip timed with bench.py c1 / c4
+O=gpurun_out/r04_second
+mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "c1 or long_prototype or random_call or c4 or wbfm or batch_equals or ragged or full_size_batch" > $O/pytest_sel.txt 2>&1
+tail -5 $O/pytest_sel.txt
+cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
+for fl in "" "-DMM_NO_MFMA" "-DMM_NO_DMA" "-DMM_NO_PK"; do
+  echo "=== flags: '$fl'"
+  PYSDR_MFMA_FLAGS="$fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { tail -5 /tmp/build.log; continue; }
+  for w in c1 c4; do
+    timeout 300 python bench.py --workload $w --no-cpu-baseline --no-host-fed --steps 15 --warmup 3 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$w', 'GS/s %.1f' % (d['value'] / 1e3), 'ms/step %.4f' % d['ms_per_step'], 'front ms %.4f' % d['kernel_ms']['front'], 'mixdec frac %.3f' % d['roofline_mixdec']['frac'])
+"
+  done
+done
+cp /tmp/keep.so pysdr_amd/libpysdr_hip.so

@@ -18,7 +18,7 @@ what=${1:-all}
 if [ "$what" = asan ] || [ "$what" = all ]; then
   build asan -fsanitize=address,undefined -fno-sanitize-recover=undefined
   ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 "$OUT/san_asan"
-  PYSDR_MIXDEC_SKEW=1 ASAN_OPTIONS=detect_leaks=1 "$OUT/san_asan" > /dev/null      # the opt-in skewed tap schedule
+  PYSDR_TUNING=1 PYSDR_MIXDEC_MFMA=0 ASAN_OPTIONS=detect_leaks=1 "$OUT/san_asan" > /dev/null   # long single-RX prototypes on the vector form
   ASAN_OPTIONS=detect_leaks=1 "$OUT/san_asan" race
 fi
 if [ "$what" = tsan ] || [ "$what" = all ]; then

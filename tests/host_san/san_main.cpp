@@ -142,6 +142,26 @@ static void narrowband(const Rate& r, int ntaps_dec) {
   pysdr_destroy(c);
 }
 
+// One sub-receiver with the reference's default 1001-tap prototype at the am.py rate: the matrix-core form of the
+// mix + decimate kernel (mixdec_mfma.hip).  Ragged and odd call lengths flip the parity of its LDS image.
+namespace pysdr { extern int g_mfma_launches; }
+static void single_rx_long_prototype() {
+  const Rate r = kRates[1];
+  const int max_chunks = 3, ntaps_dec = 1001, ntaps_af = 255;
+  pysdr_ctx* c = make_ctx(r, max_chunks, ntaps_dec, ntaps_af);
+  const auto h = taps(ntaps_dec), af = taps(2 * ntaps_af);
+  int irx = -1;
+  OK(pysdr_rx_add(c, PYSDR_AM, 100e3, h.data(), af.data(), 0.0, &irx));
+  const size_t L = (size_t)r.in_chunk;
+  const int before = pysdr::g_mfma_launches;
+  run_calls(c, r, 1, max_chunks, {L, 1, 2, 3, 17, L - 7, L + 11, 3 * L, 333, 2 * L + 1, L, 8191, 8193, 1, 1, 255, 256, 257});
+  const char* tun = getenv("PYSDR_TUNING");
+  const char* off = getenv("PYSDR_MIXDEC_MFMA");
+  const bool expect = !(tun && atoi(tun) > 0 && off && atoi(off) == 0);
+  if ((pysdr::g_mfma_launches > before) != expect) { std::fprintf(stderr, "matrix-core path: launches %d, expected %d\n", pysdr::g_mfma_launches - before, (int)expect); std::exit(1); }
+  pysdr_destroy(c);
+}
+
 static void broadcast_fm() {
   const Rate r = kRates[3];
   const int max_chunks = 4, ntaps = 255;
@@ -253,9 +273,17 @@ int main(int argc, char** argv) {
     if (r.fs == 10e6) continue;
     narrowband(r, 255);
   }
-  narrowband(kRates[1], 1001);                       // the reference's default prototype at the am.py rate (skewed schedule)
+  narrowband(kRates[1], 1001);                       // the reference's default prototype at the am.py rate
+  single_rx_long_prototype();
   narrowband(kRates[0], 1001);
-  broadcast_fm();
+  {
+    const int before = pysdr::g_mfma_launches;
+    broadcast_fm();                                  // its 10 MS/s / 40 IF decimator is the second matrix-core shape
+    const char* tun = getenv("PYSDR_TUNING");
+    const char* off = getenv("PYSDR_MIXDEC_MFMA");
+    const bool expect = !(tun && atoi(tun) > 0 && off && atoi(off) == 0);
+    if ((pysdr::g_mfma_launches > before) != expect) { std::fprintf(stderr, "broadcast FM: matrix-core launches %d\n", pysdr::g_mfma_launches - before); return 1; }
+  }
   spectrum();
   std::puts("HOST_SAN_OK");
   return 0;

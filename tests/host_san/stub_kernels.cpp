@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "mixdec_geom.h"
+#include "mixdec_mfma_geom.h"
 
 namespace pysdr {
 
@@ -59,8 +60,6 @@ int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t) {
   SAN_CHECK(a.tile_out >= 2 && (a.tile_out & 1) == 0 && a.ycap == a.yflush * a.tile_out && a.yflush >= 1, "tile_out %d", a.tile_out);
   SAN_CHECK(a.ntiles >= 1 && (long long)a.ntiles * a.tile_out >= a.n_out && (long long)(a.ntiles - 1) * a.tile_out <= std::max(a.n_out, 1), "ntiles");
   SAN_CHECK(a.dq_tile == (int)(((long long)a.tile_out * a.down) / a.up) && a.dr_tile == (int)(((long long)a.tile_out * a.down) % a.up), "tile step");
-  SAN_CHECK(a.m0_mod < 2u * (unsigned)a.up, "m0_mod");
-  if (a.skew) SAN_CHECK(a.tile_out % (4 * a.up) == 0, "skew needs whole quads of every branch per tile");
   // every byte the kernel may read or write exists
   read_all(a.x, a.n_total);
   read_all(a.hist, (size_t)a.hist_len);
@@ -100,6 +99,106 @@ int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t) {
   return PYSDR_OK;
 }
 
+// ---- the matrix-core form (mixdec_mfma.hip): the same walk the kernel takes, every DMA element read from the
+// real buffers, every window checked against what the image holds
+namespace {
+template <class G>
+int walk_mfma(const MixMfmaArgs& a, int grid) {
+  SAN_CHECK(grid >= 1, "grid %d", grid);
+  SAN_CHECK((a.hist_len & 1) == 0 && a.hist_len >= G::KT, "hist_len %d", a.hist_len);
+  SAN_CHECK((a.origin_rel0 & 1) == 0 && a.origin_rel0 <= 0 && (a.d == 0 || a.d == 1), "origin %d d %d", a.origin_rel0, a.d);
+  SAN_CHECK(a.nrel0 == a.origin_rel0 + G::KT - 1 + a.d, "nrel0 %d", a.nrel0);
+  SAN_CHECK(a.mrel0 <= 0 && a.mrel0 > -G::US, "mrel0 %d", a.mrel0);
+  SAN_CHECK(a.ntiles >= 1 && (long long)a.origin_rel0 + (long long)a.ntiles * G::TILE >= (long long)a.n_total, "tiles do not own the call");
+  SAN_CHECK(a.mrel0 + (long long)a.ntiles * G::OUT_PER_TILE >= a.n_out, "tiles do not hold the outputs");
+  read_all(a.taps, (size_t)G::UP * a.kpad);
+  const uint32_t nchunks = (a.n_total + a.chunk_len - 1) / a.chunk_len;
+  write_all(a.peak, nchunks);
+  write_all(a.y, (size_t)a.n_out);
+  std::vector<unsigned char> have((size_t)G::IMG_PIECES * 128);        // per 8-byte unit of the image: holds a stream sample
+  long long own_next = 0, outs = 0;
+  for (int tb = 0; tb < a.ntiles; ++tb) {
+    const int origin = a.origin_rel0 + tb * G::TILE;
+    std::fill(have.begin(), have.end(), 0);
+    for (int q = 0; q < G::IMG_PIECES * 64; ++q) {
+      const int seg = q / G::SPS, w = q - seg * G::SPS;
+      const int rel = origin + seg * G::P + 2 * w;
+      const bool ok = (w != G::P / 2) && rel >= -a.hist_len && rel + 1 < (int)a.n_total;
+      if (!ok) continue;
+      const float2* src = (rel >= 0) ? (a.x + rel) : (a.hist + (a.hist_len + rel));
+      SAN_CHECK((reinterpret_cast<uintptr_t>(src) & 7u) == 0, "tile %d slot %d: source not 8-byte aligned", tb, q);
+      read_all(src, 2);
+      have[2 * (size_t)q] = have[2 * (size_t)q + 1] = 1;
+    }
+    if (a.n_total & 1u) {
+      const int u = (int)a.n_total - 1 - origin;
+      if (u >= 0) {
+        const int seg = u / G::P, q = seg * G::SPS + ((u - seg * G::P) >> 1);
+        if (q < G::IMG_PIECES * 64) { read_all(a.x + (a.n_total - 1), 1); have[2 * (size_t)q] = 1; }
+      }
+    }
+    // ownership: the TILE samples from the image's origin
+    const int r_lo = origin > 0 ? origin : 0;
+    const int r_end = (origin + G::TILE < (int)a.n_total) ? origin + G::TILE : (int)a.n_total;
+    if (r_end > r_lo) {
+      SAN_CHECK(r_lo == own_next, "tile %d owns from %d, expected %lld", tb, r_lo, own_next);
+      for (int r = r_lo; r < r_end; ++r) {
+        const int u = r - origin, unit = u + 2 * (u / G::P);
+        SAN_CHECK(unit < (int)have.size() && have[(size_t)unit], "tile %d: owned sample %d not in the image", tb, r);
+      }
+      own_next = r_end;
+    }
+    // every tap of every valid output reads a sample the image holds; every read of the padded window is inside the image
+    for (int e = 0; e < G::OUT_PER_TILE; ++e) {
+      const int idx = a.mrel0 + tb * G::OUT_PER_TILE + e;
+      const int rho = e / G::US, rem = e - rho * G::US, t = rem / G::UP, c = rem - t * G::UP;
+      for (int j : {0, G::KPP - 1}) {                                                  // first and last sample of the padded window
+        const int unit = rho * (G::SEGB / 8) + (a.d + j) + 2 * ((a.d + j) / G::P);
+        SAN_CHECK(unit >= 0 && unit < (int)have.size(), "tile %d row %d: window sample %d outside the image", tb, rho, j);
+      }
+      if (idx < 0 || idx >= a.n_out) continue;
+      ++outs;
+      const int jtop = G::KT - 1 + t * G::DOWN + (c * G::DOWN) / G::UP;
+      const int rel_new = a.nrel0 + (tb * G::ROWS + rho) * G::P + t * G::DOWN + (c * G::DOWN) / G::UP;
+      SAN_CHECK(rel_new >= 0 && rel_new < (int)a.n_total, "tile %d output %d: newest sample %d outside the call", tb, idx, rel_new);
+      for (int k = 0; k < G::KT; ++k) {
+        const int j = jtop - k;
+        const int unit = rho * (G::SEGB / 8) + (a.d + j) + 2 * ((a.d + j) / G::P);
+        SAN_CHECK(have[(size_t)unit], "tile %d output %d tap %d: sample not in the image", tb, idx, k);
+      }
+    }
+  }
+  SAN_CHECK(own_next == (long long)a.n_total, "tiles own %lld samples, call has %u", own_next, a.n_total);
+  SAN_CHECK(outs == a.n_out, "tiles hold %lld outputs, call has %d", outs, a.n_out);
+  return PYSDR_OK;
+}
+}  // namespace
+
+int mixdec_mfma_shape(int up, int down, int kdec) {
+#define PYSDR_MFMA_MATCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF) \
+  if (up == UP && down == DOWN && kdec == KT) return ID;
+  PYSDR_MFMA_SHAPES(PYSDR_MFMA_MATCH)
+#undef PYSDR_MFMA_MATCH
+  return -1;
+}
+bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, unsigned long long n, MfmaPlan* p) {
+#define PYSDR_MFMA_PLAN(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF) \
+  if (shape == ID) return mfma_plan<MfmaGeo<UP, DOWN, S, KT, NB, WK, NP, NBUF>>(s0, m0, n, p);
+  PYSDR_MFMA_SHAPES(PYSDR_MFMA_PLAN)
+#undef PYSDR_MFMA_PLAN
+  return false;
+}
+int g_mfma_launches = 0;
+int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t) {
+  ++g_mfma_launches;
+#define PYSDR_MFMA_LAUNCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF) \
+  if (shape == ID) return walk_mfma<MfmaGeo<UP, DOWN, S, KT, NB, WK, NP, NBUF>>(a, grid);
+  PYSDR_MFMA_SHAPES(PYSDR_MFMA_LAUNCH)
+#undef PYSDR_MFMA_LAUNCH
+  SAN_CHECK(false, "no shape %d", shape);
+  return PYSDR_ERR_ARG;
+}
+
 int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len, uint32_t n_total, hipStream_t) {
   for (int j = 0; j < hist_len; ++j) {
     const long long rel = (long long)n_total - hist_len + j;
@@ -121,6 +220,18 @@ int launch_pll(const Stage2Args& a, hipStream_t) {
       SAN_CHECK(a.ypll[r] != nullptr, "AM-Synch rx %d has no PLL buffer", r);
       read_all(a.y[r], (size_t)a.n_out);
       write_all(a.ypll[r], (size_t)a.n_out);
+      // am_pll_lanes_kernel: grid = ceil(K / 64) waves, one lane per segment; lane k may load y[i] for every i in
+      // [s0 - W, s1) with i >= 0 && i < s1 -- the lanes behind the last segment of the last wave must get an empty
+      // range (with s1 = s0 they read up to 63 segments past the end of y)
+      const int K = a.pll.K, T = a.pll.T, W = a.pll.W;
+      for (int k = 0; k < (K + 63) / 64 * 64; ++k) {
+        const bool live = k < K;
+        const long long s0 = (long long)k * T;
+        const long long s1 = live ? std::min<long long>(s0 + T, a.n_out) : 0;     // the kernel's rule
+        const long long lo = std::max<long long>(s0 - W, 0), hi = s1;             // indices with i >= 0 && i < s1
+        if (hi > lo) SAN_CHECK(hi <= a.n_out, "carrier-loop lane %d reads y[%lld..%lld) of %d", k, lo, hi, a.n_out);
+        if (!live) SAN_CHECK(hi <= lo, "dead lane %d has a range", k);
+      }
     }
   read_all(a.state, (size_t)a.nrx);
   return PYSDR_OK;

@@ -167,9 +167,10 @@ def test_random_call_lengths_across_rates(fs, ntaps):
     """Tile geometry (incremental steps, whole-piece copies, chunk straddling, odd tails) under
     call lengths drawn at random, for UP/DOWN = 1/50, 2/75, 3/128, 3/625, 1/128, 3/64, 3/160: the
     baseband IQ and the raw-chunk peak must not depend on how the stream is cut.  The rates of
-    Tables.py:44-45 whose DOWN is a multiple of 32 (2.048, 1.024, 2.56 MS/s) run the skewed tap
-    schedule of mixdec.hip, with the 255-tap and the reference's default 1001-tap prototype
-    (params.py:134)."""
+    Tables.py:44-45 whose DOWN is a multiple of 32 (2.048, 1.024, 2.56 MS/s) are the ones whose rows share
+    LDS banks in mixdec.hip; 2.048 MS/s with the reference's default 1001-tap prototype (params.py:134) and
+    one sub-receiver would run on the matrix cores (mixdec_mfma.hip) -- here two sub-receivers keep it on
+    the vector form, the one-RX case is test_long_prototype_does_not_depend_on_the_cut."""
     rng = np.random.default_rng(int(fs) % 9973)
     L = so.chunk_sizes(fs, 48e3)[3]
     cfg = dict(so.CONFIGS['C2'], fs=fs, ntaps_dec=ntaps,
@@ -256,16 +257,25 @@ def test_batch_equals_chunked_bit_exact():
     assert np.allclose(pk, want, rtol=1e-6)
 
 
+@pytest.mark.parametrize("grid", [0, 3])
 @pytest.mark.parametrize("fs,ntaps", [(2.048e6, 1001), (1.024e6, 255)])
-def test_skewed_tap_schedule_does_not_depend_on_the_cut(fs, ntaps, monkeypatch):
-    """DOWN % 32 == 0: odd outputs of a polyphase branch walk their tap groups rotated by one (LDS
-    banks, mixdec.hip).  The rotation is a function of the ABSOLUTE output index, so the baseband
-    IQ is the same bit for bit whether the stream arrives chunk by chunk, in one batch, or cut at
-    random places (which moves every output to another tile, wave and DPP row)."""
+def test_long_prototype_does_not_depend_on_the_cut(fs, ntaps, grid, monkeypatch):
+    """One sub-receiver at 2.048 MS/s with the reference's default 1001-tap prototype runs the mix + decimate
+    on the matrix cores (mixdec_mfma.hip: rows = windows of the input, columns = the outputs a window feeds).
+    An output's row and column follow from its ABSOLUTE index and its window is summed in a fixed order, so the
+    baseband IQ is the same bit for bit whether the stream arrives chunk by chunk, in one batch, or cut at random
+    places -- odd ones included, which flips the parity of the LDS image (every output lands in another tile,
+    wave and row).  1.024 MS/s / 255 taps: the same on the vector form (DOWN % 32 == 0, rows on shared banks).
+    grid = 3: the launches are held to three workgroups (PYSDR_MIXDEC_GRID under PYSDR_TUNING=1), so every workgroup
+    walks MANY tiles even in these short calls -- the persistent loop's images in flight, the operand ring carried from
+    tile to tile and the partial-sum areas are only exercised that way (at the default grid a 12-chunk call gives
+    each workgroup a single tile; the first version of the carried ring was wrong and only the full-size test saw it)."""
+    if grid:
+        monkeypatch.setenv("PYSDR_TUNING", "1")
+        monkeypatch.setenv("PYSDR_MIXDEC_GRID", str(grid))
     cfg = dict(so.CONFIGS['C1'], fs=fs, ntaps_dec=ntaps,
                carriers=[dict(f=0.05 * fs, kind='am', amp=0.3, tone=1000.0, depth=0.5)],
                rx=[dict(frq=0.05 * fs, mode='AM', video_bw=10e3, af_bw=5e3)])
-    monkeypatch.setenv("PYSDR_MIXDEC_SKEW", "1")      # read by pysdr_create; off by default since round 3 (api.hip)
     L = so.chunk_sizes(fs, 48e3)[3]
     B = 12
     x = so.synth_iq(cfg, B * L, 31)
@@ -443,9 +453,14 @@ def test_convolver_streaming_fir_matches_scipy():
     assert np.max(np.abs(cz - signal.lfilter(h, [1.0], z.astype(np.complex128)))) <= TOL * np.max(np.abs(want))
 
 
-@pytest.mark.parametrize("stereo", [True, False])
-def test_c4_wbfm_10msps(stereo):
-    """config #4: WBFM path, 10 MS/s IQ, 1 RX, pilot-PLL stereo demod + 75 us de-emphasis."""
+@pytest.mark.parametrize("stereo,grid", [(True, 0), (False, 0), (True, 2)])
+def test_c4_wbfm_10msps(stereo, grid, monkeypatch):
+    """config #4: WBFM path, 10 MS/s IQ, 1 RX, pilot-PLL stereo demod + 75 us de-emphasis.  grid = 2: the mix + decimate
+    launches (IF decimator on the matrix cores, audio resampler on the vector form) held to two workgroups, so that each
+    walks ~20 tiles per chunk (see test_long_prototype_does_not_depend_on_the_cut)."""
+    if grid:
+        monkeypatch.setenv("PYSDR_TUNING", "1")
+        monkeypatch.setenv("PYSDR_MIXDEC_GRID", str(grid))
     from oracle import wfm_oracle as wo
     from pysdr_amd import sig_proc
     from pysdr_amd.params import RunTimeParams
