@@ -90,12 +90,31 @@ struct MixMfmaArgs {
   unsigned long long* stamps;   // [2 workgroups][16 waves][24 tiles][8] s_memtime stamps of the tile loop's phases (or null)
 #endif
 };
-// instantiations: X(id, UP, DOWN, S shifts, taps per branch, NB row blocks per tile, WK window slices, producer waves, LDS images)
+// instantiations: X(id, UP, DOWN, S shifts, taps per branch, NB row blocks per tile, WK window slices, producer waves, LDS images, operand ring carried across tiles)
 //   0: 2.048 MS/s -> 48 kHz with the reference's default 1001-tap prototype (params.py:134; am.py path, BASELINE C1)
 //   1: the 255-tap video filter of the broadcast-FM front end at 10 MS/s / 40 (BASELINE C4)
+// (producer waves / images can be overridden for A/B builds of mixdec_mfma.hip alone: they do not enter the host's plan)
+#ifndef MM_C1_NPROD
+#define MM_C1_NPROD 8
+#endif
+#ifndef MM_C1_NBUF
+#define MM_C1_NBUF 4
+#endif
+#ifndef MM_C4_NPROD
+#define MM_C4_NPROD 8
+#endif
+#ifndef MM_C4_NBUF
+#define MM_C4_NBUF 3
+#endif
+#ifndef MM_C1_CARRY
+#define MM_C1_CARRY 1
+#endif
+#ifndef MM_C4_CARRY
+#define MM_C4_CARRY 0
+#endif
 #define PYSDR_MFMA_SHAPES(X) \
-  X(0, 3, 128, 2, 334, 1, 8, 8, 4) \
-  X(1, 1, 40, 8, 255, 1, 8, 8, 3)
+  X(0, 3, 128, 2, 334, 1, 8, MM_C1_NPROD, MM_C1_NBUF, MM_C1_CARRY) \
+  X(1, 1, 40, 8, 255, 1, 8, MM_C4_NPROD, MM_C4_NBUF, MM_C4_CARRY)
 int mixdec_mfma_shape(int up, int down, int kdec);   // -1: none
 bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, unsigned long long n, MfmaPlan* p);
 int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t st);

@@ -169,7 +169,7 @@ struct MmChunk {
 //   ring   AHEAD steps of operands are in flight in registers and the ring is carried ACROSS tiles: the first AHEAD
 //          steps of a tile are read during the last MFMAs of the tile before (from the next image, which the top
 //          barrier of this trip already guaranteed), so the chain starts right behind the barrier.  Step m lives in
-//          slot m % AHEAD in every tile (SPW need not be a multiple of AHEAD: the head of the next tile is read in
+//          slot m % AHEAD in every tile (the slice length need not be a multiple of AHEAD: the head of the next tile is read in
 //          rotated order).  hipcc left alone reuses four registers with a full lgkmcnt(0) in front of every four MFMAs.
 //   peak   raw |x|^2 of the samples read in steps j0 < P + 4: row i's stretch [0, P + 4) of its window is image
 //          samples [d + i*P, d + i*P + P + 4), the 16 rows together cover the TILE samples this tile owns once (+ 4
@@ -181,8 +181,9 @@ template <class G, int Q>
 __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0, unsigned part0, int b_blk, int lane,
                                             int t_begin, int t_end) {
   constexpr int kA = G::AHEAD;
-  // this wave's share of the Toeplitz operand: steps [Q*SPW, (Q+1)*SPW) of the window, lane = (k = lane>>4, column)
-  float B1[G::SPW], B2[G::SPW];
+  // this wave's share of the Toeplitz operand: kN steps from step kS of the window, lane = (k = lane>>4, column)
+  constexpr int kN = G::slice_steps(Q), kS = G::slice_first(Q);
+  float B1[kN], B2[kN];
   {
     const int col = lane & 15, pr = col >> 1, part = col & 1;
     const int tt = pr / G::UP, cc = pr - tt * G::UP;
@@ -190,8 +191,8 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
     const int jtop = G::KT - 1 + tt * G::DOWN + offc - (lane >> 4);
     const float2* tp = a.taps + brc * a.kpad;
 #pragma unroll
-    for (int ls = 0; ls < G::SPW; ++ls) {
-      const int k = jtop - 4 * (Q * G::SPW + ls);
+    for (int ls = 0; ls < kN; ++ls) {
+      const int k = jtop - 4 * (kS + ls);
       float2 gg = make_float2(0.f, 0.f);
       if (pr < G::US && k >= 0 && k < G::KT) gg = tp[k];
       B1[ls] = part ? gg.y : gg.x;
@@ -204,7 +205,7 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
   // where this wave parks its partial tile: [b][q][col][row], 16 bytes = rows 4*(lane>>4) .. +3 of column lane & 15
   const unsigned part_off = part0 + (unsigned)((b_blk * G::WK + Q) * 1024 + (lane & 15) * 64 + (lane >> 4) * 16);
   auto rd = [&](mm_lds_cf2 pa, mm_lds_cf2 pb, int ls) {
-    const int j0 = 4 * (Q * G::SPW + ls);
+    const int j0 = 4 * (kS + ls);
     const int off8 = j0 + 2 * (j0 / G::P);                 // 8-byte units
     return (((j0 + 4) % G::P) == 0) ? pb[off8] : pa[off8];
   };
@@ -219,7 +220,9 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
 
   __syncthreads();                    // (1) tile t_begin has landed (mm_dma)
   mm_f2 ring[kA];
-  {
+#pragma unroll
+  for (int ls = 0; ls < kA; ++ls) ring[ls] = (mm_f2){0.f, 0.f};
+  if (G::CARRY) {
     const mm_lds_cf2 pa = (mm_lds_cf2)(size_t)lane_off, pb = (mm_lds_cf2)(size_t)(lane_off + lane_dB);
 #pragma unroll
     for (int ls = 0; ls < kA; ++ls) ring[ls] = rd(pa, pb, ls);
@@ -237,12 +240,17 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
       pk_run = 0.f;
       pk_chunk = ch.ck;
     }
-    // behind this barrier: tiles tb and tb+1 are in LDS, and the partial area this trip writes has been read
+    // behind this barrier: tiles tb and (CARRY) tb+1 are in LDS, and the partial area this trip writes has been read
     __syncthreads();
+    if (!G::CARRY) {                  // the head of the ring is read here, behind the barrier (one more tile of copies in flight instead)
+#pragma unroll
+      for (int ls = 0; ls < kA; ++ls) ring[ls] = rd(pa, pb, ls);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     mm_f4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     float m_prev = 0.f;
 #pragma unroll
-    for (int ls = 0; ls < G::SPW; ++ls) {
+    for (int ls = 0; ls < kN; ++ls) {
       const mm_f2 v = ring[ls % kA];
 #ifdef MM_NO_MFMA                     // experiment: the copy / LDS side alone (results WRONG)
       acc1[0] += v.x * B1[ls];
@@ -252,27 +260,26 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
       acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, B2[ls], acc2, 0, 0, 0);
 #endif
       // peak steps of this slice, in pairs: |x|^2 of the odd ones waits for the even one behind it
-      constexpr int kFirst = 4 * Q * G::SPW;
+      constexpr int kFirst = 4 * kS;
       const bool pk_step = (kFirst + 4 * ls) < G::P + 4;
       const int n_pk = (G::P + 4 - kFirst + 3) / 4;          // peak steps of this slice (<= 0: none; may exceed SPW)
       int nv = 0;
 #ifndef MM_NO_PK
       if (pk_step) {
         const float m = fmaf(v.x, v.x, v.y * v.y);
-        const bool last = (ls + 1 == G::SPW) || (ls + 1 >= n_pk);
+        const bool last = (ls + 1 == kN) || (ls + 1 >= n_pk);
         if ((ls & 1) == 0 && !last) { m_prev = m; nv = 2; }
         else if ((ls & 1) == 0) { if (pk_on) pk_run = fmaxf(pk_run, m); nv = 3; }
         else { if (pk_on) pk_run = __builtin_fmaxf(__builtin_fmaxf(pk_run, m_prev), m); nv = 3; }
       }
 #endif
-      {
-        const bool nxt = ls + kA >= G::SPW;                         // refill from the next image
-        ring[ls % kA] = nxt ? rd(na, nb, ls % kA) : rd(pa, pb, ls + kA);
-      }
+      const bool nxt = ls + kA >= kN;                               // refill from the next image
+      if (!nxt) ring[ls % kA] = rd(pa, pb, ls + kA);
+      else if (G::CARRY) ring[ls % kA] = rd(na, nb, ls % kA);
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);            // two MFMAs ...
       if (nv == 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // ... the peak of their sample ...
       else if (nv == 3) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // ... and the read that refills the slot
+      if (!nxt || G::CARRY) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // ... and the read that refills the slot
     }
     // the next trip's bookkeeping, while the last MFMAs are still in the pipe
     origin += G::TILE;
@@ -331,8 +338,8 @@ __device__ __forceinline__ void mm_epi(const MixMfmaArgs& a, unsigned part0, int
 }
 
 // The DMA waves: keep NBUF-1 tiles of copies in flight, and scan the raw peak of the (few) tiles whose image touches
-// two chunks.  At the top of trip tb they have issued tiles up to tb+NBUF-2 and guarantee that tiles up to tb+1 have
-// landed (the consumers read the head of tile tb+1 during the tail of tile tb): loads return in order, so "at most
+// two chunks.  At the top of trip tb they have issued tiles up to tb+NBUF-2 and guarantee that tiles up to tb+1 (CARRY: the
+// consumers read the head of tile tb+1 during the tail of tile tb; otherwise up to tb) have landed: loads return in order, so "at most
 // infl[..] loads outstanding" = everything older has landed.  infl[j] = copies this wave issued for tile tb+2+j; a
 // negative sum = unknown (edge tiles issue one copy per piece that has a live lane) = wait for everything.
 template <class G>
@@ -364,17 +371,19 @@ __device__ __forceinline__ void mm_dma(const MixMfmaArgs& a, unsigned lds0, int 
     mm_stage<G>(a, origin_rel, img, pw, npw, lane);
     return -1000;
   };
-  constexpr int kInfl = G::NBUF > 3 ? G::NBUF - 3 : 1;
-  int infl[kInfl];
+  constexpr int kNeed = G::CARRY ? 1 : 0;              // tiles beyond tb that must have landed at the top of trip tb
+  constexpr int kKI = G::NBUF - 2 - kNeed;             // tiles that may still be in flight there: tb+kNeed+1 .. tb+NBUF-2
+  static_assert(kKI >= 0, "images");
+  int infl[kKI > 0 ? kKI : 1];
 #pragma unroll
-  for (int j = 0; j < kInfl; ++j) infl[j] = 0;
+  for (int j = 0; j < (kKI > 0 ? kKI : 1); ++j) infl[j] = 0;
   {
     int n1 = 0;
 #pragma unroll
     for (int j = 0; j < G::NBUF - 1; ++j) {
       const int n = stage(t_begin + j, j);
       if (j >= 1) n1 += n;
-      if (j >= 2) infl[j - 2] = n;
+      if (j >= kNeed + 1 && j - kNeed - 1 < kKI) infl[j - kNeed - 1] = n;
     }
     mm_dma_wait_allow(n1);            // tile t_begin has landed
   }
@@ -389,17 +398,17 @@ __device__ __forceinline__ void mm_dma(const MixMfmaArgs& a, unsigned lds0, int 
     {
       int allow = 0;
 #pragma unroll
-      for (int j = 0; j < G::NBUF - 3; ++j) allow += infl[j];
-      mm_dma_wait_allow(G::NBUF > 3 ? allow : 0);
+      for (int j = 0; j < kKI; ++j) allow += infl[j];
+      mm_dma_wait_allow(allow);
     }
     // behind this barrier nobody reads the image of tile tb-1 any more: tile tb+NBUF-1 goes there
     __syncthreads();
     const int fslot = (slot == 0) ? G::NBUF - 1 : slot - 1;
     const int n_new = stage(tb + G::NBUF - 1, fslot);
-    if (G::NBUF > 3) {
+    if (kKI > 0) {
 #pragma unroll
-      for (int j = 0; j + 1 < G::NBUF - 3; ++j) infl[j] = infl[j + 1];
-      infl[kInfl - 1] = n_new;
+      for (int j = 0; j + 1 < kKI; ++j) infl[j] = infl[j + 1];
+      infl[kKI - 1] = n_new;
     }
     const bool one_chunk = ch.advance(a, origin, G::IMG_PIECES * 128);
     if (!one_chunk) {
@@ -491,6 +500,12 @@ __global__ __launch_bounds__(G::NTHREADS) void mixdec_mfma_kernel(const MixMfmaA
   }
   __syncthreads();                    // (0)
 
+#ifdef MM_CONS_PRIO                   // experiment: instruction arbitration priority of the roles
+  if (wave < G::NCONS) __builtin_amdgcn_s_setprio(MM_CONS_PRIO);
+#endif
+#ifdef MM_DMA_PRIO
+  if (wave >= G::NCONS && wave < G::NCONS + G::NDMA) __builtin_amdgcn_s_setprio(MM_DMA_PRIO);
+#endif
   if (wave < G::NCONS) {
     const int b_blk = wave / G::WK;
     mm_consumer_switch<G, 0>(wave - b_blk * G::WK, a, lds0, part0, b_blk, lane, t_begin, t_end);
@@ -530,7 +545,7 @@ int launch_g(const MixMfmaArgs& a, int grid, hipStream_t st) {
 
 // Which (UP, DOWN, taps per branch) have an instantiation: PYSDR_MFMA_SHAPES in common.h
 int mixdec_mfma_shape(int up, int down, int kdec) {
-#define PYSDR_MFMA_MATCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF) \
+#define PYSDR_MFMA_MATCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY) \
   if (up == UP && down == DOWN && kdec == KT) return ID;
   PYSDR_MFMA_SHAPES(PYSDR_MFMA_MATCH)
 #undef PYSDR_MFMA_MATCH
@@ -538,16 +553,16 @@ int mixdec_mfma_shape(int up, int down, int kdec) {
 }
 
 bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, unsigned long long n, MfmaPlan* p) {
-#define PYSDR_MFMA_PLAN(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF) \
-  if (shape == ID) return mfma_plan<MfmaGeo<UP, DOWN, S, KT, NB, WK, NP, NBUF>>(s0, m0, n, p);
+#define PYSDR_MFMA_PLAN(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY) \
+  if (shape == ID) return mfma_plan<MfmaGeo<UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY>>(s0, m0, n, p);
   PYSDR_MFMA_SHAPES(PYSDR_MFMA_PLAN)
 #undef PYSDR_MFMA_PLAN
   return false;
 }
 
 int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t st) {
-#define PYSDR_MFMA_LAUNCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF) \
-  if (shape == ID) return launch_g<MfmaGeo<UP, DOWN, S, KT, NB, WK, NP, NBUF>>(a, grid, st);
+#define PYSDR_MFMA_LAUNCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY) \
+  if (shape == ID) return launch_g<MfmaGeo<UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY>>(a, grid, st);
   PYSDR_MFMA_SHAPES(PYSDR_MFMA_LAUNCH)
 #undef PYSDR_MFMA_LAUNCH
   set_last_error("mixdec_mfma: no shape %d", shape);

@@ -16,16 +16,20 @@
 
 namespace pysdr {
 
-template <int UP_, int DOWN_, int S_, int KT_, int NB_, int WK_, int NPROD_, int NBUF_>
+template <int UP_, int DOWN_, int S_, int KT_, int NB_, int WK_, int NPROD_, int NBUF_, int CARRY_>
 struct MfmaGeo {
   static constexpr int UP = UP_, DOWN = DOWN_, S = S_, KT = KT_, NB = NB_, WK = WK_, NPROD = NPROD_, NBUF = NBUF_;
+  static constexpr bool CARRY = CARRY_ != 0;             // the operand ring is carried from tile to tile (needs the NEXT tile landed too)
   static constexpr int P = S * DOWN;                       // samples between consecutive rows
   static constexpr int US = UP * S;                        // outputs per row
   static constexpr int OFF_LAST = ((UP - 1) * DOWN) / UP;
   static constexpr int KP = KT + (S - 1) * DOWN + OFF_LAST;   // window length K'
   static constexpr int NSTEPS = (KP + 3) / 4;              // MFMA k-steps (4 samples each) per chain
-  static constexpr int SPW = (NSTEPS + WK - 1) / WK;       // steps per wave (WK contiguous slices of the window)
-  static constexpr int KPP = 4 * SPW * WK;                 // padded window
+  static constexpr int SPW = (NSTEPS + WK - 1) / WK;       // steps of the longest slice: WK contiguous slices of the window,
+  static constexpr int kExtra = NSTEPS % WK;               // the first NSTEPS % WK of them one step longer than the rest
+  static constexpr int slice_steps(int q) { return NSTEPS / WK + (q < kExtra ? 1 : 0); }
+  static constexpr int slice_first(int q) { return q * (NSTEPS / WK) + (q < kExtra ? q : kExtra); }
+  static constexpr int KPP = 4 * NSTEPS;                   // window padded to whole k-steps
   static constexpr int SEGB = 8 * P + 16;                  // bytes per LDS segment: P samples + one 16-byte pad
   static constexpr int SPS = P / 2 + 1;                    // 16-byte slots per segment
   static constexpr int ROWS = 16 * NB;
@@ -39,12 +43,12 @@ struct MfmaGeo {
   static constexpr int NEPI = (OUT_PER_TILE + 63) / 64;    // producer waves that run the epilogue (one thread per output)
   static constexpr int NDMA = NPROD - NEPI;                // producer waves that issue the copies
   static constexpr int NWAVES = NCONS + NPROD, NTHREADS = 64 * NWAVES;
-  static constexpr int AHEAD = SPW < 8 ? SPW : 8;          // k-steps of operands in flight per consumer wave
+  static constexpr int AHEAD = (NSTEPS / WK) < 8 ? (NSTEPS / WK) : 8;   // k-steps of operands in flight per consumer wave
   static constexpr int PART_BYTES = NB * WK * 1024;        // one tile's partial accumulators [NB][WK][16 cols][16 rows]
   static constexpr int LDS_BYTES = NBUF * IMG_BYTES + 2 * PART_BYTES;   // NBUF images: NBUF-1 tiles of copies in flight
   static_assert(P % 4 == 0, "a k-step of four samples must not straddle two segments for both parities");
   static_assert(2 * S * UP <= 16, "columns");
-  static_assert(NBUF >= 3 && NBUF <= 4, "images: one being worked on, one landed ahead of it, the rest in flight");
+  static_assert(NBUF >= 2 + (CARRY_ ? 1 : 0) && NBUF <= 4, "images: one being worked on, (CARRY) one landed ahead of it, the rest in flight");
   static_assert(KT - 1 >= (DOWN + UP - 1) / UP, "tile 0 must own the call's first sample");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   static_assert(NDMA >= 1, "producer waves");

@@ -52,18 +52,21 @@ class Geo:
         self.br = [(c * DOWN) % UP for c in range(UP)]
         self.KP = KT + (S - 1) * DOWN + self.off[UP - 1]          # K'
         self.nsteps = (self.KP + 3) // 4
-        self.spw = (self.nsteps + WK - 1) // WK                   # steps per wave
+        self.spw = (self.nsteps + WK - 1) // WK                   # steps of the longest slice
+        base, extra = divmod(self.nsteps, WK)                     # the first `extra` slices are one step longer
+        self.slice_first = [q * base + min(q, extra) for q in range(WK)]
+        self.slice_steps = [base + (1 if q < extra else 0) for q in range(WK)]
         self.SEGB = 8 * self.P + 16
         self.rows = 16 * NB
         self.tile_samples = self.rows * self.P                    # samples a tile advances by
-        self.img_samples = (self.rows - 1) * self.P + 4 * self.spw * WK + 1   # d + j max + 1
+        self.img_samples = (self.rows - 1) * self.P + 4 * self.nsteps + 1   # d + j max + 1
         nseg_full, tail = divmod(self.img_samples, self.P)
         self.img_slots = nseg_full * (self.P // 2 + 1) + (tail + 1) // 2
         self.img_bytes = self.img_slots * 16
 
     def bmat(self, g):
         """B1, B2 [4*spw*WK][16] float32"""
-        n = 4 * self.spw * self.WK
+        n = 4 * self.nsteps
         B1 = np.zeros((n, 16), np.float32)
         B2 = np.zeros((n, 16), np.float32)
         for t in range(self.S):
@@ -132,8 +135,8 @@ def run_call(geo, g, x_abs_fn, S0, n, hist_len, lds_model=True):
             for q in range(geo.WK):
                 acc1 = np.zeros((16, 16), np.float32)
                 acc2 = np.zeros((16, 16), np.float32)
-                for ls in range(geo.spw):
-                    j0 = 4 * (q * geo.spw + ls)
+                for ls in range(geo.slice_steps[q]):
+                    j0 = 4 * (geo.slice_first[q] + ls)
                     for kk in range(4):
                         j = j0 + kk
                         A = np.zeros(16, np.complex64)
@@ -193,12 +196,13 @@ def check(UP, DOWN, S, KT, NB, WK, ntaps, cuts, seed=0):
         nout += len(y)
         S0 += n
     print(f"UP {UP} DOWN {DOWN} S {S} KT {KT} NB {NB} WK {WK}: K' {geo.KP} steps {geo.nsteps} (x{geo.spw} per wave), "
-          f"image {geo.img_bytes} B, useful MACs {S*UP*KT*4/(32*4*geo.spw*WK):.3f}, outputs {nout}, worst rel {worst:.2e}")
+          f"image {geo.img_bytes} B, useful MACs {S*UP*KT*4/(32*4*geo.nsteps):.3f}, outputs {nout}, worst rel {worst:.2e}")
     assert worst < 1e-5
 
 
 if __name__ == "__main__":
     # C1: 2.048 MS/s, 1001 taps -> 334 per branch; odd cuts exercise d = 1
-    check(3, 128, 2, 334, 2, 4, 1001, [43690, 4097, 12345, 1, 2, 9000])
+    check(3, 128, 2, 334, 1, 8, 1001, [43690, 4097, 12345, 1, 2, 9000])
+    check(3, 128, 2, 334, 2, 4, 1001, [43690, 4097, 12345])
     # C4 IF decimator: 10 MS/s / 40, 255 taps
     check(1, 40, 8, 255, 1, 8, 255, [21333, 21333, 7, 15000])

@@ -175,15 +175,15 @@ int walk_mfma(const MixMfmaArgs& a, int grid) {
 }  // namespace
 
 int mixdec_mfma_shape(int up, int down, int kdec) {
-#define PYSDR_MFMA_MATCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF) \
+#define PYSDR_MFMA_MATCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY) \
   if (up == UP && down == DOWN && kdec == KT) return ID;
   PYSDR_MFMA_SHAPES(PYSDR_MFMA_MATCH)
 #undef PYSDR_MFMA_MATCH
   return -1;
 }
 bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, unsigned long long n, MfmaPlan* p) {
-#define PYSDR_MFMA_PLAN(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF) \
-  if (shape == ID) return mfma_plan<MfmaGeo<UP, DOWN, S, KT, NB, WK, NP, NBUF>>(s0, m0, n, p);
+#define PYSDR_MFMA_PLAN(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY) \
+  if (shape == ID) return mfma_plan<MfmaGeo<UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY>>(s0, m0, n, p);
   PYSDR_MFMA_SHAPES(PYSDR_MFMA_PLAN)
 #undef PYSDR_MFMA_PLAN
   return false;
@@ -191,8 +191,8 @@ bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, u
 int g_mfma_launches = 0;
 int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t) {
   ++g_mfma_launches;
-#define PYSDR_MFMA_LAUNCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF) \
-  if (shape == ID) return walk_mfma<MfmaGeo<UP, DOWN, S, KT, NB, WK, NP, NBUF>>(a, grid);
+#define PYSDR_MFMA_LAUNCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY) \
+  if (shape == ID) return walk_mfma<MfmaGeo<UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY>>(a, grid);
   PYSDR_MFMA_SHAPES(PYSDR_MFMA_LAUNCH)
 #undef PYSDR_MFMA_LAUNCH
   SAN_CHECK(false, "no shape %d", shape);
