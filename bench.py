@@ -42,8 +42,10 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PSD_CHUNK, PSD_NFFT = 32768, 65536
 DEFAULT_CHUNKS = {"c1": 4096, "c2": 2048, "c3": 2048, "c4": 2048, "c4mono": 2048}
-TUNING_ENV = ("PYSDR_MIXDEC_WGS", "PYSDR_MIXDEC_YFLUSH", "PYSDR_DEBUG_FLAGS", "PYSDR_PSD_GROUP",
-              "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_PSD_STREAMS", "PYSDR_WFM_PLL", "PYSDR_MIXDEC_SKEW", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS")
+TUNING_ENV = ("PYSDR_TUNING", "PYSDR_MIXDEC_WGS", "PYSDR_MIXDEC_YFLUSH", "PYSDR_DEBUG_FLAGS", "PYSDR_PSD_GROUP",
+              "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_PSD_STREAMS", "PYSDR_WFM_PLL", "PYSDR_MIXDEC_MFMA", "PYSDR_MIXDEC_GRID",
+              "PYSDR_AM_PLL_WAVES", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS", "PYSDR_MFMA_FLAGS")
+OTHER_CONFIGS = ("c1", "c2", "c4")      # the single-GPU BASELINE configurations the default line carries next to C3
 
 
 def parse(argv=None):
@@ -73,8 +75,12 @@ def parse(argv=None):
                          "`value`; 0 = skip")
     ap.add_argument("--verify", dest="verify", action="store_true", default=None,
                     help="after the timed loop every rank checks the LAST step's device buffers against the float32 "
-                         "oracle (first 2 chunks per sub-receiver, PSD frame 0); default ON when --gpus > 1")
+                         "oracle (first 2 chunks per sub-receiver, PSD frame 0); default ON")
     ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="the default command (workload c3, 1 GPU) also runs c1, c2 and c4 at their default batch for --steps "
+                         "steps each, in child processes AFTER its own timed loop, and reports them as `other_configs` "
+                         "(never as `value`); this switch skips that")
     return ap.parse_args(argv)
 
 
@@ -437,7 +443,7 @@ def measured_traffic(args, nrx, B, kernel_prefix, sources):
     while the kernel sources still hash to what was profiled (the profile file carries the hashes)."""
     if B != DEFAULT_CHUNKS[args.workload] or args.nrx:
         return None, None
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         # C3 (the demod kernels are the same with and without the PSD) or the workload's own passes
         name = f"{tag}_pmc_traffic.json" if args.workload == "c3" else f"{tag}_{args.workload}_pmc_traffic.json"
         p = os.path.join(ROOT, "profiles", name)
@@ -454,6 +460,39 @@ def measured_traffic(args, nrx, B, kernel_prefix, sources):
             return tot, (f"profiles/{name} (git {doc.get('git_head', '?') if isinstance(doc, dict) else '?'}): "
                          "2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of this same command")
     return None, None
+
+
+def other_configs(args):
+    """The other single-GPU BASELINE configurations (BASELINE.json configs[0], [1], [3]) through this same tool, one child
+    process each, AFTER the C3 loop has been timed and its buffers freed: throughput, step time, the front-end kernel's
+    and the job's roofline fraction and the verification stamp of each -- so that the driver's one record certifies
+    every configuration, not only the headline one ("Next round" 2).  Never `value`."""
+    res = {}
+    for w in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", str(args.steps), "--warmup",
+               str(args.warmup), "--no-cpu-baseline", "--no-host-fed", "--no-other-configs"]
+        if args.verify is not None:
+            cmd.append("--verify" if args.verify else "--no-verify")
+        t0 = time.time()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+            res[w] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                      "workload": d["config"]["workload"],
+                      "roofline": {"kernel": d["roofline_mixdec"]["kernel"], "frac": d["roofline_mixdec"]["frac"],
+                                   "achieved": d["roofline_mixdec"]["achieved"], "unit": "GB/s",
+                                   "avg_launch_ms": d["roofline_mixdec"]["avg_launch_ms"],
+                                   "traffic": d["roofline_mixdec"]["traffic"]} if d.get("roofline_mixdec") else None,
+                      "roofline_job": {"frac": d["roofline_job"]["frac"],
+                                       "algorithmic_bytes_per_sample": d["roofline_job"]["algorithmic_bytes_per_sample"]}
+                      if d.get("roofline_job") else None,
+                      "kernel_ms": d.get("kernel_ms"), "step_ms_stats": d.get("step_ms_stats"), "pilot_pll": d.get("pilot_pll"),
+                      "verified_ranks": d.get("verified_ranks"), "verify_worst_rel": d.get("verify_worst_rel"),
+                      "exit_code": p.returncode, "wall_s": round(time.time() - t0, 1)}
+        except Exception as e:            # a failed child must not take the headline line with it
+            res[w] = {"error": repr(e)[:300], "wall_s": round(time.time() - t0, 1)}
+    return res
 
 
 def main():
@@ -492,7 +531,7 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     split_rx = args.split == "rx"
-    do_verify = (world > 1) if args.verify is None else bool(args.verify)
+    do_verify = True if args.verify is None else bool(args.verify)
     if split_rx and world > ndev:
         raise SystemExit(f"--split rx needs one GPU per rank (RCCL): {world} ranks, {ndev} device(s)")
     with_psd = (args.workload == "c3") and not args.no_psd and (not split_rx or rank == 0)
@@ -725,10 +764,14 @@ def main():
         d.update(extra)
         return d
 
-    front_name = (f"mixdec_kernel<{nrx}> (fused NCO mix + polyphase decimate, all RX)" if not is_wfm else
-                  "mixdec_kernel<1,16> + wfm_disc/pll + mixdec_kernel<1,..> (FM front end: IF decimate, discriminator, pilot PLL, audio resample)")
+    mfma_on = bool(tune[7]) and nrx == 1 and ((not is_wfm and (P.UP, P.DOWN, cfg['ntaps_dec']) == (3, 128, 1001)) or
+                                              (is_wfm and rxs[0].demod.wfm_d1 == 40 and cfg['ntaps_dec'] == 255))
+    front_name = ((("mixdec_mfma_kernel (f32 MFMA, shifted-tap columns; " if mfma_on else f"mixdec_kernel<{nrx}> (") +
+                   "fused NCO mix + polyphase decimate, all RX)") if not is_wfm else
+                  (("mixdec_mfma_kernel<1/40>" if mfma_on else "mixdec_kernel<1,16>") +
+                   " + wfm_disc/pll + mixdec_kernel<1,..> (FM front end: IF decimate, discriminator, pilot PLL, audio resample)"))
     r_front = roof(front_name, k1_bytes, k1_ms if k1 else None,
-                   measured_traffic(args, nrx, B, "mixdec", ["mixdec.hip"]))
+                   measured_traffic(args, nrx, B, "mixdec", ["mixdec.hip", "mixdec_mfma.hip", "mixdec_mfma_geom.h"]))
     psd_tr = measured_traffic(args, nrx, B, "psd", ["psdfft.hip"])
     if psd_tr[0] is not None and sp is not None and sp_tune[0] > 0:
         # the profile's figure is per launch pair of one group of frames; one call = nframes / group of them
@@ -782,12 +825,13 @@ def main():
         "pilot_pll": pll,
         "tuning": {"diag_build": int(tune[0]), "debug_flags": int(tune[1]), "mixdec_wgs_per_cu": int(tune[2]),
                    "mixdec_yflush_cap": int(tune[3]), "tile_bytes": int(tune[4]), "threads": int(tune[5]),
+                   "mixdec_mfma": int(tune[7]),
                    "psd_group": int(sp_tune[0]) if sp is not None else None,
                    "psd_rocfft": int(sp_tune[1]) if sp is not None else None,
                    "psd_streams": int(sp_tune[2]) if sp is not None else None,
                    "env": {k: os.environ[k] for k in TUNING_ENV if k in os.environ},
                    "argv": " ".join(sys.argv[1:])},
-        "source_sha256": {s: source_sha(s) for s in ("mixdec.hip", "psdfft.hip", "stage2.hip", "api.hip")},
+        "source_sha256": {s: source_sha(s) for s in ("mixdec.hip", "mixdec_mfma.hip", "psdfft.hip", "stage2.hip", "api.hip")},
     }
     if duty is not None:
         out["at_reference_psd_duty"] = duty
@@ -829,6 +873,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if (rank == 0 and world == 1 and args.workload == "c3" and not args.no_other_configs and not args.no_demod
+            and not args.nrx and not args.no_psd and not args.chunks):
+        out["other_configs"] = other_configs(args)
     if rank == 0:
         try:                     # RCCL prints a version banner through C stdio: the JSON stays the LAST line
             C.CDLL(None).fflush(None)

@@ -109,12 +109,15 @@ struct MixMfmaArgs {
 #ifndef MM_C1_CARRY
 #define MM_C1_CARRY 1
 #endif
+#ifndef MM_C4_S
+#define MM_C4_S 8
+#endif
 #ifndef MM_C4_CARRY
 #define MM_C4_CARRY 0
 #endif
 #define PYSDR_MFMA_SHAPES(X) \
   X(0, 3, 128, 2, 334, 1, 8, MM_C1_NPROD, MM_C1_NBUF, MM_C1_CARRY) \
-  X(1, 1, 40, 8, 255, 1, 8, MM_C4_NPROD, MM_C4_NBUF, MM_C4_CARRY)
+  X(1, 1, 40, MM_C4_S, 255, 1, 8, MM_C4_NPROD, MM_C4_NBUF, MM_C4_CARRY)
 int mixdec_mfma_shape(int up, int down, int kdec);   // -1: none
 bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, unsigned long long n, MfmaPlan* p);
 int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t st);
