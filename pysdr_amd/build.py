@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpysdr_hip.so")
 LIB_DIAG = os.path.join(HERE, "libpysdr_hip_diag.so")   # loaded only when PYSDR_USE_DIAG_LIB=1
-SOURCES = ["api.hip", "mixdec.hip", "mixdec_mfma.hip", "stage2.hip", "misc.hip", "psdfft.hip", "waterfall.hip"]
+SOURCES = ["api.hip", "mixdec.hip", "mixdec_mfma.hip", "resamp_small.hip", "stage2.hip", "misc.hip", "psdfft.hip", "waterfall.hip"]
 # per-file extra flags (none needed today; -fno-slp-vectorize on mixdec.hip folds the DPP
 # reduction into v_add_f32_dpp but measured the same 96-99 us, so the default stays)
 EXTRA_FLAGS = {"mixdec.hip": os.environ.get("PYSDR_MIXDEC_FLAGS", "").split(),

@@ -47,6 +47,7 @@ PllPlan plan_pll(int n, double fs, double bw_hz, double taus, double taus_fast, 
   p.Wfast = taus_fast > 0 ? (((int)std::ceil(taus_fast * tau) + 63) & ~63) : 0;
   p.Wexact = 0;
   p.coarse_sweeps = 0;
+  p.exact_cap = 0;
   if (n < 3 * p.W || k_max <= 1) {
     p.K = 1;
     p.T = (std::max(n, 64) + 63) & ~63;
@@ -152,13 +153,14 @@ struct pysdr_ctx {
   int dbg_flags = 0, yflush_cap = 0;      // tuning / diagnostic switches, read from the environment once
   int am_pll_waves = -1;                  // PYSDR_AM_PLL_WAVES=1 / 0: force the wave- / lane-per-segment carrier loop (A/B runs); -1 = by size
   int pll_kmax = 0;                       // pysdr_set_pll_segments: 0 = default, 1 = serial
-  // pilot-PLL segmentation (PYSDR_WFM_PLL = "taus,taus_fast,taus_exact,coarse_sweeps,kmax,tmin" overrides for A/B runs)
+  // pilot-PLL segmentation (PYSDR_WFM_PLL = "taus,taus_fast,taus_exact,coarse_sweeps,kmax,tmin,exact_cap" overrides for A/B runs)
   // measured on MI355X (bench.py --workload c4, scripts/diag/pll_sweep.sh; front end ms per 2048 chunks):
   //   exact warm-ups 1.70 | 3 coarse sweeps + 6 / 5 / 4 tau exact 1.56 / 1.57 / 1.54 | 4 sweeps 1.61 | 2 sweeps: every join
   //   misses (180 ms of serial patching) | 3 sweeps + 3 tau exact: 115 joins miss | fast warm-up 11 / 9 tau: the check pass
   //   redoes the call (1.85 / 2.4) | 4096 / 3072 / 1024 segments with exact warm-ups 1.96 / 1.78 / 1.71 (2048: 1.70)
   double wfm_taus = 20.0, wfm_taus_fast = 13.0, wfm_taus_exact = 5.0;
   int wfm_coarse_sweeps = 3, wfm_kmax = 2048, wfm_tmin = 2048;
+  int wfm_exact_cap = 5;               // sweeps per block of the pilot loop's exact walks (0: to the bit-stable fixed point)
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
   hipEvent_t ev[kSlots][4] = {};
@@ -427,7 +429,11 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   }
   a.stamps = (c->dbg_flags & 256) ? c->d_stamps : nullptr;
 #endif
-  int rc = launch_mixdec(a, c->threads, c->grid_override > 0 ? c->grid_override : c->num_cus * wgs, c->stream);
+  // one RX, no raw peak wanted, short prototype and a small DOWN/UP (the fs1 -> FS_OUT stage of broadcast FM): one thread
+  // per output (resamp_small.hip).  Decided by the decimator's shape and its call site only, never by the call.
+  const bool small = (nrx == 1 && !peak && resamp_small_span(up, down, d.kpad) > 0);
+  int rc = small ? launch_resamp_small(a, c->stream)
+                 : launch_mixdec(a, c->threads, c->grid_override > 0 ? c->grid_override : c->num_cus * wgs, c->stream);
   if (rc) return rc;
   rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, c->stream);
   if (rc) return rc;
@@ -617,8 +623,9 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   { const char* e = tuning_env("PYSDR_WFM_PLL");
     if (e && *e) {
       double a = c->wfm_taus, b = c->wfm_taus_fast, x = c->wfm_taus_exact;
-      int sw = c->wfm_coarse_sweeps, km = c->wfm_kmax, tm = c->wfm_tmin;
-      const int got = sscanf(e, "%lf,%lf,%lf,%d,%d,%d", &a, &b, &x, &sw, &km, &tm);
+      int sw = c->wfm_coarse_sweeps, km = c->wfm_kmax, tm = c->wfm_tmin, xc = c->wfm_exact_cap;
+      const int got = sscanf(e, "%lf,%lf,%lf,%d,%d,%d,%d", &a, &b, &x, &sw, &km, &tm, &xc);
+      if (got >= 7 && xc >= 0) c->wfm_exact_cap = xc;
       if (got >= 1 && a > 0) c->wfm_taus = a;
       if (got >= 2 && b >= 0) c->wfm_taus_fast = b;
       if (got >= 3 && x > 0) c->wfm_taus_exact = x;
@@ -1017,6 +1024,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     // follows a crystal, so its phase is a straight line plus a bounded wobble) 54 after 13 tau
     w.pll = plan_pll(n1, fs1, kWfmPllBwHz, c->wfm_taus, c->wfm_taus_fast, c->wfm_tmin,
                      c->pll_kmax > 0 ? std::min(c->pll_kmax, c->wfm_kmax) : c->wfm_kmax, c->d_pllseg);
+    w.pll.exact_cap = c->wfm_exact_cap;
     if (c->wfm_coarse_sweeps > 0 && w.pll.K > 1) {
       const double tau = fs1 / (kPllZetaPlan * 2.0 * M_PI * kWfmPllBwHz);
       w.pll.Wexact = ((int)std::ceil(c->wfm_taus_exact * tau) + 63) & ~63;

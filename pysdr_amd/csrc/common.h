@@ -71,6 +71,10 @@ struct MixDecArgs {
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st);
 size_t mixdec_lds_bytes(const MixDecArgs& a);
 
+// one RX, short prototype, small DOWN/UP, no raw peak (resamp_small.hip): the fs1 -> FS_OUT stage of broadcast FM
+int resamp_small_span(int up, int down, int kpad);   // LDS samples a workgroup stages; 0 = shape not eligible
+int launch_resamp_small(const MixDecArgs& a, hipStream_t st);
+
 // ---- mix + decimate on the matrix cores, one RX with a long prototype (mixdec_mfma.hip) ----
 struct MfmaPlan;
 struct MixMfmaArgs {
@@ -162,6 +166,7 @@ struct PllPlan {
   int Wexact;               // the last Wexact samples of a warm-up run to the bit-exact fixed point like the segment itself;
                             // what lies in front of them gets `coarse_sweeps` sweeps per block (0: the whole warm-up is exact)
   int coarse_sweeps;
+  int exact_cap;            // sweeps per block of the "exact" walks (pilot loop; 0: until a sweep reproduces its input bit for bit)
   uint32_t* seg;            // [nrx][K][4]: S.phase, S.w, E.phase, E.w (float fields as bits)
 };
 

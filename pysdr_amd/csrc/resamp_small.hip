@@ -1,0 +1,110 @@
+// Rational resampler for ONE sub-receiver with a SHORT prototype and a small DOWN/UP ratio, without the raw-chunk
+// peak: the fs1 -> FS_OUT audio stage of broadcast FM (250 kHz -> 48 kHz = 24/125, 64 taps per branch; DESIGN.md 3.10,
+// the stage behind rx.demod's discriminator of Receiver.demod_data, receiver.py:235).  Same arithmetic contract as
+// mixdec.hip:  y[m] = exp(j phi(n_m)) sum_k g[p_m][k] x[n_m-k],  n_m = floor((t0 + m*DOWN)/UP), p_m = (t0 + m*DOWN) mod UP.
+//
+// Why not mixdec_kernel: that kernel gives every output a DPP row of 16 lanes (built for >= 96 taps per branch and a
+// stream that is read once at HBM speed).  With 64 taps an output's 16 lanes do 4 tap steps each and then pay the full
+// fold, rotate and index arithmetic: ~100 instructions per 4 outputs, and with 24 branches the taps cannot stay in
+// registers.  At the bench batch (10.9 M IF samples -> 2.1 M outputs) it took 117 us for 87 MB of input -- vector issue,
+// not memory.  Here ONE thread owns one output: 64 x (two 8-byte LDS reads + 4 FMAs), no cross-lane step; a workgroup's
+// 256 outputs span ~1400 consecutive inputs, staged once into LDS together with the (padded) tap table.
+// The sum runs over k = 0 .. kpad-1 in order whatever the call, tile or thread: batch == chunk by chunk bit for bit.
+#include "common.h"
+#include "mixdec_geom.h"
+
+namespace pysdr {
+
+namespace {
+
+constexpr int kRsThreads = 256;
+
+__global__ __launch_bounds__(kRsThreads) void resamp_small_kernel(const MixDecArgs a, int span_cap, int ngroups) {
+  extern __shared__ __attribute__((aligned(16))) float2 rs_lds[];
+  float2* const xs = rs_lds;                       // [span_cap] input span of one group of 256 outputs
+  float2* const tl = rs_lds + span_cap;            // [up][kpad + 1] taps (one pad per row: rows kpad*8 bytes apart would share a bank)
+  const int tid = threadIdx.x;
+  // the tap table once per workgroup (a workgroup walks every gridDim.x-th group of outputs)
+  const int kp1 = a.kpad + 1;
+  if (kRsThreads % a.kpad == 0) {
+    const int k = tid % a.kpad, rows = kRsThreads / a.kpad;
+    for (int p = tid / a.kpad; p < a.up; p += rows) tl[p * kp1 + k] = a.taps[p * a.kpad + k];
+  } else {
+    for (int j = tid; j < a.up * a.kpad; j += kRsThreads) {
+      const int p = j / a.kpad, k = j - p * a.kpad;
+      tl[p * kp1 + k] = a.taps[j];
+    }
+  }
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int i0 = grp * kRsThreads;
+    const int n_here = (a.n_out - i0 < kRsThreads) ? a.n_out - i0 : kRsThreads;
+    // input span [lo, hi] (relative to the call's first sample; negative = history)
+    uint32_t q0, r0, q1, r1;
+    divmod_magic(a.t0 + (uint32_t)i0 * (uint32_t)a.down, (uint32_t)a.up, a.magic, q0, r0);
+    divmod_magic(a.t0 + (uint32_t)(i0 + n_here - 1) * (uint32_t)a.down, (uint32_t)a.up, a.magic, q1, r1);
+    const int lo = (int)q0 - (a.kpad - 1), hi = (int)q1;
+    __syncthreads();                               // the previous group's reads of xs are done (and the taps are in place)
+    if (lo >= 0 && (uint32_t)hi < a.n_total) {
+      for (int j = tid; j <= hi - lo; j += kRsThreads) xs[j] = a.x[lo + j];
+    } else {
+      for (int j = tid; j <= hi - lo; j += kRsThreads) {
+        const int rel = lo + j;
+        float2 v = make_float2(0.f, 0.f);
+        if (rel >= 0) { if ((uint32_t)rel < a.n_total) v = a.x[rel]; }
+        else if (rel >= -a.hist_len) v = a.hist[a.hist_len + rel];
+        xs[j] = v;
+      }
+    }
+    __syncthreads();
+    if (tid < n_here) {
+      const int i = i0 + tid;
+      uint32_t q, p;
+      divmod_magic(a.t0 + (uint32_t)i * (uint32_t)a.down, (uint32_t)a.up, a.magic, q, p);
+      const float2* xp = xs + ((int)q - lo);       // x[n_m]; tap k reads xp[-k]
+      const float2* tp = tl + (int)p * kp1;
+      float sr = 0.f, si = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < a.kpad; ++k) {
+        const float2 g = tp[k], v = xp[-k];
+        sr = fmaf(g.x, v.x, sr);
+        sr = fmaf(-g.y, v.y, sr);
+        si = fmaf(g.x, v.y, si);
+        si = fmaf(g.y, v.x, si);
+      }
+      const uint32_t ph = a.phase0[0] + a.fword[0] * q;
+      const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+      const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+      float2 o;
+      o.x = sr * cs - si * sn;
+      o.y = sr * sn + si * cs;
+      a.y[0][i] = o;
+    }
+  }
+}
+
+}  // namespace
+
+// span of input samples 256 consecutive outputs need (+ the filter): what the launch reserves in LDS; 0 = not eligible
+int resamp_small_span(int up, int down, int kpad) {
+  const long span = ((long)kRsThreads * down + up - 1) / up + kpad + 4;
+  const long bytes = (span + (long)up * (kpad + 1)) * (long)sizeof(float2);
+  if (span > 4096 || bytes > 60 * 1024) return 0;
+  return (int)span;
+}
+
+int launch_resamp_small(const MixDecArgs& a, hipStream_t st) {
+  const int span = resamp_small_span(a.up, a.down, a.kpad);
+  if (span <= 0 || a.nrx != 1) {
+    set_last_error("resamp_small: up %d down %d kpad %d nrx %d not eligible", a.up, a.down, a.kpad, a.nrx);
+    return PYSDR_ERR_ARG;
+  }
+  if (a.n_out <= 0) return PYSDR_OK;
+  const size_t lds = ((size_t)span + (size_t)a.up * (a.kpad + 1)) * sizeof(float2);
+  const int ngroups = (a.n_out + kRsThreads - 1) / kRsThreads;
+  const int grid = ngroups < 2048 ? ngroups : 2048;        // ~8 workgroups per CU, each stages the tap table once
+  hipLaunchKernelGGL(resamp_small_kernel, dim3(grid), dim3(kRsThreads), lds, st, a, span, ngroups);
+  PYSDR_HIP_CHECK(hipGetLastError());
+  return PYSDR_OK;
+}
+
+}  // namespace pysdr

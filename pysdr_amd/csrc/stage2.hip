@@ -751,6 +751,10 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
 // broadcast FM (max 10) against 64 dependent steps of ten instructions each, 37 -> ~10 ns per sample.
 // The integrator is summed in scan order instead of sample by sample: up to ~370 words of 2^32 =
 // 5e-7 rad away from the sample-by-sample float32 walk of the oracle, inside the 1e-5 audio bar.
+// The "exact" walks stop after PllPlan::exact_cap sweeps (5): by the same 0.06^s that is < 3 words of 2^32 per block from
+// the bit-stable fixed point (which takes 6.6 sweeps on average, up to 10 where a rounding sits on the fence) -- two
+// orders below the scan-order deviation above -- and every walk, parallel or serial, uses the same cap, so the
+// time-parallel result still equals the one-segment walk bit for bit where the tests compare them.
 // max_it < 66: a COARSE walk for the early part of a warm-up -- after s sweeps the block's phases are
 // off by about 0.06^s of the first guess's error (the loop gain over 64 samples), i.e. two sweeps leave
 // ~1e-5 rad per block, which the exact tail of the warm-up (6 loop time constants: e^-6) forgets to
@@ -822,6 +826,7 @@ __global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
   uint32_t ph = st->wfm_phase;
   float w = st->wfm_w;
   const bool fast = pl.Wfast > 0 && st->wfm_slope_ok;
+  const int xcap = pl.exact_cap > 0 ? pl.exact_cap : 66;
   int wb = s0 - (fast ? pl.Wfast : pl.W);
   if (k > 0 && wb > 0) {
     if (fast) {
@@ -843,11 +848,11 @@ __global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
     // coarse sweeps first, the last Wexact samples exactly (both bounds on multiples of 64)
     const int sx = (pl.coarse_sweeps > 0 && s0 - pl.Wexact > wb) ? s0 - pl.Wexact : wb;
     if (wb < sx) wfm_pll_walk<false>(a, a.w[r], wb, sx, ph, w, lane, pl.coarse_sweeps);
-    wfm_pll_walk<false>(a, a.w[r], sx, s0, ph, w, lane);
+    wfm_pll_walk<false>(a, a.w[r], sx, s0, ph, w, lane, xcap);
   }
   uint32_t* sg = pl.seg + ((size_t)r * pl.K + k) * 4;
   if (lane == 0) { sg[0] = ph; sg[1] = __float_as_uint(w); }
-  wfm_pll_walk<true>(a, a.w[r], s0, s1, ph, w, lane);
+  wfm_pll_walk<true>(a, a.w[r], s0, s1, ph, w, lane, xcap);
   if (lane == 0) { sg[2] = ph; sg[3] = __float_as_uint(w); }
 }
 
@@ -910,7 +915,7 @@ __global__ __launch_bounds__(64) void wfm_pll_patch_kernel(const WfmArgs a) {
     bool joined = false;
     while (j < K) {
       const int s0 = j * pl.T, s1 = (s0 + pl.T < n) ? s0 + pl.T : n;
-      wfm_pll_walk<true>(a, a.w[r], s0, s1, ph, w, lane);
+      wfm_pll_walk<true>(a, a.w[r], s0, s1, ph, w, lane, pl.exact_cap > 0 ? pl.exact_cap : 66);
       ++patched;
       ++j;
       if (j < K && !wfm_state_differs(ph, w, sg[(size_t)j * 4 + 0], __uint_as_float(sg[(size_t)j * 4 + 1]))) {

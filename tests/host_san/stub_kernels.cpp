@@ -99,6 +99,34 @@ int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t) {
   return PYSDR_OK;
 }
 
+// ---- the short-prototype resampler (resamp_small.hip): every workgroup's input span fits what the launch reserves
+int resamp_small_span(int up, int down, int kpad) {
+  const long span = (256L * down + up - 1) / up + kpad + 4;
+  const long bytes = (span + (long)up * (kpad + 1)) * (long)sizeof(float2);
+  if (span > 4096 || bytes > 60 * 1024) return 0;
+  return (int)span;
+}
+int g_small_launches = 0;
+int launch_resamp_small(const MixDecArgs& a, hipStream_t) {
+  ++g_small_launches;
+  const int span = resamp_small_span(a.up, a.down, a.kpad);
+  SAN_CHECK(span > 0 && a.nrx == 1, "shape");
+  SAN_CHECK(a.hist_len >= a.kpad - 1, "hist_len %d kpad %d", a.hist_len, a.kpad);
+  read_all(a.x, a.n_total);
+  read_all(a.hist, (size_t)a.hist_len);
+  read_all(a.taps, (size_t)a.up * a.kpad);
+  write_all(a.y[0], (size_t)a.n_out);
+  for (int i0 = 0; i0 < a.n_out; i0 += 256) {
+    const int n_here = std::min(256, a.n_out - i0);
+    const long long lo = ((long long)a.t0 + (long long)i0 * a.down) / a.up - (a.kpad - 1);
+    const long long hi = ((long long)a.t0 + (long long)(i0 + n_here - 1) * a.down) / a.up;
+    SAN_CHECK(hi - lo + 1 <= span, "workgroup at output %d needs %lld samples, reserved %d", i0, hi - lo + 1, span);
+    SAN_CHECK(hi < (long long)a.n_total, "output %d reads sample %lld of %u", i0 + n_here - 1, hi, a.n_total);
+    SAN_CHECK(lo >= -(long long)a.hist_len - 1, "output %d reads %lld samples into the history of %d", i0, -lo, a.hist_len);
+  }
+  return PYSDR_OK;
+}
+
 // ---- the matrix-core form (mixdec_mfma.hip): the same walk the kernel takes, every DMA element read from the
 // real buffers, every window checked against what the image holds
 namespace {
