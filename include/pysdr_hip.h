@@ -180,7 +180,9 @@ void pysdr_spectrum_destroy(pysdr_spectrum* sp);
 int pysdr_spectrum_frame(pysdr_spectrum* sp, const float* x, int is_complex, int db,
                          float* psd_out, int* n_out);
 /* nframes frames taken every `hop` samples from a device-resident complex stream;
- * d_out = device [nframes][nfft] float (dB, fftshifted) */
+ * d_out = device [nframes][nfft] float (dB, fftshifted).  The fused 64k path deals its groups of frames over two HIP
+ * streams by default (per-kernel durations of a profiler trace then overlap; PYSDR_TUNING=1 PYSDR_PSD_STREAMS=1 for
+ * un-overlapped kernel times, INTEGRATION.md "tuning environment"); the call's own stream waits for the side stream. */
 int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size_t hop,
                          void* d_out);
 int pysdr_spectrum_sync(pysdr_spectrum* sp);

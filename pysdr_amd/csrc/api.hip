@@ -339,13 +339,6 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
     b.peak = peak ? peak : c->d_peak_scratch;
     b.chunk_len = peak ? (uint32_t)chunk_len : (uint32_t)std::max<size_t>(n, 1);
     b.magic_chunk = (b.chunk_len == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned long long)b.chunk_len) + 1u;
-#ifdef PYSDR_DIAG
-    if ((c->dbg_flags & 256) && !c->d_stamps) {
-      PYSDR_HIP_CHECK(hipMalloc(&c->d_stamps, 2 * 16 * 24 * 8 * sizeof(unsigned long long)));
-      PYSDR_HIP_CHECK(hipMemset(c->d_stamps, 0, 2 * 16 * 24 * 8 * sizeof(unsigned long long)));
-    }
-    b.stamps = (c->dbg_flags & 256) ? c->d_stamps : nullptr;
-#endif
     int rc = launch_mixdec_mfma(mshape, b, c->grid_override > 0 ? c->grid_override : c->num_cus, c->stream);
     if (rc) return rc;
     rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, c->stream);
@@ -1357,14 +1350,14 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
         const int w = k % ns;
         rc = launch_psd64k(d_x + (size_t)f0 * hop, hop, nf, sp->d_win, w ? sp->xwork[w] : sp->d_work,
                            d_out + (size_t)f0 * sp->nfft, db, w ? sp->xstream[w] : sp->stream);
-        if (rc) return rc;
-      }
+        if (rc) break;             // a failed launch still joins the side streams below: what was forked keeps writing
+      }                            // d_out / xwork until it is done, and the caller reacts to the error right away
       for (int i = 1; i < ns; ++i) {
         PYSDR_HIP_CHECK(hipEventRecord(sp->ev_join[i], sp->xstream[i]));
         PYSDR_HIP_CHECK(hipStreamWaitEvent(sp->stream, sp->ev_join[i], 0));
       }
       PYSDR_HIP_CHECK(hipEventRecord(sp->ev[1], sp->stream));
-      return PYSDR_OK;
+      return rc;
     }
     rc = ensure_work(sp, (size_t)std::min(group, nframes));
     if (rc) return rc;

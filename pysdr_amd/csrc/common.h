@@ -90,9 +90,6 @@ struct MixMfmaArgs {
   uint32_t phase0, fword;
   unsigned* peak;         // [nchunks] max |x|^2 as float bits (atomicMax)
   uint32_t chunk_len, magic_chunk;
-#ifdef PYSDR_DIAG
-  unsigned long long* stamps;   // [2 workgroups][16 waves][24 tiles][8] s_memtime stamps of the tile loop's phases (or null)
-#endif
 };
 // instantiations: X(id, UP, DOWN, S shifts, taps per branch, NB row blocks per tile, WK window slices, producer waves, LDS images, operand ring carried across tiles)
 //   0: 2.048 MS/s -> 48 kHz with the reference's default 1001-tap prototype (params.py:134; am.py path, BASELINE C1)

@@ -37,19 +37,6 @@ namespace pysdr {
 
 namespace {
 
-// phase stamps of the tile loop (scripts/diag/mfma_stamps.py): workgroups 3 and 131, every wave, first 24 tiles; slot 7 = HW_ID
-#ifdef PYSDR_DIAG
-#define MM_STAMP(k)                                                                                                \
-  do {                                                                                                             \
-    if (a.stamps && lane == 0 && (tb - t_begin) < 24 && (blockIdx.x == 3 || blockIdx.x == 131))                     \
-      a.stamps[(((size_t)((blockIdx.x == 3 ? 0 : 1) * 16 + wave) * 24) + (tb - t_begin)) * 8 + (k)] =              \
-          ((k) == 7) ? (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))             \
-                     : (unsigned long long)__builtin_readcyclecounter();                                            \
-  } while (0)
-#else
-#define MM_STAMP(k) do {} while (0)
-#endif
-
 typedef float mm_f4 __attribute__((ext_vector_type(4)));
 typedef float mm_f2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) mm_f2* mm_lds_cf2;

@@ -115,12 +115,16 @@ __device__ __forceinline__ void twiddle_pow0(float2 (&v)[16], float2 w, float2 w
   v[8] = cmul(v[8], b8); v[9] = cmul(v[9], cmul(b8, w)); v[10] = cmul(v[10], cmul(b8, w2)); v[11] = cmul(v[11], cmul(b8, w3));
   v[12] = cmul(v[12], b12); v[13] = cmul(v[13], cmul(b12, w)); v[14] = cmul(v[14], cmul(b12, w2)); v[15] = cmul(v[15], cmul(b12, w3));
 }
-// W_256^(i j), i, j < 16, as an LDS table of 16 rows of 18 float2 (the pad keeps the four rows a
-// wave reads at once on different banks); built by the first 256 threads of the workgroup,
+// W_256^(i j), i, j < 16, as an LDS table of 16 rows of 17 float2; built by the first 256 threads of the workgroup,
 // one v_sin/v_cos pair each.  Building the 15 powers per thread instead costs 14 complex
 // multiplications (56 of the ~350 VALU instructions of a pass) and their rounding: the table is
 // 2 % faster and three times closer to the exact transform (4.4e-7 vs 1.3e-6 of the peak).
-constexpr int kTwRow = 18;
+// Row pitch: hipcc reads a row as ds_read2_b64 pairs, which the LDS serves 16 lanes at a time on 32 banks of 4 bytes.
+// In psd_cols the 16 lanes of a group read the SAME row (broadcast); in psd_rows they read 16 DIFFERENT rows at the
+// same column, row i at dword 2 * pitch * i: with the round-1 pitch of 18 that is 4 i mod 32 -- rows i and i + 8 on
+// the same banks, the 795 k conflict cycles of 3.47 M LDS cycles in profiles/r03_c3_pmc_sq.json (23 %; the comments
+// here claimed "conflict free") -- with 17 it is 2 i mod 32, two dwords per lane: all 32 banks once.
+constexpr int kTwRow = 17;
 __device__ __forceinline__ void tw256_build(float2* tw, int tid) {
   if (tid < 256) tw[kTwRow * (tid >> 4) + (tid & 15)] = expmpi((float)((tid >> 4) * (tid & 15)) * (1.0f / 128.0f));
 }
@@ -199,8 +203,9 @@ __global__ __launch_bounds__(256) void psd_cols_kernel(const float2* __restrict_
 //   pass 1 thread (c0, pl): DFT16 over c1, * W_256^(c0 q1)     -> LDS[q1][pl][c0]
 //   pass 2 thread (pl, q1): DFT16 over c0 -> X[p + 256 (q1 + 16 q0)] -> dB -> fftshift
 // LDS slot(q1, pl, c0) = 544 q1 + 17 pl + c0: pass 1's 16-lane groups write 16 consecutive
-// slots; pass 2's 32 lanes (pl) are 17 slots apart = 34 dwords, a permutation of the even
-// banks, so both are conflict free.  32 consecutive p per store = one full 128-B line.
+// slots; pass 2's lanes (pl) are 17 slots apart = 34 dwords = 2 pl mod 32 for the 16 lanes a ds_read2_b64 access
+// serves at a time, so the data passes are conflict free (the conflicts the counters showed came from the twiddle
+// table, see kTwRow).  32 consecutive p per store = one full 128-B line.
 constexpr int kRowsPerWg = 32;
 constexpr int kRowLds = 16 * 544;
 

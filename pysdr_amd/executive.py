@@ -242,7 +242,8 @@ class SDR_EXECUTIVE:
         is submitted asynchronously and its audio is post-processed one slot later, while the next
         chunks are being read.  ``batch_chunks`` > 1 puts that many chunks into one slot = one DMA
         and one launch sequence (throughput, at the price of that many chunks of latency).  Same
-        chunks, same order, same results as ``Run``."""
+        chunks, same order, same results as ``Run`` -- live and in REPLAY_MODE, the stale last pass of a
+        replay included (``tests/test_gpu_executive.py``)."""
         from .ingest import IngestRing
         P = self.P
         B = max(1, int(batch_chunks))
@@ -254,6 +255,7 @@ class SDR_EXECUTIVE:
         t = 0.0
         self.Startup()
         slot, pending, filled = 0, None, 0
+        last = None                                         # the chunk before this one (a view into a ring slot)
 
         def finish(ps):
             nfill = ps[1]
@@ -301,9 +303,15 @@ class SDR_EXECUTIVE:
                 self.x = dst
                 self.read_chunk()
                 if P.RX_DONE:
-                    break
-                if self.x is not dst:                       # replay hands back its own array
+                    if not P.REPLAY_MODE:
+                        break                               # the live source ran dry: the chunk is only partly new
+                    # a replay that runs out leaves self.x as it was and the reference's loop body still runs once
+                    # more on that stale chunk (receiver.py:543-557,715-740; Run above does the same): here self.x
+                    # already points at the next ring slot, so the previous chunk is copied into it
+                    dst[:] = last if last is not None else 0
+                elif self.x is not dst:                     # replay hands back its own array
                     dst[:] = self.x
+                last = dst
                 if self.mode_freq_change_pending():
                     flush()                                 # a retune / mode change applies from THIS chunk on
                     dst2 = ring.buffer(slot)[0:L]

@@ -28,7 +28,7 @@ run_cfg() {  # name, pmc(0/1), bench args...
 run_cfg c3 1
 # the PSD's two kernels one after the other (the default deals half-groups over two streams, so the per-kernel
 # durations of the trace above overlap): un-overlapped per-kernel times for the same command
-PYSDR_PSD_STREAMS=1 run_cfg c3_psd1stream 0 --no-cpu-baseline
+PYSDR_TUNING=1 PYSDR_PSD_STREAMS=1 run_cfg c3_psd1stream 0 --no-cpu-baseline
 [ -n "$QUICK" ] && exit 0
 run_cfg c3_nopsd 0 --no-psd --no-cpu-baseline
 run_cfg c2 1 --workload c2

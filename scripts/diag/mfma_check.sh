@@ -1,4 +1,4 @@
-O=gpurun_out/r04_third
+O=gpurun_out/mfma_check
 mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "c1 or long_prototype or random_call or c4 or wbfm or batch_equals or ragged or full_size_batch" > $O/pytest_sel.txt 2>&1
 tail -3 $O/pytest_sel.txt

@@ -165,6 +165,44 @@ def test_ingest_ring_pipelined_run_equals_the_synchronous_run():
         assert np.max(np.abs(u - v)) <= 1e-5 * np.max(np.abs(u))
 
 
+def test_replay_run_and_pipelined_run_are_the_same_including_the_stale_last_pass(tmp_path):
+    """REPLAY_MODE: when the recording runs out the reference's loop body runs once more on the chunk it already had
+    (receiver.py:543-557,715-740).  ``Run`` reproduces that; ``Run_pipelined`` must too (it used to stop one
+    chunk early) -- same chunks, same audio, same saved IQ, with one and with several chunks per ring slot."""
+    from pysdr_amd import fileio as file_io
+    cfg = so.CONFIGS['C3']
+    nchunks = 5
+    P0 = make_P(cfg, nchunks)
+    L = P0.IN_CHUNK_SIZE
+    x = so.synth_iq(cfg, nchunks * L + L // 3, 43)          # the file ends inside chunk 5: the replay runs out
+    w = file_io.sdr_fileio('raw_iq', 'w', P0, 2, 'RAW_IQ', out_dir=str(tmp_path))
+    w.save_data(x)
+    w.close()
+
+    def run(pipelined, batch=1):
+        P = make_P(cfg, nchunks + 4, audio=2, max_batch_chunks=max(batch, 1))
+        P.REPLAY = w.fname
+        file_io.open_replay(P)
+        P.DURATION = 1e9                                    # the recording, not the clock, ends the run
+        ex = executive.SDR_EXECUTIVE(P)
+        for i, r in enumerate(cfg['rx']):
+            P.rx[i].mode, P.rx[i].af_bw, P.rx[i].bfo = r['mode'], r.get('af_bw'), r.get('bfo', 0.0)
+        seen = []
+        if pipelined:
+            ex.Run_pipelined(on_chunk=lambda e: seen.append(e.x.copy()), batch_chunks=batch)
+        else:
+            ex.Run(on_chunk=lambda e: seen.append(e.x.copy()))
+        return seen, [pl.rb.pull(pl.rb.nsamps) for pl in P.players]
+
+    sa, aa = run(False)
+    assert len(sa) >= 2 and np.array_equal(sa[-1], sa[-2])   # the stale pass: the last chunk twice
+    for batch in (1, 3):
+        sb, ab = run(True, batch)
+        assert len(sb) == len(sa) and all(np.array_equal(u, v) for u, v in zip(sa, sb)), batch
+        for u, v in zip(aa, ab):
+            assert u.shape == v.shape and np.array_equal(u, v), batch
+
+
 def test_am_synch_batched_slots_equal_the_chunked_run_within_the_parity_bar():
     """with a serial loop in the chain (AM-Synch carrier PLL) a slot of several chunks runs it
     in segments whose joins are accepted within a tolerance, so Run_pipelined(batch_chunks > 1) equals

@@ -619,6 +619,26 @@ def test_full_size_batch_is_independent_of_how_it_is_cut(name, B):
     for i, ro in enumerate(o):
         ref = np.concatenate([ro.demod_data(xu[k * L:(k + 1) * L]) for k in range(2)])
         assert relerr(whole[i][0][:len(ref)], ref) <= TOL, ro.mode
+    # ... and two chunks in the MIDDLE of the batch against the oracle ("full size" must not rest on chunks
+    # 0-1 plus self-consistency): the oracle is primed over the 192 chunks in front of them with its absolute counters
+    # (LO phase, resampler sample index, output index / BFO phase) set as if it had run from sample 0
+    # (bench.primed_oracle, checked on the CPU against a full run in tests/test_bench_cli.py)
+    import bench
+    kmid, prime = B // 2 + 3, 192
+    orx = bench.primed_oracle(cfg, None, (kmid - prime) * L)
+    want_am, want_iq = [[] for _ in orx], [[] for _ in orx]
+    for k in range(kmid - prime, kmid + 2):
+        xc = xu[(k % uniq) * L:(k % uniq + 1) * L]
+        for i, ro in enumerate(orx):
+            a = ro.demod_data(xc)
+            if k >= kmid:
+                want_am[i].append(np.array(a)); want_iq[i].append(np.array(ro.iq))
+    for i, ro in enumerate(orx):
+        am, iq, cn, _ = whole[i]
+        lo, n = int(cn[:kmid].sum()), int(cn[kmid:kmid + 2].sum())
+        assert [int(v) for v in cn[kmid:kmid + 2]] == [len(a) for a in want_am[i]], ro.mode
+        assert relerr(am[lo:lo + n], np.concatenate(want_am[i])) <= TOL, (ro.mode, 'am, mid-batch')
+        assert relerr(iq[lo:lo + n], np.concatenate(want_iq[i])) <= TOL, (ro.mode, 'iq, mid-batch')
 
 
 def test_full_size_psd_frames_do_not_depend_on_the_batch():
@@ -685,6 +705,7 @@ def test_psd_batch_is_the_same_on_any_number_of_streams_and_any_group(monkeypatc
             _lib.check(lib.pysdr_dev_upload(0, C.c_void_p(d_x.value + f0 * CH * 8), C.c_void_p(blk.ctypes.data), n * CH * 8), "upload")
         outs = {}
         for streams, group in ((1, 448), (2, 448), (3, 448), (2, 64), (1, 2000)):
+            monkeypatch.setenv("PYSDR_TUNING", "1")          # the switches below are read only under the master switch
             monkeypatch.setenv("PYSDR_PSD_STREAMS", str(streams))
             monkeypatch.setenv("PYSDR_PSD_GROUP", str(group))
             sp = C.c_void_p()

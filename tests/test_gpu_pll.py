@@ -178,6 +178,7 @@ def test_am_synch_one_lane_per_segment_equals_one_wave_per_segment(monkeypatch):
     B = 150
     L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
     x = so.synth_iq(cfg, B * L, 5)
+    monkeypatch.setenv("PYSDR_TUNING", "1")              # the switch below is read only under the master switch
     monkeypatch.setenv("PYSDR_AM_PLL_WAVES", "0")
     a1, a2, seg, pat, agc = _am_synch_batch(x, B, L, cfg)
     monkeypatch.setenv("PYSDR_AM_PLL_WAVES", "1")
@@ -237,6 +238,20 @@ def test_full_size_c4_time_parallel_equals_the_serial_walk():
                 n2 = int(cna[:2].sum())
                 assert n2 == len(want)
                 assert relerr(a[:n2], want) <= TOL
+            if k == 1:
+                # two chunks in the MIDDLE of the second call (the one whose warm-ups start from the first call's mean
+                # phase increment) against the serial NumPy oracle, primed over the 16 chunks in front of them with its
+                # absolute counters set (bench.primed_oracle: the pilot loop forgets its start within 17.5 tau = 6 chunks)
+                import bench
+                cfg = dict(fs=10e6, fs_out=48e3, ntaps_dec=255, wfm='WFM2', rx=[dict(frq=300e3, mode='WFM2', video_bw=200e3)])
+                kmid, prime = B // 2 + 5, 16
+                s_start = k * nsamp + (kmid - prime) * L
+                o = bench.primed_oracle(cfg, None, s_start)[0]
+                xs = bench.stream_slice(xu, nloop, seam, nsamp, s_start, (prime + 2) * L)
+                want = [np.array(o.demod_data(xs[j * L:(j + 1) * L])) for j in range(prime + 2)][prime:]
+                lo, n2 = int(cna[:kmid].sum()), int(cna[kmid:kmid + 2].sum())
+                assert [int(v) for v in cna[kmid:kmid + 2]] == [len(w) for w in want]
+                assert relerr(a[lo:lo + n2], np.concatenate(want)) <= TOL, 'mid-batch, second call'
         ca.close()
         cb.close()
     finally:
