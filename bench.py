@@ -117,8 +117,12 @@ RX6 = [dict(frq=200e3, mode='USB', video_bw=10e3, af_bw=3e3),
        dict(frq=-310e3, mode='CW', video_bw=10e3, af_bw=500.0, bfo=700.0),
        dict(frq=455e3, mode='NFM', video_bw=20e3, af_bw=4e3),
        dict(frq=-1.2e6, mode='AM', video_bw=10e3, af_bw=5e3),
-       dict(frq=900e3, mode='LSB', video_bw=10e3, af_bw=3e3),
-       dict(frq=-2.1e6, mode='AM', video_bw=10e3, af_bw=5e3)]
+       # sub-receivers 5 and 6 listen to carriers the C3 stream HAS (the FM one as LSB, the keyed one as AM): tuned to
+       # empty spectrum (as in rounds 2-3: +900 kHz, -2.1 MHz) their output is stop-band leakage 80 dB down, which the AGC
+       # blows up to full scale -- the verification (on by default now) then measured rounding noise against itself
+       # (2.8e-5); the work per sample is the same
+       dict(frq=455e3, mode='LSB', video_bw=10e3, af_bw=3e3),
+       dict(frq=-310e3, mode='AM', video_bw=10e3, af_bw=5e3)]
 
 
 def workload_cfg(args):

@@ -12,13 +12,15 @@ rm -rf "$OUT" && mkdir -p "$OUT"
 run_cfg() {  # name, pmc(0/1), bench args...
   local name=$1 pmc=$2; shift 2
   mkdir -p "$OUT/$name"
-  python3 bench.py "$@" > "$OUT/$name/bench.json" 2> "$OUT/$name/bench.err"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name/kt" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed > "$OUT/$name/bench_kt.json" 2> "$OUT/$name/kt.err"
+  python3 bench.py "$@" --no-other-configs > "$OUT/$name/bench.json" 2> "$OUT/$name/bench.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name/kt" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify > "$OUT/$name/bench_kt.json" 2> "$OUT/$name/kt.err"
   if [ "$pmc" = 1 ]; then
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$name/pmc_fetch" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --steps 3 --warmup 1 > "$OUT/$name/pmc_fetch.json" 2> "$OUT/$name/pmc_fetch.err"
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$name/pmc_write" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --steps 3 --warmup 1 > "$OUT/$name/pmc_write.json" 2> "$OUT/$name/pmc_write.err"
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$name/pmc_fetch" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 3 --warmup 1 > "$OUT/$name/pmc_fetch.json" 2> "$OUT/$name/pmc_fetch.err"
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$name/pmc_write" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 3 --warmup 1 > "$OUT/$name/pmc_write.json" 2> "$OUT/$name/pmc_write.err"
     # wave-level counters of the same kernels (LDS bank conflicts, VALU / LDS activity, parked cycles)
-    rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/$name/pmc_sq" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --steps 3 --warmup 1 > "$OUT/$name/pmc_sq.json" 2> "$OUT/$name/pmc_sq.err"
+    rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/$name/pmc_sq" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 3 --warmup 1 > "$OUT/$name/pmc_sq.json" 2> "$OUT/$name/pmc_sq.err"
+    # the matrix pipe (mixdec_mfma.hip: C1, C4)
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/$name/pmc_mfma" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 3 --warmup 1 > "$OUT/$name/pmc_mfma.json" 2> "$OUT/$name/pmc_mfma.err"
   fi
   # keep only the small summaries (the per-dispatch traces are tens of MB)
   find "$OUT/$name" -name "*kernel_trace.csv" -delete

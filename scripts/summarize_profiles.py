@@ -18,6 +18,7 @@ import subprocess
 import sys
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+SOURCES = ("mixdec.hip", "mixdec_mfma.hip", "mixdec_mfma_geom.h", "resamp_small.hip", "psdfft.hip", "stage2.hip", "api.hip")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs(dst, exist_ok=True)
 
@@ -72,12 +73,32 @@ for cfg in sorted(os.listdir(src)):
                          hbm_bytes_per_launch=2 * fm * 1024 + wm * 1024))
     if rows:
         doc = dict(config=cfg, git_head=head + ("+dirty" if dirty else ""),
-                   source_sha256={s: sha(s) for s in ("mixdec.hip", "psdfft.hip", "stage2.hip", "api.hip")},
+                   source_sha256={s: sha(s) for s in SOURCES},
                    note="per launch: 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate rocprofv3 --pmc passes of bench.py",
                    kernels=rows)
         name = f"{tag}_pmc_traffic.json" if cfg == "c3" else f"{tag}_{cfg}_pmc_traffic.json"
         json.dump(doc, open(os.path.join(dst, name), "w"), indent=1)
         print(cfg, json.dumps([(r["kernel"], round(r["hbm_bytes_per_launch"] / 1e6, 1)) for r in rows]))
+    for pass_name, note in (("pmc_mfma", "matrix-pipe counters, one rocprofv3 --pmc pass of bench.py: SQ_VALU_MFMA_BUSY_CYCLES counts cycles "
+                             "(32 per v_mfma_f32_16x16x4_f32), summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs"),):
+        mm = pmc(cfg, pass_name)
+        if not mm:
+            continue
+        per = collections.defaultdict(dict)
+        for (k, c), v in mm.items():
+            if "pysdr" not in k:
+                continue
+            m = re.search(r"(\w+_kernel)(<[^>]*>)?", k)
+            v = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v
+            per[(m.group(1) + (m.group(2) or "")) if m else k][c] = sum(v) / len(v)
+        rows = []
+        for k, v in sorted(per.items()):
+            row = dict(kernel=k, **{c: round(x) for c, x in sorted(v.items())})
+            if v.get("SQ_INSTS_MFMA", 0) > 0 and v.get("GRBM_GUI_ACTIVE", 0) > 0:
+                row["mfma_pipe_busy_frac"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0), 3)
+            rows.append(row)
+        json.dump(dict(config=cfg, git_head=head + ("+dirty" if dirty else ""), source_sha256={s: sha(s) for s in SOURCES},
+                       note=note, kernels=rows), open(os.path.join(dst, f"{tag}_{cfg}_{pass_name}.json"), "w"), indent=1)
     sq = pmc(cfg, "pmc_sq")
     if sq:
         per = collections.defaultdict(dict)
@@ -88,7 +109,7 @@ for cfg in sorted(os.listdir(src)):
             v = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v     # the full-batch launches only
             per[(m.group(1) + (m.group(2) or "")) if m else k][c] = sum(v) / len(v)
         doc = dict(config=cfg, git_head=head + ("+dirty" if dirty else ""),
-                   source_sha256={s: sha(s) for s in ("mixdec.hip", "psdfft.hip", "stage2.hip", "api.hip")},
+                   source_sha256={s: sha(s) for s in SOURCES},
                    note="per launch, summed over all waves (SQ_* count quad-cycles: MI355X_MICROARCH.md); one rocprofv3 --pmc pass of bench.py",
                    kernels=[dict(kernel=k, **{c: round(x) for c, x in sorted(v.items())}) for k, v in sorted(per.items())])
         json.dump(doc, open(os.path.join(dst, f"{tag}_{cfg}_pmc_sq.json"), "w"), indent=1)
