@@ -94,6 +94,8 @@ struct MixMfmaArgs {
 // instantiations: X(id, UP, DOWN, S shifts, taps per branch, NB row blocks per tile, WK window slices, producer waves, LDS images, operand ring carried across tiles)
 //   0: 2.048 MS/s -> 48 kHz with the reference's default 1001-tap prototype (params.py:134; am.py path, BASELINE C1)
 //   1: the 255-tap video filter of the broadcast-FM front end at 10 MS/s / 40 (BASELINE C4)
+//   2, 3: the same 1001-tap prototype at the other rates of Tables.py:44-45 whose window fits the LDS: 1.024 and 2.56 MS/s
+//      (8 MS/s -> 48 kHz would need 130 KB per image: it stays on the vector form, as does every multi-RX stream)
 // (producer waves / images can be overridden for A/B builds of mixdec_mfma.hip alone: they do not enter the host's plan)
 #ifndef MM_C1_NPROD
 #define MM_C1_NPROD 8
@@ -118,7 +120,9 @@ struct MixMfmaArgs {
 #endif
 #define PYSDR_MFMA_SHAPES(X) \
   X(0, 3, 128, 2, 334, 1, 8, MM_C1_NPROD, MM_C1_NBUF, MM_C1_CARRY) \
-  X(1, 1, 40, MM_C4_S, 255, 1, 8, MM_C4_NPROD, MM_C4_NBUF, MM_C4_CARRY)
+  X(1, 1, 40, MM_C4_S, 255, 1, 8, MM_C4_NPROD, MM_C4_NBUF, MM_C4_CARRY) \
+  X(2, 3, 64, 2, 334, 1, 8, 8, 4, 1) \
+  X(3, 3, 160, 2, 334, 1, 8, 8, 3, 0)
 int mixdec_mfma_shape(int up, int down, int kdec);   // -1: none
 bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, unsigned long long n, MfmaPlan* p);
 int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t st);

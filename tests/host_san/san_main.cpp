@@ -145,8 +145,7 @@ static void narrowband(const Rate& r, int ntaps_dec) {
 // One sub-receiver with the reference's default 1001-tap prototype at the am.py rate: the matrix-core form of the
 // mix + decimate kernel (mixdec_mfma.hip).  Ragged and odd call lengths flip the parity of its LDS image.
 namespace pysdr { extern int g_mfma_launches; }
-static void single_rx_long_prototype() {
-  const Rate r = kRates[1];
+static void single_rx_long_prototype(const Rate& r) {
   const int max_chunks = 3, ntaps_dec = 1001, ntaps_af = 255;
   pysdr_ctx* c = make_ctx(r, max_chunks, ntaps_dec, ntaps_af);
   const auto h = taps(ntaps_dec), af = taps(2 * ntaps_af);
@@ -274,7 +273,9 @@ int main(int argc, char** argv) {
     narrowband(r, 255);
   }
   narrowband(kRates[1], 1001);                       // the reference's default prototype at the am.py rate
-  single_rx_long_prototype();
+  single_rx_long_prototype(kRates[1]);               // 3/128
+  single_rx_long_prototype(kRates[4]);               // 3/64
+  single_rx_long_prototype(Rate{2.56e6, 3, 160, 54613});
   narrowband(kRates[0], 1001);
   {
     const int before = pysdr::g_mfma_launches;
