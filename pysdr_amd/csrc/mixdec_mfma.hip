@@ -124,7 +124,11 @@ __device__ __forceinline__ void mm_stage_interior(const float2* src0, unsigned i
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int pc = pw + i * npw;
+#ifdef MM_NO_HALO                     // experiment: only the 16 segments a tile owns are copied (results WRONG): what a halo-free image would save
+    if (pc < (16 * G::NB * G::SPS + 63) / 64)
+#else
     if (pc < G::IMG_PIECES)
+#endif
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(__float_as_uint(roff[i])), "s"(src0), "s"(img + (unsigned)pc * 1024u) : "memory");
   }
   mm_m0_restore(keep);
@@ -343,7 +347,11 @@ __device__ __forceinline__ void mm_dma(const MixMfmaArgs& a, unsigned lds0, int 
     if (w == G::P / 2) w -= 1;
     roff[i] = __uint_as_float((unsigned)((seg * G::P + 2 * w) * 8));
   }
+#ifdef MM_NO_HALO
+  const int my_pieces = ((16 * G::NB * G::SPS + 63) / 64 - pw + npw - 1) / npw;
+#else
   const int my_pieces = (G::IMG_PIECES - pw + npw - 1) / npw;
+#endif
   auto stage = [&](int tile, int slot) -> int {
     if (tile >= t_end) return 0;
 #ifdef MM_NO_DMA                      // experiment: the arithmetic side alone (results WRONG)
