@@ -137,20 +137,24 @@ __global__ __launch_bounds__(64) void am_pll_lanes_kernel(const Stage2Args a) {
   // The next block's samples are loaded from inline asm and waited for by hand at the END of the block: loads that
   // hipcc knows about cost an s_waitcnt vmcnt(0) in front of every step (it cannot count across the loop's back edge),
   // i.e. one memory latency per 8 steps on the chain.
+  // The two blocks of registers swap roles from one block of 8 steps to the next (the loop body is written out for A -> B and
+  // B -> A): with a `cur = nxt` copy at the end of a trip hipcc hoisted six of the eight copies ABOVE the hand-placed wait --
+  // legal for a "+v" tied operand, and a read of a register whose load may still be in flight (tests/test_isa_checks.py looks
+  // at the generated ISA for exactly this; the hardware does not interlock on vmcnt).
   typedef float pl_v2f __attribute__((ext_vector_type(2)));
-  pl_v2f cur[8], nxt[8];
+  pl_v2f ba[8], bb[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int i = s0 - W + q;
     const float2 v = (i >= 0 && i < s1) ? y[i] : make_float2(0.f, 0.f);
-    cur[q] = (pl_v2f){v.x, v.y};
+    ba[q] = (pl_v2f){v.x, v.y};
   }
-  for (int t = -W; t < T; t += 8) {
+  auto block = [&](pl_v2f (&cur)[8], pl_v2f (&nxt)[8], int t) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int i = s0 + t + 8 + q;
       // "+v": the register is zeroed BEFORE the asm and the load overwrites it in place, so no copy that merges a
-      // loaded and a zero value can land between the load and the hand-placed wait (the hardware does not interlock)
+      // loaded and a zero value can land between the load and the hand-placed wait
       nxt[q] = (pl_v2f){0.f, 0.f};
       if (t + 8 < T && i >= 0 && i < s1)
         asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(nxt[q]) : "v"(y + i) : "memory");
@@ -174,8 +178,10 @@ __global__ __launch_bounds__(64) void am_pll_lanes_kernel(const Stage2Args a) {
     asm volatile("s_waitcnt vmcnt(0)"
                  : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]), "+v"(nxt[5]), "+v"(nxt[6]), "+v"(nxt[7])
                  :: "memory");
-#pragma unroll
-    for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+  };
+  for (int t = -W; t < T; t += 16) {       // W and T are multiples of 64
+    block(ba, bb, t);
+    block(bb, ba, t + 8);
   }
   if (live) { sg[2] = __float_as_uint(th); sg[3] = __float_as_uint(w); }
 }
