@@ -78,3 +78,32 @@ def test_nothing_touches_an_asm_load_destination_before_its_wait():
             assert not hit, (f"stage2.hip ISA line {no}: `{code}` touches v{sorted(hit)} between the asm load of line "
                              f"{pending[sorted(hit)[0]]} and its s_waitcnt vmcnt(0)")
     assert checked >= 9, f"expected the PLL kernels' asm prefetches in the ISA, saw {checked} load registers waited for"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_no_shipped_kernel_uses_scratch():
+    """A spilled register is a hidden wait for the LDS-DMA (its reload's s_waitcnt vmcnt(0) also waits for the NEXT tile's
+    copies: DESIGN.md 4.1, round 3): every kernel of the shipped library must compile without scratch, with the flags
+    pysdr_amd/build.py uses."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pysdr_amd import build as pb                                        # SOURCES, EXTRA_FLAGS: importing builds nothing
+    files = [f for f in pb.SOURCES if f != "api.hip"]                        # api.hip holds no device code
+
+    def one(f):
+        return f, _isa(f, ["-fPIC", *pb.EXTRA_FLAGS.get(f, [])])
+
+    bad, nk = [], 0
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for f, lines in ex.map(one, files):
+            name = None
+            for ln in lines:
+                m = re.search(r"\.name:\s+(\S+)", ln)
+                if m:
+                    name = m.group(1)
+                m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", ln)
+                if m:
+                    nk += 1
+                    if int(m.group(1)) != 0:
+                        bad.append((f, name, int(m.group(1))))
+    assert nk >= 40, nk
+    assert not bad, bad
