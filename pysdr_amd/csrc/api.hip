@@ -187,6 +187,7 @@ struct pysdr_spectrum {
   hipEvent_t ev_order = nullptr;
   bool force_rocfft = false;  // PYSDR_PSD_ROCFFT: rocFFT even for the 32768 -> 65536 size
   int group = 448;            // frames per launch pair of the four-step path (PYSDR_PSD_GROUP)
+  int packed = 1;             // four-step intermediate as block-scaled 24-bit fixed point (psdfft.hip; PYSDR_PSD_PACKED=0: float2)
   // PYSDR_PSD_STREAMS=2: the groups alternate between two streams, each with its own half-size intermediate
   // (2 x group/2 frames = the same Infinity Cache footprint), so that the columns of one group run beside
   // the rows of the other and the kernel boundaries of one stream hide behind the other's kernels
@@ -1246,6 +1247,7 @@ int pysdr_spectrum_create(int device, int chunk_size, int nfft, int max_frames, 
   sp->device = device; sp->chunk = chunk_size; sp->nfft = nfft; sp->max_frames = max_frames;
   sp->force_rocfft = tuning_env("PYSDR_PSD_ROCFFT") != nullptr;
   { const char* e = tuning_env("PYSDR_PSD_GROUP"); if (e && atoi(e) > 0) sp->group = atoi(e); }
+  { const char* e = tuning_env("PYSDR_PSD_PACKED"); if (e && *e) sp->packed = atoi(e) ? 1 : 0; }
   { const char* e = tuning_env("PYSDR_PSD_STREAMS"); if (e && atoi(e) >= 1 && atoi(e) <= pysdr_spectrum::kMaxStreams) sp->nstreams = atoi(e); }
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_error("pysdr_spectrum_create: %s -> %s", #e, hipGetErrorString(_e)); pysdr_spectrum_destroy(sp); return PYSDR_ERR_HIP; } } while (0)
   CK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
@@ -1349,7 +1351,7 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
         const int nf = (nframes - f0 < part) ? nframes - f0 : part;
         const int w = k % ns;
         rc = launch_psd64k(d_x + (size_t)f0 * hop, hop, nf, sp->d_win, w ? sp->xwork[w] : sp->d_work,
-                           d_out + (size_t)f0 * sp->nfft, db, w ? sp->xstream[w] : sp->stream);
+                           d_out + (size_t)f0 * sp->nfft, db, w ? sp->xstream[w] : sp->stream, sp->packed);
         if (rc) break;             // a failed launch still joins the side streams below: what was forked keeps writing
       }                            // d_out / xwork until it is done, and the caller reacts to the error right away
       for (int i = 1; i < ns; ++i) {
@@ -1365,7 +1367,7 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
     for (int f0 = 0; f0 < nframes; f0 += group) {
       const int nf = (nframes - f0 < group) ? nframes - f0 : group;
       rc = launch_psd64k(d_x + (size_t)f0 * hop, hop, nf, sp->d_win, sp->d_work,
-                         d_out + (size_t)f0 * sp->nfft, db, sp->stream);
+                         d_out + (size_t)f0 * sp->nfft, db, sp->stream, sp->packed);
       if (rc) return rc;
     }
     PYSDR_HIP_CHECK(hipEventRecord(sp->ev[1], sp->stream));

@@ -240,7 +240,8 @@ int launch_psd_post(const float2* work, int nframes, int nfft, int half, int db,
                     hipStream_t st);
 
 // fused 32768 -> 65536 PSD path (psdfft.hip): two kernels, `work` = nframes x 65536 complex
+// packed: the intermediate as block-scaled 24-bit fixed point (6 bytes per complex) instead of float2
 int launch_psd64k(const float2* x, size_t hop, int nframes, const float* win, float2* work,
-                  float* out, int db, hipStream_t st);
+                  float* out, int db, hipStream_t st, int packed);
 
 }  // namespace pysdr

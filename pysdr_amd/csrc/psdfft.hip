@@ -271,11 +271,153 @@ __global__ __launch_bounds__(512) void psd_rows_kernel(const float2* __restrict_
   rows_unit<false>(work + (size_t)f * kN, out + (size_t)f * kN, blockIdx.x, db, threadIdx.x, lds, tw);
 }
 
+
+// ---- the same pair with a 24-BIT intermediate (round 4).  The pair is bound by the bytes it moves across the XCD <->
+// memory fabric (section 4.3 of DESIGN.md: 1.5 MB per frame, of which 1.0 MB is the intermediate written and read back),
+// not by arithmetic, so the intermediate is stored as block-scaled 24-bit fixed point: 6 instead of 8 bytes per complex,
+// 1.25 MB per frame.  Block = the 16 columns x 256 rows one columns workgroup produces; its scale maps the block's largest
+// |component| to 8388600, so a stored value is off by at most 6e-8 of the block maximum -- the rows transform adds 256 of
+// them incoherently (1e-6 of the block maximum) under a line that is at least ~16x the block's values: two orders inside the
+// 5e-6 amplitude bar of psd_check.  The two planes keep every access a power of two wide: HI = the upper 16 bits of Re and Im
+// in one dword per complex, LO = the low byte of each in one 16-bit word; same [cb][p][b] index order as the float2 form,
+// so a wave's store / load covers 256 + 128 contiguous bytes.  v_perm_b32 packs and unpacks (6 vector instructions per
+// complex on each side: +16 % on kernels that were never bound by them).
+//   per frame (512 KB of the work buffer): [0, 256 K) HI dwords, [256 K, 384 K) LO shorts, [384 K, +64) the 16 block scales
+constexpr int kPkLoOff = 65536 * 4, kPkScaleOff = 65536 * 6;
+
+__device__ __forceinline__ unsigned pk_perm(unsigned s0, unsigned s1, unsigned sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+
+__device__ __forceinline__ void cols_unit_pk(const float2* __restrict__ xf, const float* __restrict__ win,
+                                             char* __restrict__ wf, int cb, int tid, float2* lds, const float2* tw,
+                                             float* red) {
+  const int b = tid & 15, hi = tid >> 4;
+  const int bb = cb * kColsPerWg + b;
+  {
+    const int a0 = hi;
+    float2 u[16];
+#pragma unroll
+    for (int a1 = 0; a1 < 8; ++a1) {
+      const int n = 256 * (a0 + 16 * a1) + bb;
+      const float2 s = ldg2_stream(xf + n);
+      const float g = ldg1(win + n);
+      u[a1] = make_float2(s.x * g, s.y * g);
+    }
+#pragma unroll
+    for (int a1 = 8; a1 < 16; ++a1) u[a1] = make_float2(0.f, 0.f);
+    dft16(u);
+    __syncthreads();
+    twiddle_tab(u, tw, a0);
+    float2* p = lds + 16 * a0 + b;
+#pragma unroll
+    for (int p1 = 0; p1 < 16; ++p1) p[272 * p1] = u[p1];
+  }
+  __syncthreads();
+  {
+    const int p1 = hi;
+    const float2* p = lds + 272 * p1 + b;
+    float2 v[16];
+#pragma unroll
+    for (int a0 = 0; a0 < 16; ++a0) v[a0] = p[16 * a0];
+    dft16(v);
+    twiddle_pow0(v, expmpi((float)(16 * bb) * (1.0f / 32768.0f)),
+                 expmpi((float)(bb * p1) * (1.0f / 32768.0f)));
+    // the block's largest |component|: thread, wave (DPP-free butterflies through shuffles), workgroup
+    float m = 0.f;
+#pragma unroll
+    for (int p0 = 0; p0 < 16; ++p0) m = fmaxf(fmaxf(m, fabsf(v[p0].x)), fabsf(v[p0].y));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = (m > 0.f) ? __fdiv_rn(8388600.0f, m) : 1.0f;
+    if (tid == 0) *(PYSDR_AS1 float*)(wf + kPkScaleOff + 4 * cb) = (m > 0.f) ? __fdiv_rn(m, 8388600.0f) * (1.0f / 256.0f) : 0.f;
+    PYSDR_AS1 unsigned* oh = (PYSDR_AS1 unsigned*)wf + (size_t)cb * 4096 + p1 * 16 + b;
+    PYSDR_AS1 unsigned short* ol = (PYSDR_AS1 unsigned short*)(wf + kPkLoOff) + (size_t)cb * 4096 + p1 * 16 + b;
+#pragma unroll
+    for (int p0 = 0; p0 < 16; ++p0) {
+      const unsigned a = (unsigned)__float2int_rn(v[p0].x * sc), c = (unsigned)__float2int_rn(v[p0].y * sc);
+      oh[p0 * 256] = pk_perm(c, a, 0x06050201u);                       // [a.b1, a.b2, c.b1, c.b2]
+      ol[p0 * 256] = (unsigned short)pk_perm(c, a, 0x0c0c0400u);       // [a.b0, c.b0]
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void psd_cols_pk_kernel(const float2* __restrict__ x, size_t hop,
+                                                          const float* __restrict__ win, char* __restrict__ work) {
+  __shared__ __attribute__((aligned(16))) float2 lds[kColLds];
+  __shared__ __attribute__((aligned(16))) float2 tw[16 * kTwRow];
+  __shared__ float red[4];
+  const int f = blockIdx.y;
+  tw256_build(tw, threadIdx.x);
+  cols_unit_pk(x + (size_t)f * hop, win, work + (size_t)f * kN * sizeof(float2), blockIdx.x, threadIdx.x, lds, tw, red);
+}
+
+__device__ __forceinline__ void rows_unit_pk(const char* __restrict__ wf, float* __restrict__ of, int rb, int db,
+                                             int tid, float2* lds, const float2* tw) {
+  {
+    const int c0 = tid & 15, pl = tid >> 4;
+    const size_t idx = (size_t)(rb * kRowsPerWg + pl) * 16 + c0;
+    const PYSDR_AS1 unsigned* sh = (const PYSDR_AS1 unsigned*)wf + idx;
+    const PYSDR_AS1 unsigned short* sl = (const PYSDR_AS1 unsigned short*)(wf + kPkLoOff) + idx;
+    const PYSDR_AS1 float* ss = (const PYSDR_AS1 float*)(wf + kPkScaleOff);
+    unsigned h[16], l[16];
+#pragma unroll
+    for (int c1 = 0; c1 < 16; ++c1) { h[c1] = sh[4096 * c1]; l[c1] = sl[4096 * c1]; }
+    float2 u[16];
+#pragma unroll
+    for (int c1 = 0; c1 < 16; ++c1) {
+      const float inv = ss[c1];                                          // block scale / 256 (wave-uniform)
+      const int xr = (int)pk_perm(l[c1], h[c1], 0x0100040cu);            // [0, l.b0, h.b0, h.b1] = Re * 256
+      const int xi = (int)pk_perm(l[c1], h[c1], 0x0302050cu);            // [0, l.b1, h.b2, h.b3] = Im * 256
+      u[c1] = make_float2((float)xr * inv, (float)xi * inv);
+    }
+    dft16(u);
+    __syncthreads();
+    twiddle_tab(u, tw, c0);
+    float2* p = lds + 17 * pl + c0;
+#pragma unroll
+    for (int q1 = 0; q1 < 16; ++q1) p[544 * q1] = u[q1];
+  }
+  __syncthreads();
+  {
+    const int pl = tid & 31, q1 = tid >> 5;
+    const float2* p = lds + 544 * q1 + 17 * pl;
+    float2 v[16];
+#pragma unroll
+    for (int c0 = 0; c0 < 16; ++c0) v[c0] = p[c0];
+    dft16(v);
+    const int kb = rb * kRowsPerWg + pl + 256 * q1;
+#pragma unroll
+    for (int q0 = 0; q0 < 16; ++q0) {
+      const int k = kb + 4096 * q0;
+      float pw = v[q0].x * v[q0].x + v[q0].y * v[q0].y;
+      if (db) pw = 3.0102999566398120f * __builtin_amdgcn_logf(pw + 1.0e-30f);
+      stg1_stream(of + ((k + kM) & (kN - 1)), pw);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void psd_rows_pk_kernel(const char* __restrict__ work, float* __restrict__ out, int db) {
+  __shared__ __attribute__((aligned(16))) float2 lds[kRowLds];
+  __shared__ __attribute__((aligned(16))) float2 tw[16 * kTwRow];
+  const int f = blockIdx.y;
+  tw256_build(tw, threadIdx.x);
+  rows_unit_pk(work + (size_t)f * kN * sizeof(float2), out + (size_t)f * kN, blockIdx.x, db, threadIdx.x, lds, tw);
+}
+
 }  // namespace
 
 // nframes frames; `work` holds nframes x 65536 complex of intermediate.
 int launch_psd64k(const float2* x, size_t hop, int nframes, const float* win, float2* work,
-                  float* out, int db, hipStream_t st) {
+                  float* out, int db, hipStream_t st, int packed) {
+  if (packed) {
+    hipLaunchKernelGGL(psd_cols_pk_kernel, dim3(256 / kColsPerWg, nframes), dim3(256), 0, st, x, hop, win, (char*)work);
+    PYSDR_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(psd_rows_pk_kernel, dim3(256 / kRowsPerWg, nframes), dim3(512), 0, st, (const char*)work, out, db);
+    PYSDR_HIP_CHECK(hipGetLastError());
+    return PYSDR_OK;
+  }
   hipLaunchKernelGGL(psd_cols_kernel, dim3(256 / kColsPerWg, nframes), dim3(256), 0, st, x, hop, win,
                      work);
   PYSDR_HIP_CHECK(hipGetLastError());

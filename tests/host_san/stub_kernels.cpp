@@ -350,7 +350,7 @@ int launch_psd_post(const float2* work, int nframes, int nfft, int half, int, fl
   return PYSDR_OK;
 }
 
-int launch_psd64k(const float2* x, size_t hop, int nframes, const float* win, float2* work, float* out, int, hipStream_t) {
+int launch_psd64k(const float2* x, size_t hop, int nframes, const float* win, float2* work, float* out, int, hipStream_t, int) {
   read_all(win, 32768);
   for (int f = 0; f < nframes; ++f) read_all(x + (size_t)f * hop, 32768);
   write_all(work, (size_t)nframes * 65536);
