@@ -43,7 +43,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PSD_CHUNK, PSD_NFFT = 32768, 65536
 DEFAULT_CHUNKS = {"c1": 4096, "c2": 2048, "c3": 2048, "c4": 2048, "c4mono": 2048}
 TUNING_ENV = ("PYSDR_TUNING", "PYSDR_MIXDEC_WGS", "PYSDR_MIXDEC_YFLUSH", "PYSDR_DEBUG_FLAGS", "PYSDR_PSD_GROUP",
-              "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_PSD_STREAMS", "PYSDR_WFM_PLL", "PYSDR_MIXDEC_MFMA", "PYSDR_MIXDEC_GRID",
+              "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_PSD_STREAMS", "PYSDR_PSD_PACKED", "PYSDR_WFM_PLL", "PYSDR_MIXDEC_MFMA", "PYSDR_MIXDEC_GRID",
               "PYSDR_AM_PLL_WAVES", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS", "PYSDR_MFMA_FLAGS")
 OTHER_CONFIGS = ("c1", "c2", "c4")      # the single-GPU BASELINE configurations the default line carries next to C3
 
@@ -781,7 +781,9 @@ def main():
         # the profile's figure is per launch pair of one group of frames; one call = nframes / group of them
         per_launch = -(-int(sp_tune[0]) // max(1, int(sp_tune[2])))          # frames of one cols + rows launch pair
         psd_tr = (psd_tr[0] * nframes / float(per_launch), psd_tr[1] + f"; per launch pair of {per_launch} frames, scaled to the call")
-    r_psd = roof("psd kernels (window, zero-pad, 64k FFT, |.|^2, dB, fftshift)", psd_bytes, psd_ms, psd_tr,
+    r_psd = roof("psd_cols_pk + psd_rows_pk (window, zero-pad, 64k four-step FFT with a 24-bit intermediate, |.|^2, dB, fftshift)"
+                 if (sp is not None and sp_tune[3]) else "psd kernels (window, zero-pad, 64k FFT, |.|^2, dB, fftshift)",
+                 psd_bytes, psd_ms, psd_tr,
                  note="one call = all frames of the batch; per launch figures are per call")
     # the kernel (group) that dominates the timed region carries the headline roofline object
     dominant = r_psd if (r_psd is not None and (not k1 or psd_ms >= k1_ms)) else r_front
@@ -833,6 +835,7 @@ def main():
                    "psd_group": int(sp_tune[0]) if sp is not None else None,
                    "psd_rocfft": int(sp_tune[1]) if sp is not None else None,
                    "psd_streams": int(sp_tune[2]) if sp is not None else None,
+                   "psd_packed_intermediate": int(sp_tune[3]) if sp is not None else None,
                    "env": {k: os.environ[k] for k in TUNING_ENV if k in os.environ},
                    "argv": " ".join(sys.argv[1:])},
         "source_sha256": {s: source_sha(s) for s in ("mixdec.hip", "mixdec_mfma.hip", "psdfft.hip", "stage2.hip", "api.hip")},

@@ -1416,7 +1416,7 @@ int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size
 
 int pysdr_spectrum_get_tuning(pysdr_spectrum* sp, int32_t out[4]) {
   if (!sp || !out) return PYSDR_ERR_ARG;
-  out[0] = sp->group; out[1] = sp->force_rocfft ? 1 : 0; out[2] = sp->nstreams; out[3] = 0;
+  out[0] = sp->group; out[1] = sp->force_rocfft ? 1 : 0; out[2] = sp->nstreams; out[3] = sp->packed;
   return PYSDR_OK;
 }
 
