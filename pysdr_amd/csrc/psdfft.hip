@@ -330,8 +330,11 @@ __device__ __forceinline__ void cols_unit_pk(const float2* __restrict__ xf, cons
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float sc = (m > 0.f) ? __fdiv_rn(8388600.0f, m) : 1.0f;
-    if (tid == 0) *(PYSDR_AS1 float*)(wf + kPkScaleOff + 4 * cb) = (m > 0.f) ? __fdiv_rn(m, 8388600.0f) * (1.0f / 256.0f) : 0.f;
+    // (a block whose largest component is below 1e-20 contributes powers below 1e-36 * 65536: far under the 1e-30 that is
+    //  added before the logarithm -- it is stored as zeros, which also keeps 8388600 / m finite for denormal m)
+    const bool live = m >= 1.0e-20f;
+    const float sc = live ? __fdiv_rn(8388600.0f, m) : 0.0f;
+    if (tid == 0) *(PYSDR_AS1 float*)(wf + kPkScaleOff + 4 * cb) = live ? __fdiv_rn(m, 8388600.0f) * (1.0f / 256.0f) : 0.f;
     PYSDR_AS1 unsigned* oh = (PYSDR_AS1 unsigned*)wf + (size_t)cb * 4096 + p1 * 16 + b;
     PYSDR_AS1 unsigned short* ol = (PYSDR_AS1 unsigned short*)(wf + kPkLoOff) + (size_t)cb * 4096 + p1 * 16 + b;
 #pragma unroll

@@ -410,6 +410,46 @@ def test_spectrum_periodogram(chunk, nfft, overlap):
     psd_check(pr, pw)
 
 
+@pytest.mark.parametrize("packed", [1, 0])
+def test_psd_24_bit_intermediate_on_hard_inputs(packed, monkeypatch):
+    """The fused 64k PSD stores its four-step intermediate as block-scaled 24-bit fixed point (psdfft.hip, round 4).  The
+    inputs that stress a block-scaled format, every bin against the float64 oracle through psd_check (1e-5 of the peak AND
+    the per-bin bound): white noise (every term of every sum comparable), a line 100 dB above a second one and the noise
+    floor (dynamic range inside a block), an impulse (flat spectrum from one non-zero column), a chirp (flat spectrum from
+    dense data), a frame whose second half is silent, amplitudes of 1e-9 and 1e+6, an all-zero frame and one below the
+    1e-20 block floor (both must give the oracle's -300 dB).  packed = 0: the same inputs through the float2 intermediate,
+    printed side by side (the observed eta of the two forms must be of the same order)."""
+    from pysdr_amd import sig_proc
+    monkeypatch.setenv("PYSDR_TUNING", "1")
+    monkeypatch.setenv("PYSDR_PSD_PACKED", str(packed))
+    N = 32768
+    rng = np.random.default_rng(77)
+    n = np.arange(N)
+    noise = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)
+    tone = lambda f, a: (a * np.exp(2j * np.pi * f * n)).astype(np.complex64)
+    imp = np.zeros(N, np.complex64); imp[12345] = 1.0 + 0.5j
+    chirp = np.exp(1j * np.pi * (n.astype(np.float64) ** 2) / N * 0.9).astype(np.complex64)
+    half = noise.copy(); half[N // 2:] = 0
+    cases = {
+        'noise': 0.3 * noise,
+        'line + line 100 dB down + floor': tone(0.1234, 0.5) + tone(-0.3121, 0.5e-5) + 1e-7 * noise,
+        'impulse': imp,
+        'chirp': 0.4 * chirp,
+        'second half silent': 0.2 * half,
+        'amplitude 1e-9': 1e-9 * (tone(0.05, 1.0) + 0.01 * noise),
+        'amplitude 1e+6': 1e6 * (tone(0.05, 1.0) + 0.01 * noise),
+    }
+    g = sig_proc.spectrum(8000.0, N, 2 * N, 0.0)
+    o64 = so.Spectrum(8000.0, N, 2 * N, 0.0, np.float64)
+    etas = {}
+    for name, x in cases.items():
+        etas[name] = psd_check(g.periodogram(x, True), o64.periodogram(x, True))
+    print(f"packed={packed}: observed eta (bar {PSD_ETA:g}): " + ", ".join(f"{k} {v:.1e}" for k, v in etas.items()))
+    for x in (np.zeros(N, np.complex64), 1e-24 * noise):
+        pg, po = g.periodogram(x, True), o64.periodogram(x, True)
+        assert np.all(np.isfinite(pg)) and np.max(np.abs(pg - po)) <= 1e-3, (pg.min(), pg.max(), po.min(), po.max())
+
+
 @pytest.mark.parametrize("fs_khz,chunk,nfft,L", [(8000.0, 32818, 65636, 170666),   # Plotting.py:370-376 clamp at 8 MS/s
                                                  (10000.0, 32818, 65636, 213333),  # ... and at 10 MS/s
                                                  (2048.0, 43690, 87380, 43690),    # gui.py:611-616, no clamp at 2.048 MS/s
