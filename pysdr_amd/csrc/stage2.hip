@@ -532,9 +532,14 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
   // broadcast FM has no AGC blocks: the whole call is block 0 (walking 2047 empty blocks after it
   // let the envelope decay through hundreds of segment joins that never meet: 140 us)
   const int nch = a.single_block[r] ? (a.nchunks > 0 ? 1 : 0) : a.nchunks;
-  float* pk = agc_lds;                 // [nchunks] block peaks
-  float* ev = agc_lds + a.nchunks;     // [nchunks] envelopes
-  float* sS = ev + a.nchunks;          // [256] start state each segment used, [256] end state it reached
+  // LDS index of block c: one pad word per 16 blocks.  The segments below are 16 blocks long and every lane walks
+  // its own: at a pitch of 16 words the 64 lanes of a read sit on TWO banks (16-way conflict: the walk of 192 reads per
+  // lane was most of this kernel's 26 us at 4096 blocks); at 17 they sit on all of them.
+  auto px = [](int c) { return c + (c >> 4); };
+  const int nlds = px(a.nchunks) + 1;
+  float* pk = agc_lds;                 // [px(nchunks)] block peaks
+  float* ev = agc_lds + nlds;          // [px(nchunks)] envelopes
+  float* sS = ev + nlds;               // [256] start state each segment used, [256] end state it reached
   float* sE = sS + 256;
   // eight loads in flight per thread (a rolled loop waits for each 256-byte-strided load in turn)
   for (int c0 = 0; c0 < nch; c0 += 8 * 256) {
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int c = c0 + u * 256 + tid;
-      if (c < nch) pk[c] = __uint_as_float(v[u]);
+      if (c < nch) pk[px(c)] = __uint_as_float(v[u]);
     }
   }
   __syncthreads();
@@ -565,9 +570,26 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
     int wb = s0 - kWarm;
     float env = 0.f;
     if (tid == 0 || wb <= 0) { wb = 0; env = st.env; }
-    for (int c = wb; c < s0; ++c) env = agc_env_step(env, pk[c]);
+    // sixteen peaks are read ahead of the sixteen steps that use them: with one read per step the LDS latency sat on
+    // the chain 192 times
+    int c = wb;
+    for (; c + 16 <= s0; c += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = pk[px(c + u)];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) env = agc_env_step(env, v[u]);
+    }
+    for (; c < s0; ++c) env = agc_env_step(env, pk[px(c)]);
     sS[tid] = env;
-    for (int c = s0; c < s1; ++c) { env = agc_env_step(env, pk[c]); ev[c] = env; }
+    for (c = s0; c + 16 <= s1; c += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = pk[px(c + u)];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { env = agc_env_step(env, v[u]); ev[px(c + u)] = env; }
+    }
+    for (; c < s1; ++c) { env = agc_env_step(env, pk[px(c)]); ev[px(c)] = env; }
     sE[tid] = env;
   }
   __syncthreads();
@@ -578,17 +600,17 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
       if (__float_as_uint(sE[k - 1]) == __float_as_uint(sS[k])) continue;
       float env = sE[k - 1];
       const int s0 = k * T, s1 = (s0 + T < nch) ? s0 + T : nch;
-      for (int c = s0; c < s1; ++c) { env = agc_env_step(env, pk[c]); ev[c] = env; }
+      for (int c = s0; c < s1; ++c) { env = agc_env_step(env, pk[px(c)]); ev[px(c)] = env; }
       sE[k] = env;
       sS[k] = sE[k - 1];
     }
   }
   __syncthreads();
-  const float last_peak = nch > 0 ? pk[nch - 1] : st.maxbuf;
-  for (int c = tid; c < nch; c += 256) pk[c] = ev[c];      // below: pk[] holds the envelopes
+  const float last_peak = nch > 0 ? pk[px(nch - 1)] : st.maxbuf;
+  for (int c = tid; c < nch; c += 256) pk[px(c)] = ev[px(c)];      // below: pk[] holds the envelopes
   __syncthreads();
   for (int c = tid; c < nch; c += 256) {
-    const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(pk[c], 1e-12f)), 1.0e4f) : 1.f;
+    const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(pk[px(c)], 1e-12f)), 1.0e4f) : 1.f;
     a.gain[(size_t)r * a.nchunks + c] = g;
     // the raw block peaks are consumed: leave them zeroed for the next call
     a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] = 0u;
@@ -616,7 +638,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
     }
   }
   if (tid == 0 && nch > 0) {
-    const float env = pk[nch - 1];
+    const float env = pk[px(nch - 1)];
     const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(env, 1e-12f)), 1.0e4f) : 1.f;
     // field-wise: the squelch block above owns sq_level / sq_open
     a.state[r].env = env;
@@ -1007,7 +1029,8 @@ int launch_demod_fir(const Stage2Args& a, hipStream_t st) {
 }
 
 int launch_agc_scan(const Stage2Args& a, hipStream_t st) {
-  hipLaunchKernelGGL(agc_scan_kernel, dim3(a.nrx), dim3(256), ((size_t)2 * a.nchunks + 512) * sizeof(float), st, a);
+  const size_t nlds = (size_t)a.nchunks + (a.nchunks >> 4) + 1;      // padded: one word per 16 blocks (agc_scan_kernel: px)
+  hipLaunchKernelGGL(agc_scan_kernel, dim3(a.nrx), dim3(256), (2 * nlds + 512) * sizeof(float), st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }
