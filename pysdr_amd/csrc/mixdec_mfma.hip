@@ -1,34 +1,41 @@
 // Mix + polyphase decimate on the matrix cores (gfx950, v_mfma_f32_16x16x4_f32) for ONE sub-receiver with a
 // LONG prototype: the reference's default 1001-tap filter (params.py:134) at 2.048 MS/s -> 48 kHz (am.py path,
-// 334 taps per branch at 3/128) and the 255-tap video filter of the broadcast-FM front end (10 MS/s / 40).
+// 334 taps per branch at 3/128; likewise 1.024 and 2.56 MS/s) and the 255-tap video filter of the broadcast-FM
+// front end (10 MS/s / 40).
 // Same arithmetic contract as mixdec.hip: y[m] = exp(j phi(n_m)) sum_k g[p_m][k] x[n_m-k]
 // with the LO folded into the taps; it stands behind rx.lo + rx.dec of Receiver.demod_data (receiver.py:235).
 //
-// Why: with >= 256 complex taps per output the VALU form of mixdec.hip is bound by vector issue (42 packed FMAs
+// Why: with >= 256 complex taps per output the vector form of mixdec.hip is bound by vector issue (42 packed FMAs
 // + ~45 other instructions per 4 outputs, 4.4 useful MAC/clk/SIMD of 32) while HBM idles at 0.45.  f32 MFMA is
-// exact f32 at the full vector rate from ONE instruction per 1024 MACs, and leaves the VALU to the copy loop.
-// There is no 16-wide "N" in a one-channel FIR, so N is filled with SHIFTS (Toeplitz columns, mixdec_mfma_geom.h):
-// a row is a window of the input, a column is one of the S*UP outputs that window feeds, carrying that output's
-// taps displaced to where its samples sit in the window (zero elsewhere: 45-47 % of the MACs are useful, still
-// 3x the VALU form's rate).  Two chains (A = Re x, A = Im x) into adjacent columns give Re y / Im y directly.
+// exact f32 (a k-ordered fma chain) from ONE instruction per 1024 MACs.  There is no 16-wide "N" in a one-channel FIR,
+// so N is filled with SHIFTS (Toeplitz columns, mixdec_mfma_geom.h): a row is a window of the input, a column is one
+// of the S*UP outputs that window feeds, carrying that output's taps displaced to where its samples sit in the
+// window (zero elsewhere: 45-48 % of the MACs are useful).  Two chains (A = Re x, A = Im x) into adjacent columns give
+// Re y / Im y directly.  What f32 MFMA does NOT do is leave the vector unit free: scripts/diag/mfma_rate.hip measured
+// +4 ... +7 cycles of matrix time per vector instruction of ANY wave on the SIMD -- the structure below is built around that.
 //
-// Structure: persistent grid, one workgroup of NB*WK waves per CU, two LDS images + two partial-sum areas.
-//   image     = the samples of ROWS = 16*NB windows (P = S*DOWN apart) in SEGMENTS of P samples + a 16-byte pad,
-//               filled by LDS-DMA (global_load_lds_dwordx4, one 16-byte pair per lane; the pad is a skipped
-//               lane, so it costs nothing): consecutive rows sit 16 bytes further round the banks, the 16 rows
-//               of a k-step (= the 16 lanes the LDS serves together) never meet.  Without the pad they would
-//               all sit on ONE bank quad (P*8 bytes is a multiple of 256 for every rate that qualifies).
-//   wave      = (row block b, window slice q): SPW k-steps of the window against B registers that never change
-//               (2*SPW VGPRs, loaded once per launch), one ds_read_b64 + two MFMAs per step, two independent
-//               accumulators.  The WK partial tiles of a row block meet in LDS and are added in slice order by
-//               the epilogue threads (one per output) of the NEXT loop trip, which rotate by the LO phase and
-//               store straight to memory: ONE barrier per tile.
+// Structure: persistent grid, one workgroup per CU: NCONS consumer + NDMA copy + NEPI epilogue waves, NBUF LDS images
+// (one tile = one row block of 16 windows each) + two partial-sum areas, ONE barrier per tile.
+//   image     = the samples of 16 windows (P = S*DOWN apart) in SEGMENTS of P samples + a 16-byte pad, filled by LDS-DMA
+//               (global_load_lds_dwordx4, one 16-byte pair per lane; the pad is a lane that repeats its neighbour, so it
+//               costs nothing): consecutive rows sit 16 bytes further round the banks, the 16 rows of a k-step (= the
+//               16 lanes the LDS serves together) never meet.  Without the pad they would all sit on ONE bank quad
+//               (P*8 bytes is a multiple of 256 for every rate that qualifies).
+//   consumer  = window slice q of the row block for the whole launch: its share of the Toeplitz operand in registers,
+//               per k-step one ds_read_b64 through a register ring and two MFMAs into two independent accumulators;
+//               nothing else inside the chain.  The WK partial tiles meet in LDS.
+//   copy      = keeps NBUF-1 tiles of LDS-DMA in flight: SGPR base + a per-lane offset register, four scalar
+//               instructions per KiB, counted s_waitcnt vmcnt(n) (loads return in order).
+//   epilogue  = one thread per output of the PREVIOUS tile: adds the partial tiles in slice order, rotates by the LO
+//               phase (v_sin / v_cos of the exact 32-bit phase) and stores straight to memory.
 //   order     an output's sum runs over its window in a fixed order that depends only on its ABSOLUTE index
-//               (row = m div (UP*S), column = m mod (UP*S)): batch == chunk by chunk bit for bit, like the VALU
+//               (row = m div (UP*S), column = m mod (UP*S)): batch == chunk by chunk bit for bit, like the vector
 //               form.  Zero columns contribute fma(0, x, acc) = acc exactly for finite x; samples outside the
-//               call + history are never loaded (the image is zeroed once per launch and only ever holds
+//               call + history are never loaded (the images are zeroed once per launch and only ever hold
 //               finite stream samples afterwards).  A non-finite INPUT sample poisons all S*UP outputs of its
 //               rows instead of only those whose taps reach it -- the one observable difference.
+// DESIGN.md 4.1b has the measurements that led here; MM_NO_* / MM_*_PRIO / MM_C?_* are compile-time A/B switches for
+// scripts/diag/mfma_ablate.sh (work-skipping ones give WRONG results and exist for timing only).
 #include "common.h"
 #include "mixdec_geom.h"
 #include "mixdec_mfma_geom.h"
