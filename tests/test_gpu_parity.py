@@ -349,6 +349,36 @@ def test_device_resident_batch_and_untouched_input():
     _lib.check(lib.pysdr_dev_free(0, d), "free")
 
 
+@pytest.mark.parametrize("name", ["C1", "C2"])
+def test_device_batch_at_an_odd_sample_offset(name):
+    """A device-resident batch that starts at an ODD sample of its buffer is only 8-byte aligned.  The LDS-DMA of both
+    mix + decimate kernels takes such a source (scripts/diag/glds_align_test.hip: any 4-byte aligned address; the
+    matrix-core form relies on it, the vector form falls back to its generic staging): same bits as the same samples from
+    a 16-byte aligned buffer, and the oracle's values."""
+    from pysdr_amd import _lib
+    cfg = so.CONFIGS[name]
+    L, B = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3], 6
+    x = so.synth_iq(cfg, B * L + 1, 21)
+    lib = _lib.lib()
+    d = C.c_void_p()
+    _lib.check(lib.pysdr_dev_alloc(0, x.nbytes, C.byref(d)), "alloc")
+    try:
+        _lib.check(lib.pysdr_dev_upload(0, d, C.c_void_p(x.ctypes.data), x.nbytes), "upload")
+        P1, g1 = make_gpu_receivers(cfg, max_batch_chunks=B)
+        P1._pysdr_stream.process_batch(d.value + 8, B, L, on_device=True)          # samples 1 .. B*L of the buffer
+        odd = P1._pysdr_stream.fetch(0, B)
+        P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B)
+        P2._pysdr_stream.process_batch(np.ascontiguousarray(x[1:]), B, L, on_device=False)   # staged: 16-byte aligned
+        even = P2._pysdr_stream.fetch(0, B)
+    finally:
+        lib.pysdr_dev_free(0, d)
+    for u, v in zip(odd, even):
+        assert np.array_equal(u, v)
+    o = so.make_receivers(cfg, np.float32)[0]
+    want = np.concatenate([(o.demod_data(x[1 + k * L:1 + (k + 1) * L]), o.iq.copy())[1] for k in range(B)])
+    assert relerr(odd[1], want) <= TOL          # the baseband IQ (the stage under test; the NFM audio's start-up has its own allowance)
+
+
 def test_long_prototype_1001_taps_and_10msps():
     cfg = dict(so.CONFIGS['C2'], fs=10e6, ntaps_dec=1001,
                carriers=[dict(f=455e3, kind='fm', amp=0.3, tone=1000.0, dev=3000.0)])
