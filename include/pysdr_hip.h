@@ -158,7 +158,8 @@ int pysdr_get_elapsed_ms(pysdr_ctx* ctx, int which, int back, float* ms);
 int pysdr_set_tile(pysdr_ctx* ctx, int tile_bytes, int threads);
 /* What the context was really created with, so that a benchmark line can echo it (VERDICT r1
  * hygiene): out = {diagnostic build (-DPYSDR_DIAG) 0/1, PYSDR_DEBUG_FLAGS (always 0 outside a
- * diagnostic build), workgroups per CU, output-stage flush cap, tile bytes, threads, CUs, 0}. */
+ * diagnostic build), workgroups per CU, output-stage flush cap, tile bytes, threads, CUs,
+ * long single-RX prototypes on the matrix cores 0/1}. */
 int pysdr_get_tuning(pysdr_ctx* ctx, int32_t out[8]);
 
 /* ---- signal_generator.quad_mixer (receiver.py:552-553,822) --------------------
@@ -186,7 +187,8 @@ int pysdr_spectrum_frame(pysdr_spectrum* sp, const float* x, int is_complex, int
 int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size_t hop,
                          void* d_out);
 int pysdr_spectrum_sync(pysdr_spectrum* sp);
-/* out = {frames per launch group of the fused 64k path, rocFFT forced 0/1, streams the groups are dealt over, 0} */
+/* out = {frames per launch group of the fused 64k path, rocFFT forced 0/1, streams the groups are dealt over,
+ * four-step intermediate stored as 24-bit block-scaled fixed point 0/1} */
 int pysdr_spectrum_get_tuning(pysdr_spectrum* sp, int32_t out[4]);
 int pysdr_spectrum_elapsed_ms(pysdr_spectrum* sp, float* ms);
 /* Ordering between the spectrum's stream and a receiver context's stream (both read the same
