@@ -44,6 +44,10 @@ namespace pysdr {
 
 namespace {
 
+// "this many copies were issued": an edge tile issues one per piece that has a live lane, which only the hardware counts --
+// any sum that contains this value is negative, and mm_dma_wait_allow then waits for everything
+constexpr int kMmUnknown = -1000000;
+
 typedef float mm_f4 __attribute__((ext_vector_type(4)));
 typedef float mm_f2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) mm_f2* mm_lds_cf2;
@@ -371,7 +375,7 @@ __device__ __forceinline__ void mm_dma(const MixMfmaArgs& a, unsigned lds0, int 
       return my_pieces;
     }
     mm_stage<G>(a, origin_rel, img, pw, npw, lane);
-    return -1000;
+    return kMmUnknown;
   };
   constexpr int kNeed = G::CARRY ? 1 : 0;              // tiles beyond tb that must have landed at the top of trip tb
   constexpr int kKI = G::NBUF - 2 - kNeed;             // tiles that may still be in flight there: tb+kNeed+1 .. tb+NBUF-2
