@@ -230,6 +230,31 @@ def test_retune_filter_swap_mode_change_and_agc_reset():
             assert relerr(am_g, am_o) <= TOL, (k, i, 'am')
 
 
+def test_retune_and_filter_swap_on_the_matrix_core_path():
+    """The same controls on ONE sub-receiver with the reference's default 1001-tap prototype at 2.048 MS/s, whose mix +
+    decimate runs on the matrix cores: the Toeplitz operand is rebuilt from the LO-folded taps at every launch, so a retune
+    (rx.lo.change_freq, gui.py:1938) and a filter swap (rx.dec.h = ..., gui.py:1713) take effect at the next chunk, phase
+    continuous, as in the oracle; and in the middle of a BATCH they cannot happen (one launch = one set of taps)."""
+    cfg = so.CONFIGS['C1']
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    x = so.synth_iq(cfg, 10 * L, 16)
+    P, g = make_gpu_receivers(cfg)
+    o = so.make_receivers(cfg, np.float32)
+    for k in range(10):
+        if k == 3:
+            fa, fb = g[0].lo.change_freq(-100.7e3), o[0].lo.change_freq(-100.7e3)
+            assert fa == pytest.approx(fb, abs=1e-9)
+        if k == 5:
+            g[0].dec.h = g[0].dec.filter_bank[3]
+            o[0].dec.set_taps(o[0].dec.filter_bank[3])
+        if k == 7:
+            fa, fb = g[0].lo.change_freq(-100e3), o[0].lo.change_freq(-100e3)
+        xc = x[k * L:(k + 1) * L]
+        am_g, am_o = g[0].demod_data(xc), o[0].demod_data(xc)
+        assert relerr(g[0].iq, o[0].iq) <= TOL, (k, 'iq')
+        assert relerr(am_g, am_o) <= TOL, (k, 'am')
+
+
 def test_batch_equals_chunked_bit_exact():
     """One launch over B chunks == B single-chunk calls (sigs/iir.py:83-125 property),
     bit for bit: the per-output summation order does not depend on the tiling."""
