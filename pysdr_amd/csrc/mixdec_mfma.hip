@@ -251,6 +251,9 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
     }
     mm_f4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     float m_prev = 0.f;
+#ifdef MM_NO_CONS                     // experiment: the consumers only keep the barrier (results WRONG): the copy pipeline alone
+    if (a.n_out < 0)
+#endif
 #pragma unroll
     for (int ls = 0; ls < kN; ++ls) {
       const mm_f2 v = ring[ls % kA];
@@ -299,15 +302,15 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
   if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
 }
 
-// Reduce + rotate + store the outputs of tile `tb` from its partial sums (thread e = output e of the tile).
+// Reduce + rotate output e of tile `tb` from its partial sums (thread e = output e of the tile; false: no such output).
 template <class G>
-__device__ __forceinline__ void mm_epilogue(const MixMfmaArgs& a, int tb, unsigned part, int e) {
-  if (e >= G::OUT_PER_TILE) return;
+__device__ __forceinline__ bool mm_epilogue(const MixMfmaArgs& a, int tb, unsigned part, int e, float2& o) {
+  if (e >= G::OUT_PER_TILE) return false;
   const int rho = e / G::US, rem = e - rho * G::US;     // row of the tile, column pair = (t, c)
   const int t = rem / G::UP, c = rem - t * G::UP;
   const int b = rho >> 4, i = rho & 15;
   const int idx = a.mrel0 + tb * G::OUT_PER_TILE + e;
-  if (idx < 0 || idx >= a.n_out) return;
+  if (idx < 0 || idx >= a.n_out) return false;
   // partial tiles [b][q][col][row]
   const mm_lds_cf pr = (mm_lds_cf)(size_t)(part + (unsigned)(b * G::WK * 1024 + (2 * rem) * 64 + i * 4));
   float sr = pr[0], si = pr[16];
@@ -317,26 +320,51 @@ __device__ __forceinline__ void mm_epilogue(const MixMfmaArgs& a, int tb, unsign
   const uint32_t ph = a.phase0 + a.fword * (uint32_t)rel;
   const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
   const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
-  float2 o;
   o.x = sr * cs - si * sn;
   o.y = sr * sn + si * cs;
-  a.y[idx] = o;
+  return true;
 }
 
-// The epilogue waves: one thread per output of a tile, one trip behind the consumers.
+// The workgroup barrier as the epilogue waves need it: what it has to order is LDS traffic only (the partial sums), and
+// the compiler must not move LDS accesses across it; nothing inside the kernel reads what these waves store.
+__device__ __forceinline__ void mm_barrier_lds_only() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// The epilogue waves: one thread per output of a tile, one trip behind the consumers; the outputs leave with ONE store per
+// tile (kFlush = 1).  Holding the outputs of 8 / 16 tiles in registers and storing them in one burst -- the vector form had
+// to batch its stores, they shared vmcnt with its copies -- measured 3-5 % SLOWER here (0.320 / 0.325 against 0.307-0.312 ms
+// on C1, same box): the stores of these waves wait for nothing and a burst only delays them.  (MM_EPI_FLUSH for the A/B.)
 template <class G>
 __device__ __forceinline__ void mm_epi(const MixMfmaArgs& a, unsigned part0, int etid, int t_begin, int t_end) {
-  __syncthreads();                    // (1)
-  int par = 0;
-  for (int tb = t_begin; tb < t_end; ++tb) {
-    __syncthreads();
-#ifndef MM_NO_EPI                     // experiment (results WRONG)
-    if (tb > t_begin) mm_epilogue<G>(a, tb - 1, part0 + (par ? 0u : (unsigned)G::PART_BYTES), etid);
+#ifdef MM_EPI_FLUSH
+  constexpr int kFlush = MM_EPI_FLUSH;
+#else
+  constexpr int kFlush = 1;
 #endif
-    par ^= 1;
+  const int n = t_end - t_begin;
+  mm_barrier_lds_only();              // (1)
+  mm_barrier_lds_only();              // trip 0: no tile is finished yet
+  for (int i0 = 0; i0 < n; i0 += kFlush) {
+    float2 hold[kFlush];
+    bool have[kFlush];
+#pragma unroll
+    for (int j = 0; j < kFlush; ++j) {
+      have[j] = false;
+      hold[j] = make_float2(0.f, 0.f);
+      if (i0 + j < n) {               // tile i0+j is complete behind the barrier of the trip after it (or the last one)
+        mm_barrier_lds_only();
+#ifndef MM_NO_EPI                     // experiment (results WRONG)
+        have[j] = mm_epilogue<G>(a, t_begin + i0 + j, part0 + (((i0 + j) & 1) ? (unsigned)G::PART_BYTES : 0u), etid, hold[j]);
+#endif
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kFlush; ++j)
+      if (have[j]) a.y[a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + etid] = hold[j];
   }
-  __syncthreads();                    // (last)
-  mm_epilogue<G>(a, t_end - 1, part0 + (par ? 0u : (unsigned)G::PART_BYTES), etid);
 }
 
 // The DMA waves: keep NBUF-1 tiles of copies in flight, and scan the raw peak of the (few) tiles whose image touches
