@@ -255,10 +255,16 @@ def test_retune_and_filter_swap_on_the_matrix_core_path():
         assert relerr(am_g, am_o) <= TOL, (k, 'am')
 
 
-def test_batch_equals_chunked_bit_exact():
+@pytest.mark.parametrize("grid", [0, 5])
+def test_batch_equals_chunked_bit_exact(grid, monkeypatch):
     """One launch over B chunks == B single-chunk calls (sigs/iir.py:83-125 property),
-    bit for bit: the per-output summation order does not depend on the tiling."""
+    bit for bit: the per-output summation order does not depend on the tiling.  grid = 5: the persistent mix + decimate
+    kernel held to five workgroups, so that each walks ~50 tiles of the batch (incremental tile geometry, the output
+    stage's flush cadence, peaks carried across chunk boundaries) where the default grid gives it one or two."""
     from pysdr_amd import sig_proc
+    if grid:
+        monkeypatch.setenv("PYSDR_TUNING", "1")
+        monkeypatch.setenv("PYSDR_MIXDEC_GRID", str(grid))
     cfg = so.CONFIGS['C3']
     L, B = 170666, 12
     x = so.synth_iq(cfg, B * L, 7)
