@@ -775,7 +775,8 @@ def main():
                   (("mixdec_mfma_kernel<1/40>" if mfma_on else "mixdec_kernel<1,16>") +
                    " + wfm_disc/pll + mixdec_kernel<1,..> (FM front end: IF decimate, discriminator, pilot PLL, audio resample)"))
     r_front = roof(front_name, k1_bytes, k1_ms if k1 else None,
-                   measured_traffic(args, nrx, B, "mixdec", ["mixdec.hip", "mixdec_mfma.hip", "mixdec_mfma_geom.h"]))
+                   measured_traffic(args, nrx, B, "mixdec", ["mixdec_mfma.hip", "mixdec_mfma_geom.h"] if (mfma_on and not is_wfm)
+                                    else (["mixdec_mfma.hip", "mixdec_mfma_geom.h", "resamp_small.hip"] if mfma_on else ["mixdec.hip"])))
     psd_tr = measured_traffic(args, nrx, B, "psd", ["psdfft.hip"])
     if psd_tr[0] is not None and sp is not None and sp_tune[0] > 0:
         # the profile's figure is per launch pair of one group of frames; one call = nframes / group of them
