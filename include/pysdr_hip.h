@@ -148,8 +148,8 @@ int pysdr_fetch(pysdr_ctx* ctx, int irx, float* am, float* iq, int cap, int* n_o
 int pysdr_sync(pysdr_ctx* ctx);
 
 /* Per-call timing with HIP events recorded on the context's stream (a ring of the last
- * 64 calls; back = 0 is the most recent call): which = 0 mix+decimate kernel,
- * 1 detector/AF/AGC kernels, 2 whole call, 3 from the start of the call before it to the start of
+ * 64 calls; back = 0 is the most recent call): which = 0 mix+decimate kernel (front end),
+ * 1 detector/AF/AGC kernels and the history roll behind them, 2 whole call, 3 from the start of the call before it to the start of
  * this one (the period of a step when calls follow each other on the stream).  Events are only
  * recorded while enabled. */
 int pysdr_set_profile(pysdr_ctx* ctx, int enable);

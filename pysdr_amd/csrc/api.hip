@@ -129,7 +129,10 @@ struct pysdr_ctx {
   int last_wfm = 0;              // the last call ran the broadcast-FM pipeline
   float2* d_stage = nullptr;
   size_t stage_cap = 0;
-  unsigned* d_peak = nullptr;    // [max_chunks]
+  unsigned* d_peak = nullptr;    // [max_chunks] raw-chunk peaks of the last call = d_peak2[peak_cur]
+  unsigned* d_peak2[2] = {nullptr, nullptr};   // two buffers: the history-roll kernel of a call zeroes the OTHER one for the next
+  int peak_cur = 0;              //   call (a memset per call was one more kernel + 4 us on the stream)
+  bool peak_clean[2] = {true, true};   // that buffer is all zero (a call that failed before its history roll leaves the other dirty)
 #ifdef PYSDR_DIAG
   unsigned long long* d_stamps = nullptr;   // mixdec phase stamps (PYSDR_DEBUG_FLAGS & 256)
 #endif
@@ -165,6 +168,8 @@ struct pysdr_ctx {
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
   hipEvent_t ev[kSlots][4] = {};
   hipEvent_t ev_front = nullptr;          // the input of the last call has been consumed (front end done)
+  hipEvent_t front_marker = nullptr;      // the event that marks it for the LAST call (ev_front, the profile's, or none)
+  int front_wanted = 0;                   // a spectrum has ordered itself behind the front end: keep recording ev_front
   unsigned long long ncalls = 0;
   // RCCL
   void* rccl_lib = nullptr;
@@ -342,8 +347,10 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
     b.magic_chunk = (b.chunk_len == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned long long)b.chunk_len) + 1u;
     int rc = launch_mixdec_mfma(mshape, b, c->grid_override > 0 ? c->grid_override : c->num_cus, c->stream);
     if (rc) return rc;
-    rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, c->stream);
+    rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n,
+                          peak ? c->d_peak2[c->peak_cur ^ 1] : nullptr, peak ? c->cfg.max_chunks : 0, c->stream);
     if (rc) return rc;
+    if (peak) c->peak_clean[c->peak_cur ^ 1] = true;
     d.hist_cur ^= 1;
     d.s_abs = s1;
     if (res) { res->n_out = n_out; res->t0 = (uint32_t)(m0 * down - s0 * up); res->m0 = m0; }
@@ -429,8 +436,10 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   int rc = small ? launch_resamp_small(a, c->stream)
                  : launch_mixdec(a, c->threads, c->grid_override > 0 ? c->grid_override : c->num_cus * wgs, c->stream);
   if (rc) return rc;
-  rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, c->stream);
+  rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n,
+                        peak ? c->d_peak2[c->peak_cur ^ 1] : nullptr, peak ? c->cfg.max_chunks : 0, c->stream);
   if (rc) return rc;
+  if (peak) c->peak_clean[c->peak_cur ^ 1] = true;
   d.hist_cur ^= 1;
   d.s_abs = s1;
   if (res) { res->n_out = n_out; res->t0 = a.t0; res->m0 = m0; }
@@ -647,7 +656,11 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   rc = decim_init(c->main, cfg->up, cfg->down, cfg->ntaps_dec, PYSDR_MAX_RX, c->stream);
   if (rc) { pysdr_destroy(c); return rc; }
-  CK(hipMalloc(&c->d_peak, (size_t)cfg->max_chunks * sizeof(unsigned)));
+  for (int i = 0; i < 2; ++i) {
+    CK(hipMalloc(&c->d_peak2[i], (size_t)cfg->max_chunks * sizeof(unsigned)));
+    CK(hipMemsetAsync(c->d_peak2[i], 0, (size_t)cfg->max_chunks * sizeof(unsigned), c->stream));
+  }
+  c->d_peak = c->d_peak2[0];
   CK(hipMalloc(&c->d_peak_scratch, 64 * sizeof(unsigned)));
   CK(hipMalloc(&c->d_blkpeak, (size_t)PYSDR_MAX_RX * cfg->max_chunks * kBlkStride * sizeof(unsigned)));
   CK(hipMemsetAsync(c->d_blkpeak, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * kBlkStride * sizeof(unsigned), c->stream));
@@ -686,7 +699,7 @@ void pysdr_destroy(pysdr_ctx* c) {
   decim_free(c->main);
   decim_free(c->wfm_front);
   if (c->d_stage) (void)hipFree(c->d_stage);
-  if (c->d_peak) (void)hipFree(c->d_peak);
+  for (int i = 0; i < 2; ++i) if (c->d_peak2[i]) (void)hipFree(c->d_peak2[i]);
   if (c->d_peak_scratch) (void)hipFree(c->d_peak_scratch);
   if (c->d_blkpeak) (void)hipFree(c->d_blkpeak);
   if (c->d_gain) (void)hipFree(c->d_gain);
@@ -886,7 +899,7 @@ int pysdr_get_elapsed_ms(pysdr_ctx* c, int which, int back, float* ms) {
   hipEvent_t* ev = c->ev[(c->ncalls - 1 - back) % pysdr_ctx::kSlots];
   PYSDR_HIP_CHECK(hipEventSynchronize(ev[3]));
   hipEvent_t a = ev[0], b = ev[1];
-  if (which == 1) { a = ev[1]; b = ev[2]; }
+  if (which == 1) { a = ev[1]; b = ev[3]; }
   if (which == 2) { a = ev[0]; b = ev[3]; }
   if (which == 3) {              // start of the previous call -> start of this one: the period of a step
     a = c->ev[(c->ncalls - 2 - back) % pysdr_ctx::kSlots][0];
@@ -968,7 +981,11 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
 
   const int up = c->cfg.up, down = c->cfg.down;
   const unsigned long long s0 = wfm ? c->wfm_front.s_abs : c->main.s_abs;
-  PYSDR_HIP_CHECK(hipMemsetAsync(c->d_peak, 0, (size_t)nchunks * sizeof(unsigned), c->stream));
+  c->peak_cur ^= 1;                       // zeroed by the previous call's history roll (both are zero at the start)
+  c->d_peak = c->d_peak2[c->peak_cur];
+  if (!c->peak_clean[c->peak_cur])        // ... unless that call failed on the way: then by hand
+    PYSDR_HIP_CHECK(hipMemsetAsync(c->d_peak, 0, (size_t)c->cfg.max_chunks * sizeof(unsigned), c->stream));
+  c->peak_clean[c->peak_cur] = false;
 
   float2* yptr[PYSDR_MAX_RX];
   uint32_t ph[PYSDR_MAX_RX], fw[PYSDR_MAX_RX];
@@ -1035,8 +1052,13 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     }
   }
   const int n_out = res.n_out;
-  if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[1], c->stream));
-  PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream));
+  // "the input of this call has been consumed": a spectrum that orders itself behind the front end waits for it
+  // (pysdr_spectrum_order, direction 2).  An event record costs ~5.5 us of the stream's timeline on this runtime (the
+  // kernel behind it starts that much later: scripts/diag/timeline.sh), so ONE event serves both the profile and the
+  // ordering, and none is recorded when nobody asked for either.
+  c->front_marker = nullptr;
+  if (c->profile) { PYSDR_HIP_CHECK(hipEventRecord(ev[1], c->stream)); c->front_marker = ev[1]; }
+  else if (c->front_wanted) { PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream)); c->front_marker = c->ev_front; }
 
   Stage2Args s;
   memset(&s, 0, sizeof(s));
@@ -1088,7 +1110,6 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   // WFM (mono) emits the real part of the complex pipeline
   for (int r = 0; r < nrx; ++r) if (snap.rx[r].mode == PYSDR_WFM) s.out_complex[r] = 0;
   rc = launch_apply(s, c->stream); if (rc) return rc;
-  if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[2], c->stream));
 
   EpilogueArgs e;
   memset(&e, 0, sizeof(e));
@@ -1442,8 +1463,12 @@ int pysdr_spectrum_order(pysdr_spectrum* sp, pysdr_ctx* c, int direction) {
   int rc = use_device(sp->device);
   if (rc) return rc;
   if (direction == 2) {
-    PYSDR_HIP_CHECK(hipStreamWaitEvent(sp->stream, c->ev_front, 0));
-    return PYSDR_OK;
+    c->front_wanted = 1;                  // from the next call on the front end's end is marked
+    if (c->front_marker) {
+      PYSDR_HIP_CHECK(hipStreamWaitEvent(sp->stream, c->front_marker, 0));
+      return PYSDR_OK;
+    }
+    direction = 0;                        // this call was not marked: behind everything the context has queued (stricter)
   }
   if (!sp->ev_order) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&sp->ev_order, hipEventDisableTiming));
   hipStream_t first = direction == 0 ? c->stream : sp->stream;

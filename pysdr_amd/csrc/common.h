@@ -211,8 +211,9 @@ struct EpilogueArgs {
 };
 int launch_epilogue(const EpilogueArgs& a, hipStream_t st);
 // new history = last hist_len samples of [old history | x[0..n)]
+// (+ zeroes `zero[0 .. zero_n)`: the raw-peak buffer of the next call)
 int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len,
-                     uint32_t n_total, hipStream_t st);
+                     uint32_t n_total, unsigned* zero, int zero_n, hipStream_t st);
 
 // ---- broadcast FM (WFM / WFM2) at the IF rate fs1 (stage2.hip) -------------------------
 struct WfmArgs {

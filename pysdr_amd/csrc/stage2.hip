@@ -715,14 +715,16 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const EpilogueArgs a) {
 }
 
 // ---- raw-sample history of a decimator: new = last hist_len samples of [old | x]
+// (+ zero the raw-peak buffer the NEXT call will accumulate into: api.hip keeps two and flips)
 __global__ __launch_bounds__(256) void hist_roll_kernel(const float2* __restrict__ x,
                                                         const float2* __restrict__ hist_old,
                                                         float2* __restrict__ hist_new, int hist_len,
-                                                        uint32_t n_total) {
+                                                        uint32_t n_total, unsigned* __restrict__ zero, int zero_n) {
   for (int j = threadIdx.x; j < hist_len; j += 256) {
     const long long rel = (long long)n_total - hist_len + j;
     hist_new[j] = (rel >= 0) ? x[rel] : hist_old[hist_len + rel];
   }
+  for (int j = threadIdx.x; j < zero_n; j += 256) zero[j] = 0u;
 }
 
 // ---- broadcast FM at the IF rate: polar discriminator (all lanes), then the 19 kHz pilot
@@ -1054,8 +1056,8 @@ int launch_epilogue(const EpilogueArgs& a, hipStream_t st) {
 }
 
 int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len,
-                     uint32_t n_total, hipStream_t st) {
-  hipLaunchKernelGGL(hist_roll_kernel, dim3(1), dim3(256), 0, st, x, hist_old, hist_new, hist_len, n_total);
+                     uint32_t n_total, unsigned* zero, int zero_n, hipStream_t st) {
+  hipLaunchKernelGGL(hist_roll_kernel, dim3(1), dim3(256), 0, st, x, hist_old, hist_new, hist_len, n_total, zero, zero_n);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }

@@ -227,7 +227,8 @@ int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t) {
   return PYSDR_ERR_ARG;
 }
 
-int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len, uint32_t n_total, hipStream_t) {
+int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len, uint32_t n_total, unsigned* zero, int zero_n, hipStream_t) {
+  if (zero_n > 0) write_all(zero, (size_t)zero_n);
   for (int j = 0; j < hist_len; ++j) {
     const long long rel = (long long)n_total - hist_len + j;
     hist_new[j] = (rel >= 0) ? x[rel] : hist_old[hist_len + rel];
