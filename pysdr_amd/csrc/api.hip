@@ -192,6 +192,7 @@ struct pysdr_spectrum {
   hipEvent_t ev_order = nullptr;
   bool force_rocfft = false;  // PYSDR_PSD_ROCFFT: rocFFT even for the 32768 -> 65536 size
   int group = 448;            // frames per launch pair of the four-step path (PYSDR_PSD_GROUP)
+  bool ran = false;           // spectrum_run has recorded ev[1] at least once
   int packed = 1;             // four-step intermediate as block-scaled 24-bit fixed point (psdfft.hip; PYSDR_PSD_PACKED=0: float2)
   // PYSDR_PSD_STREAMS=2: the groups alternate between two streams, each with its own half-size intermediate
   // (2 x group/2 frames = the same Infinity Cache footprint), so that the columns of one group run beside
@@ -1365,8 +1366,9 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
         sp->xwork_frames = (size_t)part;
       }
       PYSDR_HIP_CHECK(hipEventRecord(sp->ev[0], sp->stream));
-      PYSDR_HIP_CHECK(hipEventRecord(sp->ev_fork, sp->stream));          // the side streams start behind whatever sp->stream waited for
-      for (int i = 1; i < ns; ++i) PYSDR_HIP_CHECK(hipStreamWaitEvent(sp->xstream[i], sp->ev_fork, 0));
+      // the side streams start behind whatever sp->stream waited for: they wait for the call's start event itself (a
+      // second event for the fork was 5.5 us more on the stream)
+      for (int i = 1; i < ns; ++i) PYSDR_HIP_CHECK(hipStreamWaitEvent(sp->xstream[i], sp->ev[0], 0));
       int k = 0;
       for (int f0 = 0; f0 < nframes; f0 += part, ++k) {
         const int nf = (nframes - f0 < part) ? nframes - f0 : part;
@@ -1419,6 +1421,7 @@ int pysdr_spectrum_frame(pysdr_spectrum* sp, const float* x, int is_complex, int
   const size_t bytes = (size_t)sp->chunk * (is_complex ? sizeof(float2) : sizeof(float));
   PYSDR_HIP_CHECK(hipMemcpyAsync(sp->d_in, x, bytes, hipMemcpyHostToDevice, sp->stream));
   rc = spectrum_run(sp, sp->d_in, 0, 1, is_complex, db, sp->d_out);
+  if (!rc) sp->ran = true;
   if (rc) return rc;
   const int nout = is_complex ? sp->nfft : sp->nfft / 2;
   PYSDR_HIP_CHECK(hipMemcpyAsync(psd_out, sp->d_out, (size_t)nout * sizeof(float), hipMemcpyDeviceToHost, sp->stream));
@@ -1431,8 +1434,9 @@ int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size
   if (!sp || !d_iq || !d_out || nframes < 1 || nframes > sp->max_frames) return PYSDR_ERR_ARG;
   int rc = use_device(sp->device);
   if (rc) return rc;
-  return spectrum_run(sp, reinterpret_cast<const float2*>(d_iq), hop, nframes, 1, 1,
-                      reinterpret_cast<float*>(d_out));
+  rc = spectrum_run(sp, reinterpret_cast<const float2*>(d_iq), hop, nframes, 1, 1, reinterpret_cast<float*>(d_out));
+  if (!rc) sp->ran = true;
+  return rc;
 }
 
 int pysdr_spectrum_get_tuning(pysdr_spectrum* sp, int32_t out[4]) {
@@ -1469,6 +1473,10 @@ int pysdr_spectrum_order(pysdr_spectrum* sp, pysdr_ctx* c, int direction) {
       return PYSDR_OK;
     }
     direction = 0;                        // this call was not marked: behind everything the context has queued (stricter)
+  }
+  if (direction == 1 && sp->ran) {        // the context behind the spectrum's last call: its end event is already there
+    PYSDR_HIP_CHECK(hipStreamWaitEvent(c->stream, sp->ev[1], 0));
+    return PYSDR_OK;
   }
   if (!sp->ev_order) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&sp->ev_order, hipEventDisableTiming));
   hipStream_t first = direction == 0 ? c->stream : sp->stream;
