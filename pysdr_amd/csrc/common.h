@@ -94,8 +94,14 @@ struct MixMfmaArgs {
 // instantiations: X(id, UP, DOWN, S shifts, taps per branch, NB row blocks per tile, WK window slices, producer waves, LDS images, operand ring carried across tiles)
 //   0: 2.048 MS/s -> 48 kHz with the reference's default 1001-tap prototype (params.py:134; am.py path, BASELINE C1)
 //   1: the 255-tap video filter of the broadcast-FM front end at 10 MS/s / 40 (BASELINE C4)
-//   2, 3: the same 1001-tap prototype at the other rates of Tables.py:44-45 whose window fits the LDS: 1.024 and 2.56 MS/s
-//      (8 MS/s -> 48 kHz would need 130 KB per image: it stays on the vector form, as does every multi-RX stream)
+//   2 - 4: the same 1001-tap prototype at the other rates of Tables.py:44-45 with UP = 3: 1.024, 2.56 and 1.792 MS/s
+//   5, 6: 1.536 and 1.92 MS/s = 1/32 and 1/40: all 1001 taps in ONE branch = 38-39 k-steps per consumer wave = 76-78
+//      VGPRs of B operands, more than the 128 registers of a 16-wave workgroup hold beside the ring.  These two run 12 waves
+//      (8 consumers + 2 copy + 2 epilogue: 168 registers each); they are bound by the matrix cores, not by the copies, so
+//      two copy waves keep up.  1/40 takes S = 6 shifts: S = 8 (41 steps) reloads spilled operands inside the tile loop,
+//      S = 7 spills five registers around it and is 9 % faster than S = 6, but no shipped kernel uses scratch
+//      (tests/test_isa_checks.py).  Vector form -> this form, measured: 1.466 -> 0.579 ms and 1.197 -> 0.567 ms per 170 M samples.
+//   (8 MS/s -> 48 kHz would need 130 KB per image: it stays on the vector form, as does every multi-RX stream.)
 // (producer waves / images can be overridden for A/B builds of mixdec_mfma.hip alone: they do not enter the host's plan)
 #ifndef MM_C1_NPROD
 #define MM_C1_NPROD 8
@@ -122,7 +128,10 @@ struct MixMfmaArgs {
   X(0, 3, 128, 2, 334, 1, 8, MM_C1_NPROD, MM_C1_NBUF, MM_C1_CARRY) \
   X(1, 1, 40, MM_C4_S, 255, 1, 8, MM_C4_NPROD, MM_C4_NBUF, MM_C4_CARRY) \
   X(2, 3, 64, 2, 334, 1, 8, 8, 4, 1) \
-  X(3, 3, 160, 2, 334, 1, 8, 8, 3, 0)
+  X(3, 3, 160, 2, 334, 1, 8, 8, 3, 0) \
+  X(4, 3, 112, 2, 334, 1, 8, 8, 4, 1) \
+  X(5, 1, 32, 8, 1001, 1, 8, 4, 3, 0) \
+  X(6, 1, 40, 6, 1001, 1, 8, 4, 3, 0)
 int mixdec_mfma_shape(int up, int down, int kdec);   // -1: none
 bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, unsigned long long n, MfmaPlan* p);
 int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t st);

@@ -1,5 +1,5 @@
 """One sub-receiver with the reference's default 1001-tap prototype (params.py:134) at the rates of Tables.py:44-45 that have
-a matrix-core shape (mixdec_mfma.hip: 1.024, 2.048, 2.56 MS/s -> 48 kHz), batch resident in HBM: front-end kernel time and
+a matrix-core shape (mixdec_mfma.hip: 1.024, 1.536, 1.792, 1.92, 2.048, 2.56 MS/s -> 48 kHz), batch resident in HBM: front-end kernel time and
 fraction of the 8 TB/s HBM roofline, matrix-core form and (PYSDR_TUNING=1 PYSDR_MIXDEC_MFMA=0, in a child process) vector form.
     python scripts/long_prototype_rates.py"""
 import ctypes as C, json, os, subprocess, sys, time
@@ -45,7 +45,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         print(json.dumps(one(float(sys.argv[1]))))
         sys.exit(0)
-    for fs in (1.024e6, 2.048e6, 2.56e6):
+    for fs in (1.024e6, 1.536e6, 1.792e6, 1.92e6, 2.048e6, 2.56e6):
         row = {}
         for name, env in (("matrix cores", {}), ("vector form", {"PYSDR_TUNING": "1", "PYSDR_MIXDEC_MFMA": "0"})):
             p = subprocess.run([sys.executable, os.path.abspath(__file__), str(fs)], env=dict(os.environ, **env), stdout=subprocess.PIPE)

@@ -276,6 +276,9 @@ int main(int argc, char** argv) {
   single_rx_long_prototype(kRates[1]);               // 3/128
   single_rx_long_prototype(kRates[4]);               // 3/64
   single_rx_long_prototype(Rate{2.56e6, 3, 160, 54613});
+  single_rx_long_prototype(Rate{1.792e6, 3, 112, 38229});
+  single_rx_long_prototype(Rate{1.536e6, 1, 32, 32768});   // 12-wave shapes: all 1001 taps in one branch
+  single_rx_long_prototype(Rate{1.92e6, 1, 40, 40960});
   narrowband(kRates[0], 1001);
   {
     const int before = pysdr::g_mfma_launches;

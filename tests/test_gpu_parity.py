@@ -289,14 +289,16 @@ def test_batch_equals_chunked_bit_exact(grid, monkeypatch):
 
 
 @pytest.mark.parametrize("grid", [0, 3])
-@pytest.mark.parametrize("fs,ntaps", [(2.048e6, 1001), (1.024e6, 255), (1.024e6, 1001), (2.56e6, 1001)])
+@pytest.mark.parametrize("fs,ntaps", [(2.048e6, 1001), (1.024e6, 255), (1.024e6, 1001), (2.56e6, 1001),
+                                      (1.536e6, 1001), (1.792e6, 1001), (1.92e6, 1001)])
 def test_long_prototype_does_not_depend_on_the_cut(fs, ntaps, grid, monkeypatch):
     """One sub-receiver at 2.048 MS/s with the reference's default 1001-tap prototype runs the mix + decimate
     on the matrix cores (mixdec_mfma.hip: rows = windows of the input, columns = the outputs a window feeds).
     An output's row and column follow from its ABSOLUTE index and its window is summed in a fixed order, so the
     baseband IQ is the same bit for bit whether the stream arrives chunk by chunk, in one batch, or cut at random
     places -- odd ones included, which flips the parity of the LDS image (every output lands in another tile,
-    wave and row).  1.024 and 2.56 MS/s with 1001 taps: the other two matrix-core shapes (3/64, 3/160).
+    wave and row).  1.024, 2.56, 1.792, 1.536 and 1.92 MS/s with 1001 taps: the other matrix-core shapes (3/64, 3/160, 3/112, and 1/32, 1/40
+    whose one-branch 1001 taps need the 12-wave form).
     1.024 MS/s / 255 taps: the same on the vector form (DOWN % 32 == 0, rows on shared banks).
     grid = 3: the launches are held to three workgroups (PYSDR_MIXDEC_GRID under PYSDR_TUNING=1), so every workgroup
     walks MANY tiles even in these short calls -- the persistent loop's images in flight, the operand ring carried from
