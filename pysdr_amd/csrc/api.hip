@@ -161,8 +161,11 @@ struct pysdr_ctx {
   //   exact warm-ups 1.70 | 3 coarse sweeps + 6 / 5 / 4 tau exact 1.56 / 1.57 / 1.54 | 4 sweeps 1.61 | 2 sweeps: every join
   //   misses (180 ms of serial patching) | 3 sweeps + 3 tau exact: 115 joins miss | fast warm-up 11 / 9 tau: the check pass
   //   redoes the call (1.85 / 2.4) | 4096 / 3072 / 1024 segments with exact warm-ups 1.96 / 1.78 / 1.71 (2048: 1.70)
+  // round 4, after the sweeps went from 35 to 22 vector instructions (stage2.hip wfm_pll_walk; scripts/diag/c4_kt.sh, us per
+  // segment-kernel launch, same box): 1024 / 1280 / 1536 / 1792 / 2048 segments 388 / 365 / 349-351 / 379 / 370 -- the walk
+  // is now as much the latency of one segment's chain as the SIMDs' issue rate, and fewer, longer segments walk less warm-up
   double wfm_taus = 20.0, wfm_taus_fast = 13.0, wfm_taus_exact = 5.0;
-  int wfm_coarse_sweeps = 3, wfm_kmax = 2048, wfm_tmin = 2048;
+  int wfm_coarse_sweeps = 3, wfm_kmax = 1536, wfm_tmin = 2048;
   int wfm_exact_cap = 5;               // sweeps per block of the pilot loop's exact walks (0: to the bit-stable fixed point)
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)

@@ -489,7 +489,15 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
           int r = 0, c2 = ch;
           while (c2 >= cpr) { c2 -= cpr; ++r; }
           const int j = c2 * 64 + lane;
+#ifdef MD_Y_PLAIN                     // A/B: plain stores
           if (j < n_st) a.y[r][i_base + j] = ys[r * a.ycap + j];
+#else
+          if (j < n_st) {
+            typedef float md_f2 __attribute__((ext_vector_type(2)));
+            const float2 v = ys[r * a.ycap + j];
+            __builtin_nontemporal_store((md_f2){v.x, v.y}, (md_f2*)(a.y[r] + i_base + j));
+          }
+#endif
         }
       i_base = cur.i_first + cur.tile_n;
     }

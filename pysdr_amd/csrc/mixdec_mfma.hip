@@ -356,14 +356,36 @@ __device__ __forceinline__ void mm_epi(const MixMfmaArgs& a, unsigned part0, int
       hold[j] = make_float2(0.f, 0.f);
       if (i0 + j < n) {               // tile i0+j is complete behind the barrier of the trip after it (or the last one)
         mm_barrier_lds_only();
-#ifndef MM_NO_EPI                     // experiment (results WRONG)
+#if defined(MM_EPI_ZERO)              // experiment (results WRONG): the stores alone, no partial sums read
+        have[j] = etid < G::OUT_PER_TILE && a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + etid >= 0 &&
+                  a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + etid < a.n_out;
+#elif !defined(MM_NO_EPI)             // experiment (results WRONG)
         have[j] = mm_epilogue<G>(a, t_begin + i0 + j, part0 + (((i0 + j) & 1) ? (unsigned)G::PART_BYTES : 0u), etid, hold[j]);
 #endif
       }
     }
 #pragma unroll
-    for (int j = 0; j < kFlush; ++j)
-      if (have[j]) a.y[a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + etid] = hold[j];
+    for (int j = 0; j < kFlush; ++j) {
+#if defined(MM_EPI_NO_STORE)          // experiment (results WRONG): everything but the store
+      if (have[j] && hold[j].x == 1.2345e30f)
+#else
+      if (have[j])
+#endif
+#if defined(MM_EPI_PLAIN)            // A/B: plain stores
+        a.y[a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + etid] = hold[j];
+#elif defined(MM_EPI_SC)             // experiment: system-scope write-through stores
+        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(a.y + a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + etid), "v"(hold[j]) : "memory");
+#elif defined(MM_EPI_SAMEPLACE)      // experiment (results WRONG): every tile's outputs go to the workgroup's first slot (stays in the L2)
+        a.y[a.mrel0 + t_begin * G::OUT_PER_TILE + etid] = hold[j];
+#elif defined(MM_EPI_WIDE)           // experiment (results WRONG): the same bytes as 16-byte stores from half the lanes
+        { if (etid < G::OUT_PER_TILE / 2) *(mm_f4*)(a.y + a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + 2 * etid) = (mm_f4){hold[j].x, hold[j].y, hold[j].x, hold[j].y}; }
+#else
+        // nontemporal: these 768-byte pieces are 2.3 % of the kernel's bytes, but as plain stores they cost 4.5 % of its time
+        // (copy pipeline alone: 8 %; scripts/diag/mfma_ablate.sh MM_EPI_*: plain 0.3155-0.3181 ms, nt 0.3027, no store at all
+        // 0.3136; copies only 0.2925 / 0.2695 / 0.2442)
+        __builtin_nontemporal_store((mm_f2){hold[j].x, hold[j].y}, (mm_f2*)(a.y + a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + etid));
+#endif
+    }
   }
 }
 

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512) void psd_rows_kernel(const float2* __restrict_
 // in one dword per complex, LO = the low byte of each in one 16-bit word; same [cb][p][b] index order as the float2 form,
 // so a wave's store / load covers 256 + 128 contiguous bytes.  v_perm_b32 packs and unpacks (6 vector instructions per
 // complex on each side: +16 % on kernels that were never bound by them).
-//   per frame (512 KB of the work buffer): [0, 256 K) HI dwords, [256 K, 384 K) LO shorts, [384 K, +64) the 16 block scales
+//   per frame (512 KB of the work buffer): [0, 256 K) HI dwords, [256 K, 384 K) LO shorts, [384 K, +256) the 16 x 4 block scales
 constexpr int kPkLoOff = 65536 * 4, kPkScaleOff = 65536 * 6;
 
 __device__ __forceinline__ unsigned pk_perm(unsigned s0, unsigned s1, unsigned sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
@@ -321,27 +321,41 @@ __device__ __forceinline__ void cols_unit_pk(const float2* __restrict__ xf, cons
     dft16(v);
     twiddle_pow0(v, expmpi((float)(16 * bb) * (1.0f / 32768.0f)),
                  expmpi((float)(bb * p1) * (1.0f / 32768.0f)));
-    // the block's largest |component|: thread, wave (DPP-free butterflies through shuffles), workgroup
+    // the block's largest |component|: thread, wave (DPP-free butterflies through shuffles), workgroup.
+    // Measured (scripts/diag/psd_variants.sh, PSD alone, ms per 10666 frames): shipped 2.27; a fixed scale (-DPSDX_NO_SCALE,
+    // results wrong) 2.18; a scale per WAVE (-DPSDX_WAVE_SCALE: no barrier, no LDS round trip in front of the stores; parity
+    // green) 2.35-2.41 against 2.35-2.37 on the same box: the barrier is not what the reduction costs.  Without the LO plane
+    // (-DPSDX_NO_LO, results wrong) 2.00, without both 1.85: the pair moves its bytes at ~6 TB/s in every variant.
     float m = 0.f;
+#if defined(PSDX_NO_SCALE)
+    m = 64.f;
+#else
 #pragma unroll
     for (int p0 = 0; p0 < 16; ++p0) m = fmaxf(fmaxf(m, fabsf(v[p0].x)), fabsf(v[p0].y));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+#ifndef PSDX_WAVE_SCALE
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+#endif
+#endif
     // (a block whose largest component is below 1e-20 contributes powers below 1e-36 * 65536: far under the 1e-30 that is
     //  added before the logarithm -- it is stored as zeros, which also keeps 8388600 / m finite for denormal m)
     const bool live = m >= 1.0e-20f;
     const float sc = live ? __fdiv_rn(8388600.0f, m) : 0.0f;
-    if (tid == 0) *(PYSDR_AS1 float*)(wf + kPkScaleOff + 4 * cb) = live ? __fdiv_rn(m, 8388600.0f) * (1.0f / 256.0f) : 0.f;
+    // four scale slots per block, one per wave (the same value four times unless PSDX_WAVE_SCALE)
+    if ((tid & 63) == 0)
+      *(PYSDR_AS1 float*)(wf + kPkScaleOff + 4 * (4 * cb + (tid >> 6))) = live ? __fdiv_rn(m, 8388600.0f) * (1.0f / 256.0f) : 0.f;
     PYSDR_AS1 unsigned* oh = (PYSDR_AS1 unsigned*)wf + (size_t)cb * 4096 + p1 * 16 + b;
     PYSDR_AS1 unsigned short* ol = (PYSDR_AS1 unsigned short*)(wf + kPkLoOff) + (size_t)cb * 4096 + p1 * 16 + b;
 #pragma unroll
     for (int p0 = 0; p0 < 16; ++p0) {
       const unsigned a = (unsigned)__float2int_rn(v[p0].x * sc), c = (unsigned)__float2int_rn(v[p0].y * sc);
       oh[p0 * 256] = pk_perm(c, a, 0x06050201u);                       // [a.b1, a.b2, c.b1, c.b2]
+#ifndef PSDX_NO_LO                    // experiment (results WRONG): the HI plane alone
       ol[p0 * 256] = (unsigned short)pk_perm(c, a, 0x0c0c0400u);       // [a.b0, c.b0]
+#endif
     }
   }
 }
@@ -366,11 +380,15 @@ __device__ __forceinline__ void rows_unit_pk(const char* __restrict__ wf, float*
     const PYSDR_AS1 float* ss = (const PYSDR_AS1 float*)(wf + kPkScaleOff);
     unsigned h[16], l[16];
 #pragma unroll
+#ifdef PSDX_NO_LO
+    for (int c1 = 0; c1 < 16; ++c1) { h[c1] = sh[4096 * c1]; l[c1] = 0u; }
+#else
     for (int c1 = 0; c1 < 16; ++c1) { h[c1] = sh[4096 * c1]; l[c1] = sl[4096 * c1]; }
+#endif
     float2 u[16];
 #pragma unroll
     for (int c1 = 0; c1 < 16; ++c1) {
-      const float inv = ss[c1];                                          // block scale / 256 (wave-uniform)
+      const float inv = ss[4 * c1 + ((tid >> 6) & 3)];                   // block scale / 256 (wave-uniform: the wave's 4 rows p share p % 16 >> 2)
       const int xr = (int)pk_perm(l[c1], h[c1], 0x0100040cu);            // [0, l.b0, h.b0, h.b1] = Re * 256
       const int xi = (int)pk_perm(l[c1], h[c1], 0x0302050cu);            // [0, l.b1, h.b2, h.b3] = Im * 256
       u[c1] = make_float2((float)xr * inv, (float)xi * inv);

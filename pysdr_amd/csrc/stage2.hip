@@ -754,8 +754,12 @@ __device__ __forceinline__ float wave_scan_add(float v) {
   v += PYSDR_DPP_F(0x112, 0xF);
   v += PYSDR_DPP_F(0x114, 0xF);
   v += PYSDR_DPP_F(0x118, 0xF);
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  // the two steps across the rows of 16 add in place: rows outside the mask keep v.  Written through update_dpp, hipcc
+  // cannot fold "v + (row masked off ? 0 : bcast)" into one DPP add (x + 0 is not x for x = -0) and issues v_mov_b32_dpp +
+  // v_add_f32 + a v_mov that zeroes the old value: 6 instructions where these are 2, on the pilot loop's critical chain
+  // (2 wait states between a VALU write and its DPP read)
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
 #undef PYSDR_DPP_F
   return v;
 }
@@ -775,7 +779,7 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
 // 64 dependent steps: given a guess of the 64 phases every lane computes its sample's error signal
 // e = mpx cos(theta) * norm in parallel; the integrator after sample j is w0 + ki * (inclusive scan
 // of e), the correction corr_j = rint((w_j + kp e_j) * 2^32/2pi), and the phase in front of sample j
-// is ph0 + (exclusive scan of fword0 + corr).  Sample 0's phase is exact from the start, so sweep k
+// is ph0 + j fword0 + (exclusive scan of corr).  Sample 0's phase is exact from the start, so sweep k
 // makes at least samples 0..k exact and the iteration ends -- at the serial recursion's own
 // trajectory -- when a sweep reproduces its input phases bit for bit: measured 6.6 sweeps per block on
 // broadcast FM (max 10) against 64 dependent steps of ten instructions each, 37 -> ~10 ns per sample.
@@ -805,22 +809,43 @@ __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restric
     if (nidx < i_end)                                      // in flight during the sweeps below ("+v": see am_pll_lanes_kernel)
       asm volatile("global_load_dword %0, %1, off" : "+v"(m_next) : "v"(&o[nidx].x) : "memory");
     const int count = (i_end - i0 < 64) ? i_end - i0 : 64;
+    // once per block instead of once per sweep: the sample times the detector's normalisation, zero in the dead lanes of
+    // a last partial block (e = (m norm) cos, where the oracle rounds (m cos) norm: one ulp of e, far inside the join tolerance)
+    const float mn = (lane < count) ? __fmul_rn(m, a.norm) : 0.f;
     const uint32_t inc0 = a.fword0 + (uint32_t)__float2int_rn(__fmul_rn(w0, a.rad2word));
     uint32_t ph = ph0 + (uint32_t)lane * inc0;             // guess: free running at the integrator's rate
+    const uint32_t base = ph0 + (uint32_t)lane * a.fword0; // the nominal advance is added once per block, the sweeps scan the corrections only
     uint32_t tot = 0u;
     float wj = w0;
-    for (int it = 0; it < max_it; ++it) {
-      const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+    auto sweep = [&](uint32_t pin) -> uint32_t {
+      const float rev = (float)(int)pin * (1.0f / 4294967296.0f);
       const float c = __builtin_amdgcn_cosf(rev);
-      const float e = (lane < count) ? __fmul_rn(__fmul_rn(m, c), a.norm) : 0.f;
-      wj = __fadd_rn(w0, __fmul_rn(a.ki, wave_scan_add(e)));
-      const int corr = __float2int_rn(__fmul_rn(__fadd_rn(wj, __fmul_rn(a.kp, e)), a.rad2word));
-      const uint32_t step = a.fword0 + (uint32_t)corr;
-      tot = wave_scan_add(step);
-      const uint32_t phn = ph0 + tot - step;
-      const bool same = !__any(phn != ph);
-      ph = phn;
-      if (same) break;
+      const float e = __fmul_rn(mn, c);
+      // (fused multiply-adds: one rounding where the oracle's NumPy has two -- 1 ulp of an integrator that is already
+      //  summed in scan order, see above)
+      wj = __fmaf_rn(a.ki, wave_scan_add(e), w0);
+      const uint32_t corr = (uint32_t)__float2int_rn(__fmul_rn(__fmaf_rn(a.kp, e, wj), a.rad2word));
+      tot = wave_scan_add(corr);
+      return base + tot - corr;
+    };
+    // two sweeps per trip, so that the phases alternate between two registers instead of being copied back every sweep
+    if (max_it <= 8) {
+      // a capped walk runs its sweeps without asking whether the last one changed anything: the bit-stable fixed point
+      // takes 6.6 sweeps on average, so a test per sweep (a compare and six scalar instructions) almost never ends a walk
+      // of 3 or 5 early -- and a sweep from the fixed point reproduces it, so the result is the same either way
+      for (int it = 0;; it += 2) {
+        const uint32_t p1 = sweep(ph);
+        if (it + 1 >= max_it) { ph = p1; break; }
+        ph = sweep(p1);
+        if (it + 2 >= max_it) break;
+      }
+    } else {
+      for (int it = 0;;) {
+        const uint32_t p1 = sweep(ph);
+        if (!__any(p1 != ph) || ++it >= max_it) { ph = p1; break; }
+        ph = sweep(p1);
+        if (!__any(ph != p1) || ++it >= max_it) break;
+      }
     }
     // the next block's samples (issued a block of sweeps ago) and the previous block's store
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(m_next) :: "memory");
@@ -831,7 +856,7 @@ __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restric
       // neighbouring segments are reading it meanwhile -- no location is both read and written here
       reinterpret_cast<float*>(o + i0 + lane)[1] = __fmul_rn(m, __fmul_rn(2.f, s2));
     }
-    ph0 = ph0 + (uint32_t)__builtin_amdgcn_readlane((int)tot, count - 1);
+    ph0 = ph0 + (uint32_t)count * a.fword0 + (uint32_t)__builtin_amdgcn_readlane((int)tot, count - 1);
     w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wj), count - 1));
   }
 }

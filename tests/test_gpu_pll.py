@@ -199,7 +199,7 @@ def test_am_synch_one_lane_per_segment_equals_one_wave_per_segment(monkeypatch):
 def test_full_size_c4_time_parallel_equals_the_serial_walk():
     """BASELINE config #4 at the size and in the way bench.py times it: 2048 chunks x 213333 samples
     (3.5 GB) resident in HBM, three consecutive calls of ONE continuous broadcast-FM stream (call k
-    reads the 1.7 M-sample loop from offset k * nsamp mod 1.7 M), ~2032 pilot-PLL segments per call,
+    reads the 1.7 M-sample loop from offset k * nsamp mod 1.7 M), ~1524 pilot-PLL segments per call,
     the 13-tau warm-up from the previous call's mean phase increment from the second call on.  The
     reference for every sample is the SAME build with the loop forced to its serial walk
     (pysdr_set_pll_segments(ctx, 1): one wave, sample by sample) on a second context; the first two
@@ -228,7 +228,7 @@ def test_full_size_c4_time_parallel_equals_the_serial_walk():
             b, _, cnb, pkb = cb.fetch(0, B, want_iq=False)
             seg, pat = pll_stats(ca)
             assert pll_stats(cb) == (1, 0)
-            assert seg >= 1900 and pat <= 2, (k, seg, pat)
+            assert seg >= 1400 and pat <= 2, (k, seg, pat)
             assert np.array_equal(cna, cnb) and int(cna.sum()) == len(a) == len(b)
             assert np.array_equal(pka, pkb)
             assert relerr(a, b) <= TOL, (k, relerr(a, b))
