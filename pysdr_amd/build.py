@@ -23,7 +23,7 @@ EXTRA_FLAGS = {"mixdec.hip": os.environ.get("PYSDR_MIXDEC_FLAGS", "").split(),
                "api.hip": os.environ.get("PYSDR_API_FLAGS", "").split(),   # a shape's S / NB enter the host's plan: pass the same -D to both   # experiments: -DMM_NO_PK, -DMM_PROD_PRIO=n
                # packed-f32 pairs built by the SLP vectoriser run at half rate on gfx950 and are fed by
                # v_mov shuffles: the AF FIR is written for plain FMAs
-               "stage2.hip": ["-fno-slp-vectorize"],
+               "stage2.hip": ["-fno-slp-vectorize"] + os.environ.get("PYSDR_STAGE2_FLAGS", "").split(),
                # FFT butterflies are adds: v_pk_add_f32 issues at 5.6 cycles against 2 x 3.1 for two plain adds and
                # hipcc pays for the pairing with v_mov shuffles and 17 more registers (A/B: PYSDR_PSD_FLAGS)
                # measured on C3, PSD ms per 10666 frames: default 2.752 / 2.774, -fno-slp-vectorize 2.731 / 2.731,

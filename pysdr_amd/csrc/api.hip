@@ -1110,11 +1110,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     if (rc) return rc;
   }
   rc = launch_demod_fir(s, c->stream); if (rc) return rc;
-  rc = launch_agc_scan(s, c->stream); if (rc) return rc;
-  // WFM (mono) emits the real part of the complex pipeline
-  for (int r = 0; r < nrx; ++r) if (snap.rx[r].mode == PYSDR_WFM) s.out_complex[r] = 0;
-  rc = launch_apply(s, c->stream); if (rc) return rc;
-
+  // the gains, and beside them (same launch) the history roll of the FS_OUT-rate buffers: the AF FIR was their last reader
   EpilogueArgs e;
   memset(&e, 0, sizeof(e));
   e.nrx = nrx; e.n_out = n_out; e.hy = c->hy;
@@ -1122,7 +1118,10 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     e.ybase[r] = snap.rx[r].d_y;
     e.ypllbase[r] = (s.det[r] == kDetPll) ? snap.rx[r].d_ypll : nullptr;
   }
-  rc = launch_epilogue(e, c->stream); if (rc) return rc;
+  rc = launch_agc_scan(s, e, c->stream); if (rc) return rc;
+  // WFM (mono) emits the real part of the complex pipeline
+  for (int r = 0; r < nrx; ++r) if (snap.rx[r].mode == PYSDR_WFM) s.out_complex[r] = 0;
+  rc = launch_apply(s, c->stream); if (rc) return rc;
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[3], c->stream));
   c->ncalls++;
 

@@ -210,7 +210,6 @@ struct Stage2Args {
 };
 int launch_pll(const Stage2Args& a, hipStream_t st);
 int launch_demod_fir(const Stage2Args& a, hipStream_t st);
-int launch_agc_scan(const Stage2Args& a, hipStream_t st);
 int launch_apply(const Stage2Args& a, hipStream_t st);
 
 struct EpilogueArgs {
@@ -218,7 +217,8 @@ struct EpilogueArgs {
   float2* ybase[PYSDR_MAX_RX];        // buffer start (prefix at [0,hy))
   float2* ypllbase[PYSDR_MAX_RX];     // may be null
 };
-int launch_epilogue(const EpilogueArgs& a, hipStream_t st);
+// block gains (one workgroup per RX) + the history roll of the FS_OUT-rate buffers (two workgroups per RX), one launch
+int launch_agc_scan(const Stage2Args& a, const EpilogueArgs& e, hipStream_t st);
 // new history = last hist_len samples of [old history | x[0..n)]
 // (+ zeroes `zero[0 .. zero_n)`: the raw-peak buffer of the next call)
 int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len,

@@ -525,10 +525,25 @@ __device__ __forceinline__ float agc_env_step(float env, float peak) {
   return (peak > env) ? peak : dec;
 }
 
-__global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
+// Workgroups nrx .. 3 nrx - 1 of the same launch roll the histories of the FS_OUT-rate buffers (prefix <- last hy outputs,
+// through LDS so that overlapping source / destination ranges are safe): nothing behind the AF FIR reads those buffers
+// again in this call, and as a launch of its own (round 1-3) this copy of a few KB cost 4.2 us of stream time behind the
+// gains instead of running beside them.
+__global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const EpilogueArgs eh) {
   extern __shared__ __attribute__((aligned(16))) float agc_lds[];
-  const int r = blockIdx.x;
   const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.nrx) {
+    const int job = blockIdx.x - a.nrx;
+    float2* base = (job < eh.nrx) ? eh.ybase[job] : eh.ypllbase[job - eh.nrx];
+    if (base == nullptr) return;
+    float2* sh = reinterpret_cast<float2*>(agc_lds);
+    // element j of the new prefix = old element n_out + j  (prefix occupies [0,hy))
+    for (int j = tid; j < eh.hy; j += 256) sh[j] = base[eh.n_out + j];
+    __syncthreads();
+    for (int j = tid; j < eh.hy; j += 256) base[j] = sh[j];
+    return;
+  }
+  const int r = blockIdx.x;
   // broadcast FM has no AGC blocks: the whole call is block 0 (walking 2047 empty blocks after it
   // let the envelope decay through hundreds of segment joins that never meet: 140 us)
   const int nch = a.single_block[r] ? (a.nchunks > 0 ? 1 : 0) : a.nchunks;
@@ -541,16 +556,22 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
   float* ev = agc_lds + nlds;          // [px(nchunks)] envelopes
   float* sS = ev + nlds;               // [256] start state each segment used, [256] end state it reached
   float* sE = sS + 256;
-  // eight loads in flight per thread (a rolled loop waits for each 256-byte-strided load in turn)
-  for (int c0 = 0; c0 < nch; c0 += 8 * 256) {
-    unsigned v[8];
+  // sixteen loads in flight per thread (a rolled loop waits for each 256-byte-strided load in turn; these lines were last
+  // touched by the AF FIR's atomics and come from the memory side: a round of loads is ~4 us whatever its size -- 4096
+  // blocks in two rounds of eight per thread took 8 of this kernel's 20 us, scripts/diag/agc_ablate.sh)
+  for (int c0 = 0; c0 < nch; c0 += 16 * 256) {
+    unsigned v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int c = c0 + u * 256 + tid;
+#ifdef AGCX_NO_LOAD                   // experiment (results WRONG)
+      v[u] = (c < nch) ? 0x3f000000u + c : 0u;
+#else
       v[u] = (c < nch) ? a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] : 0u;
+#endif
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int c = c0 + u * 256 + tid;
       if (c < nch) pk[px(c)] = __uint_as_float(v[u]);
     }
@@ -565,7 +586,11 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
   constexpr int kWarm = 176;             // 0.9^176 = 9e-9 < 2^-24: a decaying start value is gone from a float
   const int T = (nch + 255) / 256 < 16 ? 16 : (nch + 255) / 256;
   const int K = (nch + T - 1) / T;
+#ifdef AGCX_NO_CHAIN                  // experiment (results WRONG)
+  if (tid < K && a.n_out < 0) {
+#else
   if (tid < K) {
+#endif
     const int s0 = tid * T, s1 = (s0 + T < nch) ? s0 + T : nch;
     int wb = s0 - kWarm;
     float env = 0.f;
@@ -613,32 +638,68 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a) {
     const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(pk[px(c)], 1e-12f)), 1.0e4f) : 1.f;
     a.gain[(size_t)r * a.nchunks + c] = g;
     // the raw block peaks are consumed: leave them zeroed for the next call
+#ifndef AGCX_NO_ZERO                  // experiment (results WRONG from the second call on)
     a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] = 0u;
+#endif
   }
+  const float env_last = nch > 0 ? pk[px(nch - 1)] : 0.f;       // (the squelch section reuses pk[])
   if (a.sq_thresh[r] > 0.f) {
+    // One-pole smoothing of the block noise, lvl += 0.64 (noise - lvl) over the blocks that hold samples, and the gate
+    // (gain 0 = squelched).  The recursion forgets its start by 0.36 per block -- 0.36^17 < 2^-24 -- so it runs like the
+    // envelope above: segments of T blocks, each warmed up over the kSqWarm blocks in front of it from lvl = 0, all joins
+    // compared bit for bit and only a miss (a run of empty blocks in a warm-up) sends lane 0 on the serial walk.  (One lane
+    // walking all blocks: 2048 x three dependent operations ~ 13 us if nothing overlapped it; measured, the kernel went from
+    // 14.5 to 15.0 us on the NBFM configuration -- its time is the strided loads at the top, scripts/diag/agc_ablate.sh.)
+    constexpr int kSqWarm = 32;
+    __syncthreads();                                 // pk[] (envelopes) has been consumed by the gains above
+    float* nz = ev;                                  // [px(nch)] block noise, < 0: a block without samples
+    float* lv = pk;                                  // [px(nch)] smoothed level behind each block
+    for (int c = tid; c < nch; c += 256) {
+      const size_t k = ((size_t)r * a.nchunks + c) * kBlkStride;
+      const unsigned n = a.blkcnt[k];
+      nz[px(c)] = n > 0u ? __fdiv_rn(a.blknoise[k], (float)n) : -1.f;
+      a.blknoise[k] = 0.f;
+      a.blkcnt[k] = 0u;
+    }
     __syncthreads();
-    if (tid == 0) {
-      // serial one-pole smoothing of the block noise, gate the gain (0 = squelched)
-      float lvl = st.sq_level;
-      int open = st.sq_open;
-      for (int c = 0; c < nch; ++c) {
-        const size_t k = (size_t)r * a.nchunks + c;
-        const unsigned n = a.blkcnt[k * kBlkStride];
-        if (n > 0u) {
-          const float noise = __fdiv_rn(a.blknoise[k * kBlkStride], (float)n);
-          lvl = __fadd_rn(lvl, __fmul_rn(0.64f, __fsub_rn(noise, lvl)));
-          open = (lvl <= a.sq_thresh[r]) ? 1 : 0;
-          if (!open) a.gain[k] = 0.f;
-        }
-        a.blknoise[k * kBlkStride] = 0.f;
-        a.blkcnt[k * kBlkStride] = 0u;
+    auto sq_step = [](float lvl, float noise) { return __fadd_rn(lvl, __fmul_rn(0.64f, __fsub_rn(noise, lvl))); };
+    if (tid < K) {
+      const int s0 = tid * T, s1 = (s0 + T < nch) ? s0 + T : nch;
+      int wb = s0 - kSqWarm;
+      float lvl = 0.f;
+      if (tid == 0 || wb <= 0) { wb = 0; lvl = st.sq_level; }
+      for (int c = wb; c < s0; ++c) { const float v = nz[px(c)]; if (v >= 0.f) lvl = sq_step(lvl, v); }
+      sS[tid] = lvl;
+      for (int c = s0; c < s1; ++c) { const float v = nz[px(c)]; if (v >= 0.f) lvl = sq_step(lvl, v); lv[px(c)] = lvl; }
+      sE[tid] = lvl;
+    }
+    __syncthreads();
+    const bool sq_miss = tid > 0 && tid < K && __float_as_uint(sE[tid - 1]) != __float_as_uint(sS[tid]);
+    if (__syncthreads_or(sq_miss) && tid == 0) {
+      for (int k = 1; k < K; ++k) {
+        if (__float_as_uint(sE[k - 1]) == __float_as_uint(sS[k])) continue;
+        float lvl = sE[k - 1];
+        const int s0 = k * T, s1 = (s0 + T < nch) ? s0 + T : nch;
+        for (int c = s0; c < s1; ++c) { const float v = nz[px(c)]; if (v >= 0.f) lvl = sq_step(lvl, v); lv[px(c)] = lvl; }
+        sE[k] = lvl;
+        sS[k] = sE[k - 1];
       }
-      a.state[r].sq_level = lvl;
+    }
+    __syncthreads();
+    for (int c = tid; c < nch; c += 256)
+      if (nz[px(c)] >= 0.f && !(lv[px(c)] <= a.sq_thresh[r])) a.gain[(size_t)r * a.nchunks + c] = 0.f;
+    if (tid == 0 && nch > 0) {
+      // the gate follows the last block that held samples
+      int open = st.sq_open;
+      for (int c = nch - 1; c >= 0; --c)
+        if (nz[px(c)] >= 0.f) { open = (lv[px(c)] <= a.sq_thresh[r]) ? 1 : 0; break; }
+      a.state[r].sq_level = lv[px(nch - 1)];
       a.state[r].sq_open = open;
     }
+    __syncthreads();                                 // pk[] no longer holds envelopes: the block below reads its copy
   }
   if (tid == 0 && nch > 0) {
-    const float env = pk[px(nch - 1)];
+    const float env = env_last;
     const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(env, 1e-12f)), 1.0e4f) : 1.f;
     // field-wise: the squelch block above owns sq_level / sq_open
     a.state[r].env = env;
@@ -698,20 +759,6 @@ __global__ __launch_bounds__(256) void apply_kernel(const Stage2Args a) {
     else reinterpret_cast<float2*>(a.am[r])[i + j] =
         a.matrix[r] ? make_float2((v.x + v.y) * g[j], (v.x - v.y) * g[j]) : make_float2(v.x * g[j], v.y * g[j]);
   }
-}
-
-// ---- history roll of the FS_OUT-rate buffers: prefix <- last hy outputs.  One workgroup
-// per buffer so overlapping source/destination ranges are safe.
-__global__ __launch_bounds__(256) void epilogue_kernel(const EpilogueArgs a) {
-  const int job = blockIdx.x;
-  const int tid = threadIdx.x;
-  float2* base = (job < a.nrx) ? a.ybase[job] : a.ypllbase[job - a.nrx];
-  if (base == nullptr) return;
-  // element j of the new prefix = old element n_out + j  (prefix occupies [0,hy))
-  __shared__ float2 sh[4096];
-  for (int j = tid; j < a.hy; j += 256) sh[j] = base[a.n_out + j];
-  __syncthreads();
-  for (int j = tid; j < a.hy; j += 256) base[j] = sh[j];
 }
 
 // ---- raw-sample history of a decimator: new = last hist_len samples of [old | x]
@@ -1055,9 +1102,14 @@ int launch_demod_fir(const Stage2Args& a, hipStream_t st) {
   return PYSDR_OK;
 }
 
-int launch_agc_scan(const Stage2Args& a, hipStream_t st) {
+int launch_agc_scan(const Stage2Args& a, const EpilogueArgs& e, hipStream_t st) {
+  if (e.hy > 4096) {
+    set_last_error("epilogue: history %d too long", e.hy);
+    return PYSDR_ERR_ARG;
+  }
   const size_t nlds = (size_t)a.nchunks + (a.nchunks >> 4) + 1;      // padded: one word per 16 blocks (agc_scan_kernel: px)
-  hipLaunchKernelGGL(agc_scan_kernel, dim3(a.nrx), dim3(256), (2 * nlds + 512) * sizeof(float), st, a);
+  const size_t lds = std::max((2 * nlds + 512) * sizeof(float), (size_t)e.hy * sizeof(float2));
+  hipLaunchKernelGGL(agc_scan_kernel, dim3(a.nrx + 2 * e.nrx), dim3(256), lds, st, a, e);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }
@@ -1066,16 +1118,6 @@ int launch_apply(const Stage2Args& a, hipStream_t st) {
   if (a.n_out <= 0) return PYSDR_OK;
   dim3 grid((a.n_out + 1023) / 1024, a.nrx);
   hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, st, a);
-  PYSDR_HIP_CHECK(hipGetLastError());
-  return PYSDR_OK;
-}
-
-int launch_epilogue(const EpilogueArgs& a, hipStream_t st) {
-  if (a.hy > 4096) {
-    set_last_error("epilogue: history %d too long", a.hy);
-    return PYSDR_ERR_ARG;
-  }
-  hipLaunchKernelGGL(epilogue_kernel, dim3(2 * a.nrx), dim3(256), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }

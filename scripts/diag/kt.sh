@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for w in "$@"; do
   O=gpurun_out/r04_kt/$w
   rm -rf $O && mkdir -p $O
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 bench.py --workload $w --no-cpu-baseline --no-host-fed --steps 10 --warmup 3 > $O/bench.json 2> $O/err.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 bench.py --workload $w --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 10 --warmup 3 > $O/bench.json 2> $O/err.txt
   python3 - "$O" <<'PY'
 import csv, glob, sys
 for f in glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True):

@@ -281,13 +281,14 @@ int launch_demod_fir(const Stage2Args& a, hipStream_t) {
   return PYSDR_OK;
 }
 
-int launch_agc_scan(const Stage2Args& a, hipStream_t) {
+static int stub_epilogue(const EpilogueArgs& a);
+int launch_agc_scan(const Stage2Args& a, const EpilogueArgs& e, hipStream_t) {
   for (int r = 0; r < a.nrx; ++r) {
     for (int k = 0; k < a.nchunks; ++k) g_sink = (float)a.blkpeak[((size_t)r * a.nchunks + k) * kBlkStride];
     write_all(a.gain + (size_t)r * a.nchunks, (size_t)a.nchunks);
   }
   read_all(a.state, (size_t)a.nrx);
-  return PYSDR_OK;
+  return stub_epilogue(e);
 }
 
 int launch_apply(const Stage2Args& a, hipStream_t) {
@@ -298,7 +299,7 @@ int launch_apply(const Stage2Args& a, hipStream_t) {
   return PYSDR_OK;
 }
 
-int launch_epilogue(const EpilogueArgs& a, hipStream_t) {
+static int stub_epilogue(const EpilogueArgs& a) {
   SAN_CHECK(a.hy <= 4096, "hy %d", a.hy);
   for (int r = 0; r < a.nrx; ++r)
     for (float2* base : {a.ybase[r], a.ypllbase[r]})
