@@ -648,8 +648,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
     // (gain 0 = squelched).  The recursion forgets its start by 0.36 per block -- 0.36^17 < 2^-24 -- so it runs like the
     // envelope above: segments of T blocks, each warmed up over the kSqWarm blocks in front of it from lvl = 0, all joins
     // compared bit for bit and only a miss (a run of empty blocks in a warm-up) sends lane 0 on the serial walk.  (One lane
-    // walking all blocks: 2048 x three dependent operations ~ 13 us if nothing overlapped it; measured, the kernel went from
-    // 14.5 to 15.0 us on the NBFM configuration -- its time is the strided loads at the top, scripts/diag/agc_ablate.sh.)
+    // walking all blocks was 2048 x three dependent operations ~ 13 us per call with the squelch armed; bench.py does not arm it.)
     constexpr int kSqWarm = 32;
     __syncthreads();                                 // pk[] (envelopes) has been consumed by the gains above
     float* nz = ev;                                  // [px(nch)] block noise, < 0: a block without samples
