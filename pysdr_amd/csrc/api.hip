@@ -46,6 +46,7 @@ PllPlan plan_pll(int n, double fs, double bw_hz, double taus, double taus_fast, 
   p.W = ((int)std::ceil(taus * tau) + 63) & ~63;
   p.Wfast = taus_fast > 0 ? (((int)std::ceil(taus_fast * tau) + 63) & ~63) : 0;
   p.Wexact = 0;
+  p.Wc_hi = p.Wc_mid = 0;
   p.coarse_sweeps = 0;
   p.exact_cap = 0;
   if (n < 3 * p.W || k_max <= 1) {
@@ -166,6 +167,7 @@ struct pysdr_ctx {
   // is now as much the latency of one segment's chain as the SIMDs' issue rate, and fewer, longer segments walk less warm-up
   double wfm_taus = 20.0, wfm_taus_fast = 13.0, wfm_taus_exact = 5.0;
   int wfm_coarse_sweeps = 3, wfm_kmax = 1536, wfm_tmin = 2048;
+  double wfm_taus_hi = 0.0, wfm_taus_mid = 0.0;   // staged coarse warm-up (PllPlan::Wc_hi / Wc_mid) in time constants; 0, 0: one stage
   int wfm_exact_cap = 5;               // sweeps per block of the pilot loop's exact walks (0: to the bit-stable fixed point)
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
@@ -631,7 +633,9 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
     if (e && *e) {
       double a = c->wfm_taus, b = c->wfm_taus_fast, x = c->wfm_taus_exact;
       int sw = c->wfm_coarse_sweeps, km = c->wfm_kmax, tm = c->wfm_tmin, xc = c->wfm_exact_cap;
-      const int got = sscanf(e, "%lf,%lf,%lf,%d,%d,%d,%d", &a, &b, &x, &sw, &km, &tm, &xc);
+      double th = c->wfm_taus_hi, tmid = c->wfm_taus_mid;
+      const int got = sscanf(e, "%lf,%lf,%lf,%d,%d,%d,%d,%lf,%lf", &a, &b, &x, &sw, &km, &tm, &xc, &th, &tmid);
+      if (got >= 9 && th >= 0 && tmid >= 0) { c->wfm_taus_hi = th; c->wfm_taus_mid = tmid; }
       if (got >= 7 && xc >= 0) c->wfm_exact_cap = xc;
       if (got >= 1 && a > 0) c->wfm_taus = a;
       if (got >= 2 && b >= 0) c->wfm_taus_fast = b;
@@ -1044,6 +1048,10 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
       const double tau = fs1 / (kPllZetaPlan * 2.0 * M_PI * kWfmPllBwHz);
       w.pll.Wexact = ((int)std::ceil(c->wfm_taus_exact * tau) + 63) & ~63;
       w.pll.coarse_sweeps = c->wfm_coarse_sweeps;
+      if (c->wfm_taus_hi > 0 || c->wfm_taus_mid > 0) {
+        w.pll.Wc_hi = ((int)std::ceil(c->wfm_taus_hi * tau) + 63) & ~63;
+        w.pll.Wc_mid = ((int)std::ceil(c->wfm_taus_mid * tau) + 63) & ~63;
+      }
     }
     rc = launch_wfm(w, c->stream);
     if (rc) return rc;

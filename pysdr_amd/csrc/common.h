@@ -176,6 +176,8 @@ struct PllPlan {
   int Wexact;               // the last Wexact samples of a warm-up run to the bit-exact fixed point like the segment itself;
                             // what lies in front of them gets `coarse_sweeps` sweeps per block (0: the whole warm-up is exact)
   int coarse_sweeps;
+  int Wc_hi, Wc_mid;        // staged coarse part (0, 0: all of it at coarse_sweeps): the Wc_hi samples in front of the exact tail get
+                            // coarse_sweeps, the Wc_mid samples in front of those coarse_sweeps - 1, whatever lies before coarse_sweeps - 2 (>= 1)
   int exact_cap;            // sweeps per block of the "exact" walks (pilot loop; 0: until a sweep reproduces its input bit for bit)
   uint32_t* seg;            // [nrx][K][4]: S.phase, S.w, E.phase, E.w (float fields as bits)
 };

@@ -948,7 +948,20 @@ __global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
   if (wb < s0) {
     // coarse sweeps first, the last Wexact samples exactly (both bounds on multiples of 64)
     const int sx = (pl.coarse_sweeps > 0 && s0 - pl.Wexact > wb) ? s0 - pl.Wexact : wb;
-    if (wb < sx) wfm_pll_walk<false>(a, a.w[r], wb, sx, ph, w, lane, pl.coarse_sweeps);
+    if (wb < sx) {
+      // staged: the start error of a warm-up (0.03 rad from the mean-increment guess) is far above what few sweeps leave
+      // behind per block (~1.5e-3 rad after one, 1e-4 after two, 6e-6 after three) until it has decayed to that level
+      if (pl.Wc_hi > 0 || pl.Wc_mid > 0) {
+        const int s_hi = (sx - pl.Wc_hi > wb) ? sx - pl.Wc_hi : wb;
+        const int s_mid = (s_hi - pl.Wc_mid > wb) ? s_hi - pl.Wc_mid : wb;
+        const int sw_mid = pl.coarse_sweeps > 1 ? pl.coarse_sweeps - 1 : 1, sw_lo = pl.coarse_sweeps > 2 ? pl.coarse_sweeps - 2 : 1;
+        if (wb < s_mid) wfm_pll_walk<false>(a, a.w[r], wb, s_mid, ph, w, lane, sw_lo);
+        if (s_mid < s_hi) wfm_pll_walk<false>(a, a.w[r], s_mid, s_hi, ph, w, lane, sw_mid);
+        if (s_hi < sx) wfm_pll_walk<false>(a, a.w[r], s_hi, sx, ph, w, lane, pl.coarse_sweeps);
+      } else {
+        wfm_pll_walk<false>(a, a.w[r], wb, sx, ph, w, lane, pl.coarse_sweeps);
+      }
+    }
     wfm_pll_walk<false>(a, a.w[r], sx, s0, ph, w, lane, xcap);
   }
   uint32_t* sg = pl.seg + ((size_t)r * pl.K + k) * 4;
