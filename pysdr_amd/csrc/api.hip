@@ -153,6 +153,7 @@ struct pysdr_ctx {
   int tile_bytes = 0, threads = 1024;  // per LDS buffer (two per workgroup); 0 = as large as fits
   int wgs_per_cu = 1, num_cus = 256;
   int grid_override = 0;               // PYSDR_MIXDEC_GRID: workgroups of the mix+decimate launches (tests: many tiles per workgroup in a small call)
+  int resamp_plain = 0;                // PYSDR_RESAMP_PLAIN=1: the audio resampler of broadcast FM one output per thread (resamp_small_kernel) instead of branch-major (A/B)
   int mfma_enable = 1;                 // long single-RX prototypes on the matrix cores (mixdec_mfma.hip); 0: VALU form (A/B)
   int dbg_flags = 0, yflush_cap = 0;      // tuning / diagnostic switches, read from the environment once
   int am_pll_waves = -1;                  // PYSDR_AM_PLL_WAVES=1 / 0: force the wave- / lane-per-segment carrier loop (A/B runs); -1 = by size
@@ -439,7 +440,7 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   // one RX, no raw peak wanted, short prototype and a small DOWN/UP (the fs1 -> FS_OUT stage of broadcast FM): one thread
   // per output (resamp_small.hip).  Decided by the decimator's shape and its call site only, never by the call.
   const bool small = (nrx == 1 && !peak && resamp_small_span(up, down, d.kpad) > 0);
-  int rc = small ? launch_resamp_small(a, c->stream)
+  int rc = small ? launch_resamp_small(a, c->grid_override, c->resamp_plain, c->stream)
                  : launch_mixdec(a, c->threads, c->grid_override > 0 ? c->grid_override : c->num_cus * wgs, c->stream);
   if (rc) return rc;
   rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n,
@@ -628,6 +629,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   { const char* e = tuning_env("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0) c->yflush_cap = atoi(e); }
   { const char* e = tuning_env("PYSDR_AM_PLL_WAVES"); if (e && *e) c->am_pll_waves = atoi(e) > 0 ? 1 : 0; }
   { const char* e = tuning_env("PYSDR_MIXDEC_MFMA"); if (e && *e) c->mfma_enable = atoi(e) ? 1 : 0; }
+  { const char* e = tuning_env("PYSDR_RESAMP_PLAIN"); if (e && *e) c->resamp_plain = atoi(e) ? 1 : 0; }
   { const char* e = tuning_env("PYSDR_MIXDEC_GRID"); if (e && atoi(e) > 0) c->grid_override = atoi(e); }
   { const char* e = tuning_env("PYSDR_WFM_PLL");
     if (e && *e) {

@@ -107,7 +107,7 @@ int resamp_small_span(int up, int down, int kpad) {
   return (int)span;
 }
 int g_small_launches = 0;
-int launch_resamp_small(const MixDecArgs& a, hipStream_t) {
+int launch_resamp_small(const MixDecArgs& a, int, int, hipStream_t) {
   ++g_small_launches;
   const int span = resamp_small_span(a.up, a.down, a.kpad);
   SAN_CHECK(span > 0 && a.nrx == 1, "shape");

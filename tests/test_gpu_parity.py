@@ -557,6 +557,42 @@ def test_convolver_streaming_fir_matches_scipy():
     assert np.max(np.abs(cz - signal.lfilter(h, [1.0], z.astype(np.complex128)))) <= TOL * np.max(np.abs(want))
 
 
+def test_wbfm_audio_resampler_forms_agree_bit_for_bit(monkeypatch):
+    """The fs1 -> FS_OUT stage of broadcast FM (24/125, 64 taps per branch) runs branch-major (resamp_branch_kernel: a
+    half-wave per polyphase branch, the next tile's input in registers while this one is summed) -- and, under
+    PYSDR_TUNING=1 PYSDR_RESAMP_PLAIN=1, one output per thread (resamp_small_kernel).  Both sum an output's taps in the
+    same order: the audio of a 12-chunk batch is identical bit for bit, also with the launches held to three workgroups
+    (PYSDR_MIXDEC_GRID: every workgroup then walks several tiles, the register prefetch included)."""
+    from oracle import wfm_oracle as wo
+    from pysdr_amd import sig_proc
+    from pysdr_amd.params import RunTimeParams
+    fs, L, B = 10e6, 213333, 12
+    x = wo.synth_wfm(fs, B * L, 4)
+    out = {}
+    for name, env in (("branch", {}), ("plain", {"PYSDR_RESAMP_PLAIN": "1"}), ("branch3", {"PYSDR_MIXDEC_GRID": "3"}),
+                      ("plain3", {"PYSDR_RESAMP_PLAIN": "1", "PYSDR_MIXDEC_GRID": "3"})):
+        for k in ("PYSDR_RESAMP_PLAIN", "PYSDR_MIXDEC_GRID"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("PYSDR_TUNING", "1")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        P = RunTimeParams(fs=fs, fc=[98.1e6], mode='WFM2', nfilt=255, foffset=300e3, vid_bw=200e3, max_batch_chunks=B)
+        g = sig_proc.Receiver(P, 300e3, 0, '1')
+        ctx = P._pysdr_stream
+        ctx.process_batch(x, B, L)
+        a, _, cn, _ = ctx.fetch(0, B, want_iq=False)
+        out[name] = (a.copy(), cn.copy())
+        ctx.close()
+    ref = out["branch"]
+    assert len(ref[0]) == int(ref[1].sum()) and len(ref[0]) > 12000
+    for name in ("plain", "branch3", "plain3"):
+        assert np.array_equal(out[name][1], ref[1]), name
+        assert np.array_equal(out[name][0].view(np.uint32), ref[0].view(np.uint32)), name
+    o = wo.WfmReceiver(fs, 48e3, 300e3, stereo=True, ntaps_dec=255, dtype=np.float32)
+    want = np.concatenate([o.demod_data(x[k * L:(k + 1) * L]) for k in range(3)])
+    assert relerr(ref[0][:len(want)], want) <= TOL
+
+
 @pytest.mark.parametrize("stereo,grid", [(True, 0), (False, 0), (True, 2)])
 def test_c4_wbfm_10msps(stereo, grid, monkeypatch):
     """config #4: WBFM path, 10 MS/s IQ, 1 RX, pilot-PLL stereo demod + 75 us de-emphasis.  grid = 2: the mix + decimate
