@@ -984,12 +984,24 @@ __global__ __launch_bounds__(64) void wfm_pll_check_kernel(const WfmArgs a) {
   if (pl.Wfast > 0 && st->wfm_slope_ok && pl.K > 1) {
     const uint32_t* sg = pl.seg + (size_t)r * pl.K * 4;
     int miss = 0;
-    for (int base = 1; base < pl.K; base += 64) {
-      const int kk = base + lane;
-      const bool mm = kk < pl.K &&
-          wfm_state_differs(sg[(size_t)(kk - 1) * 4 + 2], __uint_as_float(sg[(size_t)(kk - 1) * 4 + 3]),
-                            sg[(size_t)kk * 4 + 0], __uint_as_float(sg[(size_t)kk * 4 + 1]));
-      miss += __popcll(__ballot(mm));
+    // eight joins per lane in flight (one load round trip per 512 joins instead of per 64: this wave is alone on the stream)
+    for (int base = 1; base < pl.K; base += 512) {
+      uint2 e[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = base + 64 * u + lane;
+        e[u] = b[u] = make_uint2(0u, 0u);
+        if (kk < pl.K) {
+          e[u] = *reinterpret_cast<const uint2*>(sg + (size_t)(kk - 1) * 4 + 2);
+          b[u] = *reinterpret_cast<const uint2*>(sg + (size_t)kk * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = base + 64 * u + lane;
+        const bool mm = kk < pl.K && wfm_state_differs(e[u].x, __uint_as_float(e[u].y), b[u].x, __uint_as_float(b[u].y));
+        miss += __popcll(__ballot(mm));
+      }
     }
     redo = miss > 2;
   }
@@ -1013,14 +1025,24 @@ __global__ __launch_bounds__(64) void wfm_pll_patch_kernel(const WfmArgs a) {
   int k = 1;
   while (k < K) {
     int bad = K;
-    for (int base = k; base < K && bad == K; base += 64) {
-      const int kk = base + lane;
-      bool mm = false;
-      if (kk < K)
-        mm = wfm_state_differs(sg[(size_t)(kk - 1) * 4 + 2], __uint_as_float(sg[(size_t)(kk - 1) * 4 + 3]),
-                               sg[(size_t)kk * 4 + 0], __uint_as_float(sg[(size_t)kk * 4 + 1]));
-      const unsigned long long bal = __ballot(mm);
-      if (bal) bad = base + __builtin_ctzll(bal);
+    for (int base = k; base < K && bad == K; base += 512) {     // eight joins per lane in flight, as in the check kernel
+      uint2 e[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = base + 64 * u + lane;
+        e[u] = b[u] = make_uint2(0u, 0u);
+        if (kk < K) {
+          e[u] = *reinterpret_cast<const uint2*>(sg + (size_t)(kk - 1) * 4 + 2);
+          b[u] = *reinterpret_cast<const uint2*>(sg + (size_t)kk * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = base + 64 * u + lane;
+        const bool mm = kk < K && wfm_state_differs(e[u].x, __uint_as_float(e[u].y), b[u].x, __uint_as_float(b[u].y));
+        const unsigned long long bal = __ballot(mm);
+        if (bal && bad == K) bad = base + 64 * u + __builtin_ctzll(bal);
+      }
     }
     if (bad >= K) break;
     uint32_t ph = sg[(size_t)(bad - 1) * 4 + 2];

@@ -10,6 +10,6 @@ for cfg in "${@:-default}"; do
 import csv, glob, sys
 for f in glob.glob(sys.argv[1] + "/*/*kernel_stats.csv"):
     for r in list(csv.DictReader(open(f)))[:8]:
-        print("   %-40s calls %4s avg %9.1f us  %5.1f %%" % (r["Name"].split("(")[0][-40:], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+        print("   %-40s calls %4s avg %9.1f us  %5.1f %%" % (r["Name"].replace("(anonymous namespace)::", "").replace("pysdr::", "").replace("void ", "")[:40], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 PY
 done
