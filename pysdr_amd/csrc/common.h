@@ -13,6 +13,15 @@
 
 #include "../../include/pysdr_hip.h"
 
+// cache policy of the LDS-DMA loads of the vector mix + decimate kernel (mixdec.hip): nontemporal (A/B: -DPYSDR_GLDS_PLAIN).
+// The input is read once; measured per kernel (profiles/r04_glds_nt.txt): mixdec<1,6> 0.72-0.74 -> 0.76 of the HBM peak,
+// mixdec<4,6> inside C3 0.68 -> 0.73.  The matrix-core kernel chooses per shape (MfmaGeo::NT): 10 MS/s / 40 +3 %, C1 -1 %.
+#if defined(PYSDR_GLDS_PLAIN)
+#define PYSDR_GLDS_POLICY ""
+#else
+#define PYSDR_GLDS_POLICY " nt"
+#endif
+
 namespace pysdr {
 
 void set_last_error(const char* fmt, ...);
@@ -115,23 +124,27 @@ struct MixMfmaArgs {
 #ifndef MM_C4_NBUF
 #define MM_C4_NBUF 3
 #endif
-#ifndef MM_C1_CARRY
-#define MM_C1_CARRY 1
+#ifndef MM_C1_FLAGS
+#define MM_C1_FLAGS 1
 #endif
 #ifndef MM_C4_S
 #define MM_C4_S 8
 #endif
-#ifndef MM_C4_CARRY
-#define MM_C4_CARRY 0
+#ifndef MM_C4_FLAGS
+#define MM_C4_FLAGS 2
+#endif
+// last column: flags = CARRY | 2 * NT (MfmaGeo)
+#ifndef MM_NTX
+#define MM_NTX 0                        // A/B of the other shapes' copies: -DMM_NTX=2
 #endif
 #define PYSDR_MFMA_SHAPES(X) \
-  X(0, 3, 128, 2, 334, 1, 8, MM_C1_NPROD, MM_C1_NBUF, MM_C1_CARRY) \
-  X(1, 1, 40, MM_C4_S, 255, 1, 8, MM_C4_NPROD, MM_C4_NBUF, MM_C4_CARRY) \
-  X(2, 3, 64, 2, 334, 1, 8, 8, 4, 1) \
-  X(3, 3, 160, 2, 334, 1, 8, 8, 3, 0) \
-  X(4, 3, 112, 2, 334, 1, 8, 8, 4, 1) \
-  X(5, 1, 32, 8, 1001, 1, 8, 4, 3, 0) \
-  X(6, 1, 40, 6, 1001, 1, 8, 4, 3, 0)
+  X(0, 3, 128, 2, 334, 1, 8, MM_C1_NPROD, MM_C1_NBUF, MM_C1_FLAGS) \
+  X(1, 1, 40, MM_C4_S, 255, 1, 8, MM_C4_NPROD, MM_C4_NBUF, MM_C4_FLAGS) \
+  X(2, 3, 64, 2, 334, 1, 8, 8, 4, 1 | MM_NTX) \
+  X(3, 3, 160, 2, 334, 1, 8, 8, 3, 2 | MM_NTX) \
+  X(4, 3, 112, 2, 334, 1, 8, 8, 4, 1 | MM_NTX) \
+  X(5, 1, 32, 8, 1001, 1, 8, 4, 3, 0 | MM_NTX) \
+  X(6, 1, 40, 6, 1001, 1, 8, 4, 3, 0 | MM_NTX)
 int mixdec_mfma_shape(int up, int down, int kdec);   // -1: none
 bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, unsigned long long n, MfmaPlan* p);
 int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t st);

@@ -93,7 +93,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, const void* lds_wave_ba
       (unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds_wave_base);
   unsigned keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" PYSDR_GLDS_POLICY "\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(gsrc), "s"(dst)
       : "memory");
@@ -108,7 +108,7 @@ __device__ __forceinline__ unsigned m0_save() {
 }
 __device__ __forceinline__ void m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep) : "memory"); }
 __device__ __forceinline__ void glds16_m0(const void* gsrc, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" PYSDR_GLDS_POLICY ::"v"(gsrc), "s"(lds_dst) : "memory");
 }
 // LDS read through an explicit address-space-3 pointer + a constant element offset: the constant
 // goes into the DS instruction's offset field (through a generic pointer hipcc spent one VALU add per

@@ -61,8 +61,10 @@ __device__ __forceinline__ unsigned mm_m0_save() {
 }
 __device__ __forceinline__ void mm_m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep) : "memory"); }
 // one 16-byte LDS-DMA element per active lane: LDS destination = M0 + lane*16 (see mixdec.hip glds16)
+template <bool NT>
 __device__ __forceinline__ void mm_glds16(const void* gsrc, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+  if (NT) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gsrc), "s"(lds_dst) : "memory");
+  else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void mm_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // wait until at most `n` of this wave's loads are outstanding (wave-uniform n; the count is an immediate)
@@ -105,7 +107,7 @@ __device__ __forceinline__ void mm_stage(const MixMfmaArgs& a, int origin_rel, u
     const int rel = origin_rel + seg * G::P + 2 * w;
     const bool ok = (w != G::P / 2) && rel >= -a.hist_len && rel + 1 < (int)a.n_total;
     const float2* src = (rel >= 0) ? (a.x + rel) : (a.hist + (a.hist_len + rel));
-    if (ok) mm_glds16(src, img + (unsigned)pc * 1024u);
+    if (ok) mm_glds16<G::NT>(src, img + (unsigned)pc * 1024u);
   }
   mm_m0_restore(keep);
   // the last sample of an odd-length call starts a pair whose second half does not exist
@@ -140,7 +142,10 @@ __device__ __forceinline__ void mm_stage_interior(const float2* src0, unsigned i
 #else
     if (pc < G::IMG_PIECES)
 #endif
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(__float_as_uint(roff[i])), "s"(src0), "s"(img + (unsigned)pc * 1024u) : "memory");
+    {
+      if (G::NT) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(__float_as_uint(roff[i])), "s"(src0), "s"(img + (unsigned)pc * 1024u) : "memory");
+      else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(__float_as_uint(roff[i])), "s"(src0), "s"(img + (unsigned)pc * 1024u) : "memory");
+    }
   }
   mm_m0_restore(keep);
 }

@@ -16,10 +16,12 @@
 
 namespace pysdr {
 
-template <int UP_, int DOWN_, int S_, int KT_, int NB_, int WK_, int NPROD_, int NBUF_, int CARRY_>
+// FLAGS_: bit 0 = CARRY (the operand ring is carried from tile to tile), bit 1 = NT (the LDS-DMA loads are nontemporal)
+template <int UP_, int DOWN_, int S_, int KT_, int NB_, int WK_, int NPROD_, int NBUF_, int FLAGS_>
 struct MfmaGeo {
   static constexpr int UP = UP_, DOWN = DOWN_, S = S_, KT = KT_, NB = NB_, WK = WK_, NPROD = NPROD_, NBUF = NBUF_;
-  static constexpr bool CARRY = CARRY_ != 0;             // the operand ring is carried from tile to tile (needs the NEXT tile landed too)
+  static constexpr bool CARRY = (FLAGS_ & 1) != 0;       // the operand ring is carried from tile to tile (needs the NEXT tile landed too)
+  static constexpr bool NT = (FLAGS_ & 2) != 0;          // nontemporal copies: measured per shape (profiles/r04_glds_nt.txt)
   static constexpr int P = S * DOWN;                       // samples between consecutive rows
   static constexpr int US = UP * S;                        // outputs per row
   static constexpr int OFF_LAST = ((UP - 1) * DOWN) / UP;
@@ -48,7 +50,7 @@ struct MfmaGeo {
   static constexpr int LDS_BYTES = NBUF * IMG_BYTES + 2 * PART_BYTES;   // NBUF images: NBUF-1 tiles of copies in flight
   static_assert(P % 4 == 0, "a k-step of four samples must not straddle two segments for both parities");
   static_assert(2 * S * UP <= 16, "columns");
-  static_assert(NBUF >= 2 + (CARRY_ ? 1 : 0) && NBUF <= 4, "images: one being worked on, (CARRY) one landed ahead of it, the rest in flight");
+  static_assert(NBUF >= 2 + ((FLAGS_ & 1) ? 1 : 0) && NBUF <= 4, "images: one being worked on, (CARRY) one landed ahead of it, the rest in flight");
   static_assert(KT - 1 >= (DOWN + UP - 1) / UP, "tile 0 must own the call's first sample");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   static_assert(NDMA >= 1, "producer waves");
