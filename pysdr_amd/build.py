@@ -20,6 +20,7 @@ SOURCES = ["api.hip", "mixdec.hip", "mixdec_mfma.hip", "resamp_small.hip", "stag
 # reduction into v_add_f32_dpp but measured the same 96-99 us, so the default stays)
 EXTRA_FLAGS = {"mixdec.hip": os.environ.get("PYSDR_MIXDEC_FLAGS", "").split(),
                "mixdec_mfma.hip": os.environ.get("PYSDR_MFMA_FLAGS", "").split(),
+               "resamp_small.hip": os.environ.get("PYSDR_RESAMP_FLAGS", "").split(),
                "api.hip": os.environ.get("PYSDR_API_FLAGS", "").split(),   # a shape's S / NB enter the host's plan: pass the same -D to both   # experiments: -DMM_NO_PK, -DMM_PROD_PRIO=n
                # packed-f32 pairs built by the SLP vectoriser run at half rate on gfx950 and are fed by
                # v_mov shuffles: the AF FIR is written for plain FMAs

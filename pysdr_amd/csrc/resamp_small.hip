@@ -129,7 +129,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
 #pragma unroll
       for (int u = 0; u < kRbPre; ++u) {
         const int j = tid + u * nth;
-        pre[u] = (j <= hi - lo) ? a.x[lo + j] : make_float2(0.f, 0.f);
+        pre[u] = (j <= hi - lo) ? a.x[lo + j] : make_float2(0.f, 0.f);   // (nontemporal: no difference, 47.8-48.9 against 48.2-49.3 us)
       }
     } else {
 #pragma unroll
