@@ -197,7 +197,7 @@ struct pysdr_spectrum {
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipEvent_t ev_order = nullptr;
   bool force_rocfft = false;  // PYSDR_PSD_ROCFFT: rocFFT even for the 32768 -> 65536 size
-  int group = 448;            // frames per launch pair of the four-step path (PYSDR_PSD_GROUP)
+  int group = 0;              // frames per launch pair of the four-step path (PYSDR_PSD_GROUP); 0 = 480 with the 24-bit intermediate, 448 with float2
   bool ran = false;           // spectrum_run has recorded ev[1] at least once
   int packed = 1;             // four-step intermediate as block-scaled 24-bit fixed point (psdfft.hip; PYSDR_PSD_PACKED=0: float2)
   // PYSDR_PSD_STREAMS=2: the groups alternate between two streams, each with its own half-size intermediate
@@ -1351,8 +1351,11 @@ static int spectrum_run(pysdr_spectrum* sp, const float2* d_x, size_t hop, int n
     // Running the rows of group g beside the columns of group g+1 on a second stream with two FULL groups
     // of intermediate is slower (3.9 ms, round 1: the two working sets evict each other); with HALF a group per
     // stream it is 5 % faster (round 3, below).
-    int group = sp->group;
-    if (group < 1) group = 1;
+    // (round 4: the 24-bit intermediate is 384 KB per frame and the mix + decimate kernel beside it now copies
+    //  nontemporal: 320 / 384 / 448 / 512 / 576 / 640 frames = C3 step 3.04 / 2.97 / 2.96-2.97 / 2.93 / 2.94 / 3.26 ms,
+    //  scripts/diag/psd_group_sweep.sh; on a second box 448 / 512 / 576 = 2.99-3.01 / 2.95-2.99 / 3.05: the cliff moves from box
+    //  to box, so the default sits between the old 448 and the best 512)
+    int group = sp->group > 0 ? sp->group : (sp->packed ? 480 : 448);
     if (sp->nstreams > 1 && nframes > group) {
       // The groups are dealt out over `nstreams` streams, each with its own intermediate of group / nstreams
       // frames (together the same Infinity Cache footprint as one group): the columns of one sub-group run
@@ -1453,7 +1456,7 @@ int pysdr_spectrum_batch(pysdr_spectrum* sp, const void* d_iq, int nframes, size
 
 int pysdr_spectrum_get_tuning(pysdr_spectrum* sp, int32_t out[4]) {
   if (!sp || !out) return PYSDR_ERR_ARG;
-  out[0] = sp->group; out[1] = sp->force_rocfft ? 1 : 0; out[2] = sp->nstreams; out[3] = sp->packed;
+  out[0] = sp->group > 0 ? sp->group : (sp->packed ? 480 : 448); out[1] = sp->force_rocfft ? 1 : 0; out[2] = sp->nstreams; out[3] = sp->packed;
   return PYSDR_OK;
 }
 

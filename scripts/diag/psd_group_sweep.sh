@@ -1,4 +1,4 @@
-for grp in 448 512 576 640 704 768 896; do
+for grp in 320 384 448 512 576 640 448; do
   PYSDR_TUNING=1 PYSDR_PSD_GROUP=$grp python bench.py --no-cpu-baseline --no-host-fed --no-other-configs --no-verify 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
