@@ -352,10 +352,11 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
     b.peak = peak ? peak : c->d_peak_scratch;
     b.chunk_len = peak ? (uint32_t)chunk_len : (uint32_t)std::max<size_t>(n, 1);
     b.magic_chunk = (b.chunk_len == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned long long)b.chunk_len) + 1u;
+    // the history roll rides in the launch (hist_roll.h): the epilogue waves of workgroup 0 during their idle first trip
+    b.hist_new = d.d_hist[d.hist_cur ^ 1];
+    b.zero = peak ? c->d_peak2[c->peak_cur ^ 1] : nullptr;
+    b.zero_n = peak ? c->cfg.max_chunks : 0;
     int rc = launch_mixdec_mfma(mshape, b, c->grid_override > 0 ? c->grid_override : c->num_cus, c->stream);
-    if (rc) return rc;
-    rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n,
-                          peak ? c->d_peak2[c->peak_cur ^ 1] : nullptr, peak ? c->cfg.max_chunks : 0, c->stream);
     if (rc) return rc;
     if (peak) c->peak_clean[c->peak_cur ^ 1] = true;
     d.hist_cur ^= 1;
@@ -440,12 +441,17 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   // one RX, no raw peak wanted, short prototype and a small DOWN/UP (the fs1 -> FS_OUT stage of broadcast FM): one thread
   // per output (resamp_small.hip).  Decided by the decimator's shape and its call site only, never by the call.
   const bool small = (nrx == 1 && !peak && resamp_small_span(up, down, d.kpad) > 0);
+  // the history roll rides in the launch (hist_roll.h: workgroup 0, while its first tile's copies are in flight)
+  a.hist_new = d.d_hist[d.hist_cur ^ 1];
+  a.zero = peak ? c->d_peak2[c->peak_cur ^ 1] : nullptr;
+  a.zero_n = peak ? c->cfg.max_chunks : 0;
   int rc = small ? launch_resamp_small(a, c->grid_override, c->resamp_plain, c->stream)
                  : launch_mixdec(a, c->threads, c->grid_override > 0 ? c->grid_override : c->num_cus * wgs, c->stream);
   if (rc) return rc;
-  rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n,
-                        peak ? c->d_peak2[c->peak_cur ^ 1] : nullptr, peak ? c->cfg.max_chunks : 0, c->stream);
-  if (rc) return rc;
+  if (small && n_out <= 0) {          // the resampler starts no kernel for a call without outputs: the roll on its own
+    rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, a.zero, a.zero_n, c->stream);
+    if (rc) return rc;
+  }
   if (peak) c->peak_clean[c->peak_cur ^ 1] = true;
   d.hist_cur ^= 1;
   d.s_abs = s1;

@@ -66,6 +66,8 @@ struct MixDecArgs {
   unsigned* peak;         // [nchunks] max |x|^2 as float bits (atomicMax)
   uint32_t chunk_len;
   uint32_t magic_chunk;   // floor(2^32/chunk_len)+1
+  // the history roll rides in this launch (hist_roll.h): new history, the next call's raw-peak buffer to zero; null = not here
+  float2* hist_new; unsigned* zero; int zero_n;
   int dbg;                // diagnostic build switches (PYSDR_DEBUG_FLAGS); 0 in production
 #ifdef PYSDR_DIAG
   unsigned long long* stamps;   // [2 workgroups][16 waves][24 tiles][8] s_memtime stamps of the tile loop's phases (or null)
@@ -99,6 +101,8 @@ struct MixMfmaArgs {
   uint32_t phase0, fword;
   unsigned* peak;         // [nchunks] max |x|^2 as float bits (atomicMax)
   uint32_t chunk_len, magic_chunk;
+  // the history roll rides in this launch (hist_roll.h): new history, the next call's raw-peak buffer to zero; null = not here
+  float2* hist_new; unsigned* zero; int zero_n;
 };
 // instantiations: X(id, UP, DOWN, S shifts, taps per branch, NB row blocks per tile, WK window slices, producer waves, LDS images, operand ring carried across tiles)
 //   0: 2.048 MS/s -> 48 kHz with the reference's default 1001-tap prototype (params.py:134; am.py path, BASELINE C1)

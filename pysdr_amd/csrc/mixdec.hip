@@ -28,6 +28,7 @@
 //                rows (DOWN samples apart) overlap on few banks.
 #include "common.h"
 #include "mixdec_geom.h"
+#include "hist_roll.h"
 
 namespace pysdr {
 
@@ -294,6 +295,9 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   int pk_lo = 0;                 // samples [pk_lo, pk_hi] of chunk pk_chunk exist in this call
   int pk_hi = (int)(a.chunk_len < a.n_total ? a.chunk_len : a.n_total) - 1;
   if (!PYSDR_DBG(a, 2)) stage_tile(a, cur, buf0, tid, nthr);
+  // the decimator's history roll, by workgroup 0 while its first tile's copies are in flight (hist_roll.h)
+  if (blockIdx.x == 0 && a.hist_new != nullptr)
+    roll_history(a.x, a.hist, a.hist_new, a.hist_len, a.n_total, a.zero, a.zero_n, tid, nthr);
 
   if (kCanHold && hold) {
     // this wave's taps: one branch (p_f is the same for every tile: tile_out*DOWN is a multiple of UP),

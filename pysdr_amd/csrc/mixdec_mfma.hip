@@ -39,6 +39,7 @@
 #include "common.h"
 #include "mixdec_geom.h"
 #include "mixdec_mfma_geom.h"
+#include "hist_roll.h"
 
 namespace pysdr {
 
@@ -351,6 +352,9 @@ __device__ __forceinline__ void mm_epi(const MixMfmaArgs& a, unsigned part0, int
 #endif
   const int n = t_end - t_begin;
   mm_barrier_lds_only();              // (1)
+  // trip 0 leaves these waves idle (no tile is finished yet): workgroup 0's roll the decimator's history meanwhile
+  if (blockIdx.x == 0 && a.hist_new != nullptr)
+    roll_history(a.x, a.hist, a.hist_new, a.hist_len, a.n_total, a.zero, a.zero_n, etid, 64 * G::NEPI);
   mm_barrier_lds_only();              // trip 0: no tile is finished yet
   for (int i0 = 0; i0 < n; i0 += kFlush) {
     float2 hold[kFlush];

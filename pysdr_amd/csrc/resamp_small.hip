@@ -12,6 +12,7 @@
 // The sum runs over k = 0 .. kpad-1 in order whatever the call, tile or thread: batch == chunk by chunk bit for bit.
 #include "common.h"
 #include "mixdec_geom.h"
+#include "hist_roll.h"
 
 namespace pysdr {
 
@@ -24,6 +25,8 @@ __global__ __launch_bounds__(kRsThreads) void resamp_small_kernel(const MixDecAr
   float2* const xs = rs_lds;                       // [span_cap] input span of one group of 256 outputs
   float2* const tl = rs_lds + span_cap;            // [up][kpad + 1] taps (one pad per row: rows kpad*8 bytes apart would share a bank)
   const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && a.hist_new != nullptr)    // the decimator's history roll rides in this launch (hist_roll.h)
+    roll_history(a.x, a.hist, a.hist_new, a.hist_len, a.n_total, a.zero, a.zero_n, tid, kRsThreads);
   // the tap table once per workgroup (a workgroup walks every gridDim.x-th group of outputs)
   const int kp1 = a.kpad + 1;
   if (kRsThreads % a.kpad == 0) {
@@ -101,6 +104,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
   float2* const os = rs_lds + span_cap;            // [tile_out] the tile's outputs, in output order
   float2* const tl = os + tile_out;                // [up][kpad + 1] taps
   const int tid = threadIdx.x, nth = blockDim.x;   // nth = up * 32
+  if (blockIdx.x == 0 && a.hist_new != nullptr)    // the decimator's history roll rides in this launch (hist_roll.h)
+    roll_history(a.x, a.hist, a.hist_new, a.hist_len, a.n_total, a.zero, a.zero_n, tid, nth);
   const int kp1 = a.kpad + 1;
   for (int j = tid; j < a.up * a.kpad; j += nth) {
     const int p = j / a.kpad, k = j - p * a.kpad;

@@ -4,6 +4,7 @@
 // one-shot (sigs/iir.py:83-125).  The data rate here is UP/DOWN (~1/167) of the input
 // rate, so these kernels are latency-, not bandwidth-, critical.
 #include "common.h"
+#include "hist_roll.h"
 
 namespace pysdr {
 
@@ -776,11 +777,7 @@ __global__ __launch_bounds__(256) void hist_roll_kernel(const float2* __restrict
                                                         const float2* __restrict__ hist_old,
                                                         float2* __restrict__ hist_new, int hist_len,
                                                         uint32_t n_total, unsigned* __restrict__ zero, int zero_n) {
-  for (int j = threadIdx.x; j < hist_len; j += 256) {
-    const long long rel = (long long)n_total - hist_len + j;
-    hist_new[j] = (rel >= 0) ? x[rel] : hist_old[hist_len + rel];
-  }
-  for (int j = threadIdx.x; j < zero_n; j += 256) zero[j] = 0u;
+  roll_history(x, hist_old, hist_new, hist_len, n_total, zero, zero_n, threadIdx.x, 256);
 }
 
 // ---- broadcast FM at the IF rate: polar discriminator (all lanes), then the 19 kHz pilot

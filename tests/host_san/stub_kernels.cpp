@@ -51,7 +51,9 @@ size_t mixdec_lds_bytes(const MixDecArgs& a) {
   return (2 * (size_t)a.tile_cap + (size_t)a.nrx * a.up * a.kpad + (size_t)a.nrx * a.ycap) * sizeof(float2);
 }
 
+static void roll_on_host(const float2* x, const float2* hist_old, float2* hist_new, int hist_len, uint32_t n_total, unsigned* zero, int zero_n);
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t) {
+  if (a.hist_new) roll_on_host(a.x, a.hist, a.hist_new, a.hist_len, a.n_total, a.zero, a.zero_n);
   SAN_CHECK(threads >= 64 && threads <= 1024 && (threads & 63) == 0, "threads %d", threads);
   SAN_CHECK(grid >= 1, "grid %d", grid);
   SAN_CHECK(mixdec_lds_bytes(a) <= 160 * 1024, "LDS %zu", mixdec_lds_bytes(a));
@@ -109,6 +111,7 @@ int resamp_small_span(int up, int down, int kpad) {
 int g_small_launches = 0;
 int launch_resamp_small(const MixDecArgs& a, int, int, hipStream_t) {
   ++g_small_launches;
+  if (a.hist_new && a.n_out > 0) roll_on_host(a.x, a.hist, a.hist_new, a.hist_len, a.n_total, a.zero, a.zero_n);   // the real launcher starts no kernel without outputs
   const int span = resamp_small_span(a.up, a.down, a.kpad);
   SAN_CHECK(span > 0 && a.nrx == 1, "shape");
   SAN_CHECK(a.hist_len >= a.kpad - 1, "hist_len %d kpad %d", a.hist_len, a.kpad);
@@ -202,6 +205,16 @@ int walk_mfma(const MixMfmaArgs& a, int grid) {
 }
 }  // namespace
 
+// the history roll as hist_roll.h does it (one workgroup of the decimator kernel, or the launch of its own)
+static void roll_on_host(const float2* x, const float2* hist_old, float2* hist_new, int hist_len, uint32_t n_total, unsigned* zero, int zero_n) {
+  SAN_CHECK(hist_new != nullptr && hist_new != hist_old, "history roll in place");
+  if (zero_n > 0) write_all(zero, (size_t)zero_n);
+  for (int j = 0; j < hist_len; ++j) {
+    const long long rel = (long long)n_total - hist_len + j;
+    hist_new[j] = (rel >= 0) ? x[rel] : hist_old[hist_len + rel];
+  }
+}
+
 int mixdec_mfma_shape(int up, int down, int kdec) {
 #define PYSDR_MFMA_MATCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY) \
   if (up == UP && down == DOWN && kdec == KT) return ID;
@@ -219,6 +232,7 @@ bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, u
 int g_mfma_launches = 0;
 int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t) {
   ++g_mfma_launches;
+  if (a.hist_new) roll_on_host(a.x, a.hist, a.hist_new, a.hist_len, a.n_total, a.zero, a.zero_n);
 #define PYSDR_MFMA_LAUNCH(ID, UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY) \
   if (shape == ID) return walk_mfma<MfmaGeo<UP, DOWN, S, KT, NB, WK, NP, NBUF, CARRY>>(a, grid);
   PYSDR_MFMA_SHAPES(PYSDR_MFMA_LAUNCH)
@@ -228,11 +242,7 @@ int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t) {
 }
 
 int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, int hist_len, uint32_t n_total, unsigned* zero, int zero_n, hipStream_t) {
-  if (zero_n > 0) write_all(zero, (size_t)zero_n);
-  for (int j = 0; j < hist_len; ++j) {
-    const long long rel = (long long)n_total - hist_len + j;
-    hist_new[j] = (rel >= 0) ? x[rel] : hist_old[hist_len + rel];
-  }
+  roll_on_host(x, hist_old, hist_new, hist_len, n_total, zero, zero_n);
   return PYSDR_OK;
 }
 
