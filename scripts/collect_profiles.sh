@@ -9,10 +9,12 @@ OUT=${1:-gpurun_out/prof}
 QUICK=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$OUT" && mkdir -p "$OUT"
+TAG=${PROFILE_TAG:-r04}
+declare -a CFG_NAMES=() CFG_ARGS=()
 run_cfg() {  # name, pmc(0/1), bench args...
   local name=$1 pmc=$2; shift 2
   mkdir -p "$OUT/$name"
-  python3 bench.py "$@" --no-other-configs > "$OUT/$name/bench.json" 2> "$OUT/$name/bench.err"
+  CFG_NAMES+=("$name"); CFG_ARGS+=("$* ${PYSDR_PSD_STREAMS:+@1stream}")
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name/kt" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify > "$OUT/$name/bench_kt.json" 2> "$OUT/$name/kt.err"
   if [ "$pmc" = 1 ]; then
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$name/pmc_fetch" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 3 --warmup 1 > "$OUT/$name/pmc_fetch.json" 2> "$OUT/$name/pmc_fetch.err"
@@ -25,7 +27,6 @@ run_cfg() {  # name, pmc(0/1), bench args...
   # keep only the small summaries (the per-dispatch traces are tens of MB)
   find "$OUT/$name" -name "*kernel_trace.csv" -delete
   find "$OUT/$name" -name "*counter_collection.csv" -size +8M -delete
-  echo "$name: $(tail -c 300 "$OUT/$name/bench.json" | head -c 120)"
 }
 run_cfg c3 1
 # the PSD's two kernels one after the other (the default deals half-groups over two streams, so the per-kernel
@@ -38,3 +39,18 @@ run_cfg c1 1 --workload c1
 run_cfg c4 1 --workload c4
 run_cfg c4mono 0 --workload c4mono --no-cpu-baseline
 run_cfg rx6 0 --nrx 6 --no-psd --no-cpu-baseline
+# The plain bench lines (events only, no profiler attached) come LAST: the counters above are first condensed into
+# profiles/<tag>_pmc_traffic.json (stamped with the hashes of the kernel sources), so that the lines carry `traffic`.
+python3 scripts/summarize_profiles.py "$OUT" profiles "$TAG" > "$OUT/summarize.log" 2>&1
+for i in "${!CFG_NAMES[@]}"; do
+  name=${CFG_NAMES[$i]}; args=${CFG_ARGS[$i]}
+  if [[ "$args" == *@1stream* ]]; then
+    PYSDR_TUNING=1 PYSDR_PSD_STREAMS=1 python3 bench.py ${args%@1stream} --no-other-configs > "$OUT/$name/bench.json" 2> "$OUT/$name/bench.err"
+  else
+    python3 bench.py $args --no-other-configs > "$OUT/$name/bench.json" 2> "$OUT/$name/bench.err"
+  fi
+  echo "$name: $(python3 -c "
+import json,sys
+d=json.loads(open('$OUT/$name/bench.json').read().strip().splitlines()[-1])
+print('GS/s %.1f ms %.4f frac %.3f traffic %s job %.3f' % (d['value']/1e3, d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('traffic'), d['roofline_job']['frac']))")"
+done
