@@ -251,7 +251,10 @@ __global__ __launch_bounds__(64) void am_pll_patch_kernel(const Stage2Args a) {
 // (loads from HBM + detector) 44, the remaining atomics 21, the stores 3 (16-byte stores; 23 as
 // eight strided dwords) -- the phases of the workgroups of a CU run in step and barely overlap.
 constexpr int kW = 8;                  // outputs per thread
-constexpr int kFirThreads = 256;
+#ifndef FIRX_THREADS
+#define FIRX_THREADS 256               // A/B: threads (x 8 outputs) per workgroup of the AF FIR
+#endif
+constexpr int kFirThreads = FIRX_THREADS;
 constexpr int kFirOut = kW * kFirThreads;   // outputs per workgroup
 constexpr int kFirRealReal = 0;        // d real, c real    -> real
 constexpr int kFirRePart = 1;          // d cplx, c cplx    -> Re(c*d)
