@@ -404,7 +404,12 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   const int r = a.fir_rx[blockIdx.y];
   const int tid = threadIdx.x;
-  const int i0 = blockIdx.x * kFirOut;
+  // The pairing of taps below depends on whether an output is an even or an odd one of its lane (fir_block): the tiles
+  // are laid out from an EVEN absolute output index, so that an output's sum runs in the same order whatever call it
+  // falls into (a batch of chunks with odd output counts against the chunk-by-chunk loop: 1 ulp apart before round 4,
+  // test_batch_of_chunks_with_odd_output_counts_equals_chunked_bit_exact).  par = 1: output -1 of tile 0 does not exist.
+  const int par = (int)(a.m0_lo & 1u);
+  const int i0 = blockIdx.x * kFirOut - par;
   const int det = a.det[r];
   const float2* y = (det == kDetPll) ? a.ypll[r] : a.y[r];
   const int H = fir_taps_padded(a.ntaps);                // taps, zero padded to whole groups of 12
@@ -450,14 +455,14 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   // held a block boundary -- every other wave -- was 0.5 M atomics per call and 20 us.)  Blocks
   // shorter than that (tiny chunk_len) fall through to per-element atomics.
   const bool squelch = (a.sq_thresh[r] > 0.f) && (det == kDetFm);
-  const bool valid = ib < a.n_out;
+  const bool valid = ib < a.n_out;                        // (ib = -1 for lane 0 of tile 0 when par: its outputs 0 .. 6 exist)
   uint32_t blk_lo = 0xFFFFFFFFu, blk_hi = 0xFFFFFFFFu;
   if (valid) {
     const int last = (ib + kW - 1 < a.n_out) ? ib + kW - 1 : a.n_out - 1;
-    blk_lo = block_of(a, r, ib);
+    blk_lo = block_of(a, r, ib < 0 ? 0 : ib);
     blk_hi = block_of(a, r, last);
     // the lane's 8 outputs are 32 (64) contiguous bytes: 16-byte stores, not eight strided dwords
-    if (ib + kW <= a.n_out) {
+    if (ib >= 0 && ib + kW <= a.n_out) {
       if (CPLX) {
         float4* o = reinterpret_cast<float4*>(a.a[r] + ib);
 #pragma unroll
@@ -475,8 +480,8 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   if (valid) {
 #pragma unroll
     for (int j = 0; j < kW; ++j)
-      if (ib + j < a.n_out) {
-        if (ib + kW > a.n_out) {
+      if (ib + j >= 0 && ib + j < a.n_out) {
+        if (ib < 0 || ib + kW > a.n_out) {
           if (CPLX) a.a[r][ib + j] = acc[j];
           else reinterpret_cast<float*>(a.a[r])[ib + j] = acc[j].x;   // real outputs: 4 bytes each
         }
@@ -1139,7 +1144,7 @@ int launch_demod_fir(const Stage2Args& a, hipStream_t st) {
     for (int r = 0; r < a.nrx; ++r)
       if ((a.out_complex[r] ? 1 : 0) == cplx) b.fir_rx[n++] = r;
     if (n == 0) continue;
-    dim3 grid((a.n_out + kFirOut - 1) / kFirOut, n);
+    dim3 grid((a.n_out + (int)(a.m0_lo & 1u) + kFirOut - 1) / kFirOut, n);      // tiles start at an even absolute output (demod_fir_kernel)
     if (cplx) hipLaunchKernelGGL(demod_fir_kernel<true>, grid, dim3(kFirThreads), lds, st, b);
     else hipLaunchKernelGGL(demod_fir_kernel<false>, grid, dim3(kFirThreads), lds, st, b);
     PYSDR_HIP_CHECK(hipGetLastError());

@@ -660,6 +660,72 @@ def test_nfm_noise_squelch_mutes_when_the_carrier_drops():
     assert opened[2] and opened[3] and not opened[5] and not opened[6] and opened[14]
 
 
+@pytest.mark.parametrize("L", [1500, 700, 43690 // 4])
+def test_batch_of_chunks_with_odd_output_counts_equals_chunked_bit_exact(L):
+    """Chunks of 1500 samples at 3/500 are 9 outputs, of 700 samples 4 or 5, of 10922 samples 65 or 66: inside a batch
+    half of the chunks then start at an ODD output of the call.  The AF FIR pairs the taps of an output differently for
+    the even and the odd outputs of a lane; its tiles are anchored at an even ABSOLUTE output index, so an output's sum
+    runs in the same order in both worlds (before round 4: anchored at the call's first output, 1 ulp apart in ~8 %
+    of the outputs -- found by the squelch test below; every earlier identity test had even counts)."""
+    cfg = so.CONFIGS['C3']
+    B = 300
+    x = so.synth_iq(cfg, B * L, 9)
+    P1, g1 = make_gpu_receivers(cfg)
+    am1 = [[] for _ in g1]
+    iq1 = [[] for _ in g1]
+    for k in range(B):
+        for i, rx in enumerate(g1):
+            am1[i].append(rx.demod_data(x[k * L:(k + 1) * L]).copy())
+            iq1[i].append(rx.iq.copy())
+    assert any(len(a) & 1 for a in am1[0])
+    P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    ctx = P2._pysdr_stream
+    # two calls, the second one starting at an odd absolute output for L = 1500 (150 x 9 outputs in the first)
+    for lo, hi in ((0, B // 2), (B // 2, B)):
+        ctx.process_batch(x[lo * L:hi * L], hi - lo, L, on_device=False)
+        for i in range(len(g2)):
+            am, iq, cn, pk = ctx.fetch(i, hi - lo)
+            assert list(cn) == [len(a) for a in am1[i][lo:hi]]
+            assert np.array_equal(iq.view(np.uint32), np.concatenate(iq1[i][lo:hi]).view(np.uint32)), (i, lo)
+            assert np.array_equal(am.view(np.uint32), np.concatenate(am1[i][lo:hi]).view(np.uint32)), (i, lo)
+    assert g2[3].agc.gain == g1[3].agc.gain and g2[0].agc.maxbuf == g1[0].agc.maxbuf
+
+
+@pytest.mark.parametrize("L,B", [(170666, 120), (3000, 400), (700, 900)])
+def test_squelch_in_a_batch_equals_chunk_by_chunk_bit_exact(L, B):
+    """The squelch's smoothing of the block noise runs time-parallel inside a batch (agc_scan_kernel: segments of
+    16+ blocks, each warmed up over the 32 blocks in front of it, joins compared bit for bit, serial fallback on a
+    miss) -- 120 blocks = 8 segments, 400 / 900 blocks of 18 / 4 outputs = 25 / 57 segments.  Gate, level and audio of the
+    batch must be what the chunk-by-chunk loop (one block per call: the serial recursion) gives, bit for bit, with
+    the station going off the air and coming back inside the batch; the first chunks also against the oracle."""
+    cfg = so.CONFIGS['C2']
+    x = so.synth_iq(cfg, B * L, 14)
+    noise_only = so.synth_iq(dict(cfg, carriers=[]), B * L, 15)
+    a, b = (B // 3) * L, (B // 3 + B // 4) * L
+    x[a:b] = noise_only[a:b]
+    P1, g1 = make_gpu_receivers(cfg)
+    g1[0].squelch = 0.05
+    am1, gate1 = [], []
+    for k in range(B):
+        am1.append(g1[0].demod_data(x[k * L:(k + 1) * L]).copy())
+        gate1.append(g1[0].squelch_state[1])
+    P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    g2[0].squelch = 0.05
+    ctx = P2._pysdr_stream
+    ctx.process_batch(x, B, L, on_device=False)
+    am, iq, cn, pk = ctx.fetch(0, B)
+    assert list(cn) == [len(v) for v in am1]
+    assert np.array_equal(am.view(np.uint32), np.concatenate(am1).view(np.uint32))
+    assert g2[0].squelch_state == g1[0].squelch_state
+    assert any(gate1) and not all(gate1)                     # the gate really opened and closed inside the batch
+    if L == 170666:
+        o = so.make_receivers(cfg, np.float32)
+        o[0].squelch = np.float32(0.05)
+        want = [o[0].demod_data(x[k * L:(k + 1) * L]) for k in range(6)]
+        for k in range(1, 6):
+            assert relerr(am1[k], want[k]) <= TOL, k
+
+
 def test_waterfall_backend_matches_plotting_py_numerics():
     """Plotting.py:536-626,689-695 with the history on the device."""
     from pysdr_amd.waterfall import Waterfall
