@@ -1105,6 +1105,8 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     s.out_complex[r] = (x.mode == PYSDR_IQ || wfm) ? 1 : 0;
     s.fir_complex[r] = s.out_complex[r];
     s.single_block[r] = wfm ? 1 : 0;
+    s.single_spread = 1;
+    while (s.single_spread * 2 <= std::min(nchunks, 32)) s.single_spread *= 2;
     s.matrix[r] = (x.mode == PYSDR_WFM2) ? 1 : 0;
     s.bfo_fword[r] = x.bfo_fword;
     s.sq_thresh[r] = x.sq_thresh;

@@ -428,7 +428,11 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   for (int e = tid; e < E; e += kFirThreads) {
     const int i = i0 - H + e - 3;
     // (indices in front of the kept history only ever meet zero-padded taps)
+#ifdef FIRX_NO_STAGE                  // experiment (results WRONG): no loads, no detector
+    const float2 d = make_float2(1.0f + (float)e, 0.5f);
+#else
     const float2 d = (i >= -a.hy + 2) ? detect(a, r, det, y, i) : make_float2(0.f, 0.f);
+#endif
     sre[fir_pad(e)] = d.x;
     sim[fir_pad(e)] = d.y;
   }
@@ -440,6 +444,10 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   __syncthreads();
 
   float2 acc[kW];
+#ifdef FIRX_NO_SUM                    // experiment (results WRONG): no inner product
+  for (int j = 0; j < kW; ++j) acc[j] = make_float2(sre[fir_pad(kW * tid + H + 3 + j)], sim[fir_pad(kW * tid + H + 3 + j)]);
+  if (false)
+#endif
   if (CPLX) {
     fir_run<kFirCplx>(sre, sim, tre, tim, tre_s, tim_s, nblk, H, tid, acc);
   } else {
@@ -513,8 +521,13 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
       cnt0 += __shfl_xor(cnt0, o); cnt1 += __shfl_xor(cnt1, o);
     }
   }
+#ifdef FIRX_NO_ATOMICS                // experiment (results WRONG): no block peaks
+  if (m0 + m1 == 1.2345e30f)
+#endif
   if ((tid & 63) == 0 && wb0 != 0xFFFFFFFFu) {
-    const size_t k0 = ((size_t)r * a.nchunks + wb0) * kBlkStride, k1 = k0 + kBlkStride;
+    // (a single-block RX -- broadcast FM -- deals its waves over single_spread accumulators: agc_scan_kernel folds them)
+    const uint32_t sp = a.single_block[r] ? (blockIdx.x & (uint32_t)(a.single_spread - 1)) : 0u;
+    const size_t k0 = ((size_t)r * a.nchunks + wb0 + sp) * kBlkStride, k1 = k0 + kBlkStride;
     if (m0 > 0.f) atomicMax(a.blkpeak + k0, __float_as_uint(m0));
     if (m1 > 0.f) atomicMax(a.blkpeak + k1, __float_as_uint(m1));
     if (squelch) {
@@ -556,6 +569,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
   // broadcast FM has no AGC blocks: the whole call is block 0 (walking 2047 empty blocks after it
   // let the envelope decay through hundreds of segment joins that never meet: 140 us)
   const int nch = a.single_block[r] ? (a.nchunks > 0 ? 1 : 0) : a.nchunks;
+  const int nacc = a.single_block[r] ? (a.nchunks > 0 ? a.single_spread : 0) : a.nchunks;   // accumulators the AF FIR wrote
   // LDS index of block c: one pad word per 16 blocks.  The segments below are 16 blocks long and every lane walks
   // its own: at a pitch of 16 words the 64 lanes of a read sit on TWO banks (16-way conflict: the walk of 192 reads per
   // lane was most of this kernel's 26 us at 4096 blocks); at 17 they sit on all of them.
@@ -568,24 +582,32 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
   // sixteen loads in flight per thread (a rolled loop waits for each 256-byte-strided load in turn; these lines were last
   // touched by the AF FIR's atomics and come from the memory side: a round of loads is ~4 us whatever its size -- 4096
   // blocks in two rounds of eight per thread took 8 of this kernel's 20 us, scripts/diag/agc_ablate.sh)
-  for (int c0 = 0; c0 < nch; c0 += 16 * 256) {
+  for (int c0 = 0; c0 < nacc; c0 += 16 * 256) {
     unsigned v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int c = c0 + u * 256 + tid;
 #ifdef AGCX_NO_LOAD                   // experiment (results WRONG)
-      v[u] = (c < nch) ? 0x3f000000u + c : 0u;
+      v[u] = (c < nacc) ? 0x3f000000u + c : 0u;
 #else
-      v[u] = (c < nch) ? a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] : 0u;
+      v[u] = (c < nacc) ? a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] : 0u;
 #endif
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int c = c0 + u * 256 + tid;
-      if (c < nch) pk[px(c)] = __uint_as_float(v[u]);
+      if (c < nacc) pk[px(c)] = __uint_as_float(v[u]);
     }
   }
   __syncthreads();
+  if (a.single_block[r] && nacc > 1) {                 // the one block's peak = the largest of its accumulators
+    if (tid == 0) {
+      float m = pk[px(0)];
+      for (int c = 1; c < nacc; ++c) m = fmaxf(m, pk[px(c)]);
+      pk[px(0)] = m;
+    }
+    __syncthreads();
+  }
   const RxDevState st = a.state[r];
   // The recursion is serial, but an attack (peak > env) overwrites the state and a decay forgets it
   // by 0.9 per block: segments of T blocks, each started kWarm blocks early from env = 0, reach the
@@ -651,6 +673,8 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
     a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] = 0u;
 #endif
   }
+  if (a.single_block[r])
+    for (int c = 1 + tid; c < nacc; c += 256) a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] = 0u;
   const float env_last = nch > 0 ? pk[px(nch - 1)] : 0.f;       // (the squelch section reuses pk[])
   if (a.sq_thresh[r] > 0.f) {
     // One-pole smoothing of the block noise, lvl += 0.64 (noise - lvl) over the blocks that hold samples, and the gate

@@ -1,0 +1,18 @@
+# where demod_fir_kernel's time goes (results of the FIRX_NO_* builds are WRONG): kernel averages on C1 / C3 (no PSD) / C4
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
+for fl in "" "-DFIRX_NO_STAGE" "-DFIRX_NO_SUM" "-DFIRX_NO_ATOMICS" "-DFIRX_NO_STAGE -DFIRX_NO_ATOMICS" "-DFIRX_NO_SUM -DFIRX_NO_ATOMICS"; do
+  PYSDR_STAGE2_FLAGS="$fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { echo "build failed: $fl"; grep error /tmp/build.log | head -3; continue; }
+  for w in c1 "c3 --no-psd" c4; do
+    O=gpurun_out/fir_kt; rm -rf $O; mkdir -p $O
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 bench.py --workload $w --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 10 --warmup 3 > $O/bench.json 2> $O/err.txt
+    python3 - "$O" "$fl" "$w" <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'demod_fir' in r['Name']:
+            print('%-36s %-12s %-26s avg us %7.1f' % (sys.argv[2], sys.argv[3], r['Name'].split('::')[-1][:26], float(r['AverageNs']) / 1e3))
+PY
+  done
+done
+cp /tmp/keep.so pysdr_amd/libpysdr_hip.so
