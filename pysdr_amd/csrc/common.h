@@ -155,12 +155,15 @@ int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t st
 
 // ---- stage 2 at FS_OUT (stage2.hip) --------------------------------------------------
 #ifndef PYSDR_BLK_STRIDE
-#define PYSDR_BLK_STRIDE 64
+#define PYSDR_BLK_STRIDE 16
 #endif
 // Words between the per-block accumulators (block peak, noise sum, count) of consecutive blocks.
 // Atomics on one 128-byte line serialise at the L2 / memory side: with the accumulators of 32
-// blocks in a line the FIR kernel spent 50 of its 165 us waiting for them (measured: stride 1 ->
-// 165 us, 64 words = 256 bytes -> 115 us, 1024 -> 118 us).
+// blocks in a line the FIR kernel spent 50 of its 165 us waiting for them (round 2, one atomic per LANE that held a
+// block boundary: stride 1 -> 165 us, 64 words = 256 bytes -> 115 us, 1024 -> 118 us).  Since a wave issues at most two
+// atomics per quantity the FIR kernel no longer cares (round 4, scripts/diag/blkstride_ab.sh, C1: 55.5 / 54.5 / 53.4-57.1 /
+// 55.8 / 55.8 / 56.4 us at 64 / 32 / 16 / 8 / 4 / 1 words) -- but agc_scan_kernel, which gathers them, does: 21.7 / 22.6 /
+// 15.9-16.6 / 15.9 / 14.5 / 13.8 us.  16 words = 64 bytes: the pair costs 70 us where 64 words cost 77.
 constexpr int kBlkStride = PYSDR_BLK_STRIDE;
 
 struct RxDevState {       // one per RX, lives in device memory
