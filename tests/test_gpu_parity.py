@@ -7,6 +7,7 @@ no captured reference I/O exists; this is parity with the build's oracle, which 
 to the reference only where tests/test_oracle_pins.py says so."""
 import ctypes as C
 
+import os
 import numpy as np
 import pytest
 
@@ -689,6 +690,21 @@ def test_batch_of_chunks_with_odd_output_counts_equals_chunked_bit_exact(L):
             assert np.array_equal(iq.view(np.uint32), np.concatenate(iq1[i][lo:hi]).view(np.uint32)), (i, lo)
             assert np.array_equal(am.view(np.uint32), np.concatenate(am1[i][lo:hi]).view(np.uint32)), (i, lo)
     assert g2[3].agc.gain == g1[3].agc.gain and g2[0].agc.maxbuf == g1[0].agc.maxbuf
+
+
+def test_odd_and_ragged_counts_in_every_mode_equal_chunked_bit_exact():
+    """scripts/diag/odd_counts_sweep.py: IQ / LSB / RTTY / AM / CW behind the matrix-core front end (2.048 MS/s, 1001
+    taps) with 170 and 62-63 outputs per chunk, IQ / USB at 8 MS/s with 9, and broadcast FM mono with chunks of 20001
+    and 3333 samples (odd IF and audio counts): batches cut into two or three calls against the chunk-by-chunk loop,
+    baseband and audio bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "diag", "odd_counts_sweep.py")], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=600).stdout.decode()
+    lines = [l for l in out.splitlines() if "odd-count chunks" in l]
+    assert len(lines) == 14, out
+    assert all(l.rstrip().endswith(": OK") for l in lines), out
+    assert sum(int(l.split("odd-count chunks")[1].split(":")[0]) for l in lines) > 500
 
 
 @pytest.mark.parametrize("L,B", [(170666, 120), (3000, 400), (700, 900)])
