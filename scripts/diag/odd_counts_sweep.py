@@ -43,6 +43,11 @@ c2 = so.CONFIGS['C2']
 for mode, af in (('IQ', 10e3), ('USB', 3e3)):
     cfg = dict(c2, rx=[dict(frq=-1.1e6, mode=mode, video_bw=20e3, af_bw=af)])
     case('8 MS/s 255 taps ' + mode, cfg, 1500, 150, [51])
+# six and eight receivers on one stream (the tasks of the vector kernel are dealt out by (branch, RX half) above four)
+modes = [('USB', 3e3), ('CW', 1e3), ('NFM', 0.0), ('AM', 5e3), ('LSB', 3e3), ('IQ', 10e3), ('AM', 5e3), ('NFM', 0.0)]
+for n in (6, 8):
+    cfg = dict(c2, rx=[dict(frq=-1.5e6 + 0.4e6 * i, mode=m, video_bw=20e3, af_bw=af, bfo=700.0 if m == 'CW' else 0.0) for i, (m, af) in enumerate(modes[:n])])
+    case('8 MS/s 255 taps, %d RX' % n, cfg, 2500, 60, [23])
 
 # broadcast FM mono (no pilot loop: every stage is a fixed-order sum): ragged chunk lengths, odd IF / audio counts
 from oracle import wfm_oracle as wo
