@@ -64,6 +64,8 @@ def parse(argv=None):
     ap.add_argument("--overlap-psd", action="store_true", help="PSD on its own stream, unordered w.r.t. the demod")
     ap.add_argument("--serial-psd", action="store_true", help="PSD strictly behind the whole demod (incl. stage 2)")
     ap.add_argument("--no-demod", action="store_true", help="diagnostic: PSD only")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="diagnostic: no HIP events inside the calls of the timed loop (what the live kernel timing costs)")
     ap.add_argument("--tile-bytes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -636,13 +638,19 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    _lib.check(lib.pysdr_set_profile(ctx.h, 1), "profile")
+    # Live kernel timing (HIP events inside the call) on the LAST quarter of the timed steps, at least 4: an event record
+    # costs ~5.5 us of the stream's timeline on this runtime (three per call = 2-4 % of a C1 / C2 step,
+    # scripts: bench.py --no-kernel-events), so the timing is sampled inside the timed region instead of riding on every step
+    ev_steps = 0 if args.no_kernel_events else min(args.steps, 64, max(4, args.steps // 4))
+    _lib.check(lib.pysdr_set_profile(ctx.h, 0), "profile")
 
     if dist is not None:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if ev_steps and i == args.steps - ev_steps:
+            _lib.check(lib.pysdr_set_profile(ctx.h, 1), "profile")
         step()
     sync()
     dt_local = time.perf_counter() - t0
@@ -651,7 +659,7 @@ def main():
     dt = time.perf_counter() - t0
 
     # kernel timings: HIP events on the stream the kernels run on, averaged over the timed steps
-    nev = 0 if (args.no_demod or not rxs) else min(args.steps, 64)
+    nev = 0 if (args.no_demod or not rxs) else ev_steps
     ms = C.c_float(0)
     k1, k2 = [], []
     for back in range(nev):
@@ -662,7 +670,7 @@ def main():
     # per-step spread of the timed loop (the step period on the stream: start of call k-1 -> start of call k,
     # which includes whatever the PSD ordered behind / in front of it took)
     periods = []
-    for back in range(max(0, min(args.steps - 1, 62)) if nev else 0):
+    for back in range(max(0, min(nev - 1, 62)) if nev else 0):
         if lib.pysdr_get_elapsed_ms(ctx.h, 3, back, C.byref(ms)) == 0:
             periods.append(ms.value)
     k1_ms = float(np.mean(k1)) if k1 else float('nan')
@@ -825,6 +833,9 @@ def main():
             "algorithmic_bytes_per_sample": bytes_per_sample_job,
             "note": "per GPU: whole-step wall clock against SURVEY 8(d)'s compulsory bytes per input sample"},
         "kernel_ms": {"front": k1_ms if k1 else None, "stage2": k2_ms, "psd_call": psd_ms},
+        "kernel_events": {"steps": nev, "of": args.steps,
+                          "what": "the last steps of the timed loop carry HIP events inside the call (kernel_ms, roofline, step_ms_stats); "
+                                  "an event record costs ~5.5 us of stream time, so the others run without"},
         "step_ms_stats": ({"min": float(np.min(periods)), "median": float(np.median(periods)), "max": float(np.max(periods)),
                            "n": len(periods), "front_min": float(np.min(k1)), "front_max": float(np.max(k1)),
                            "what": "HIP-event period between consecutive steps on the context's stream over the timed loop"}
