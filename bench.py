@@ -746,7 +746,10 @@ def main():
     if 'wfm' in cfg and rxs:
         sg, pt = C.c_int(0), C.c_int(0)
         _lib.check(lib.pysdr_pll_stats(ctx.h, 0, C.byref(sg), C.byref(pt)), "pll_stats")
-        pll = {"segments": sg.value, "patched_serially": pt.value}
+        jw, jd = C.c_int(0), C.c_float(0)
+        _lib.check(lib.pysdr_pll_join_margin(ctx.h, 0, C.byref(jw), C.byref(jd)), "pll_join_margin")
+        pll = {"segments": sg.value, "patched_serially": pt.value,
+               "widest_join": {"phase_words_of_2^32": jw.value, "tolerance": 512, "integrator_rad_per_sample": jd.value, "tolerance_w": 1e-9}}
     tune = (C.c_int32 * 8)()
     _lib.check(lib.pysdr_get_tuning(ctx.h, tune), "get_tuning")
     sp_tune = (C.c_int32 * 4)()

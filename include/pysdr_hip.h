@@ -119,6 +119,10 @@ int pysdr_agc_get(pysdr_ctx* ctx, int irx, pysdr_agc_state* st);
 int pysdr_pll_stats(pysdr_ctx* ctx, int irx, int* segments, int* patched);
 /* A/B knob for the above: at most `max_segments` per call (1 = the plain serial walk, 0 = default) */
 int pysdr_set_pll_segments(pysdr_ctx* ctx, int max_segments);
+/* WFM2 pilot loop of the last batch: the widest join between two segments of the time-parallel walk BEFORE any patching --
+ * |phase difference| in words of 2^32 (accepted up to 512) and |integrator difference| in rad/sample (up to 1e-9).  A
+ * diagnostic of this build (no reference call site): what a shorter / cheaper warm-up setting (PYSDR_WFM_PLL) is judged by. */
+int pysdr_pll_join_margin(pysdr_ctx* ctx, int irx, int* max_words, float* max_dw);
 /* NFM noise squelch (north_star "AGC/squelch"; design notes sigs/squelch.m:92-145): per chunk the
  * mean |2nd difference| of the discriminator output is smoothed (one pole) and the chunk is
  * muted while it exceeds `thresh`; thresh <= 0 disables (default). */

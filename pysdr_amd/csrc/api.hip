@@ -47,6 +47,7 @@ PllPlan plan_pll(int n, double fs, double bw_hz, double taus, double taus_fast, 
   p.Wfast = taus_fast > 0 ? (((int)std::ceil(taus_fast * tau) + 63) & ~63) : 0;
   p.Wexact = 0;
   p.Wc_hi = p.Wc_mid = 0;
+  p.tail_cap = 0;
   p.coarse_sweeps = 0;
   p.exact_cap = 0;
   if (n < 3 * p.W || k_max <= 1) {
@@ -166,9 +167,13 @@ struct pysdr_ctx {
   // round 4, after the sweeps went from 35 to 22 vector instructions (stage2.hip wfm_pll_walk; scripts/diag/c4_kt.sh, us per
   // segment-kernel launch, same box): 1024 / 1280 / 1536 / 1792 / 2048 segments 388 / 365 / 349-351 / 379 / 370 -- the walk
   // is now as much the latency of one segment's chain as the SIMDs' issue rate, and fewer, longer segments walk less warm-up
-  double wfm_taus = 20.0, wfm_taus_fast = 13.0, wfm_taus_exact = 5.0;
+  // judged by the widest join they leave (pysdr_pll_join_margin, tolerance 512 words; scripts/diag/c4_pll4.sh): exact tail 5 / 4 tau
+  // 107 / 122 words (C4 step 1.170 / 1.160 ms); two sweeps over the first half of the coarse part 280; exact tail at 4 sweeps 422;
+  // both: joins miss; warm-up of 12 / 14 tau instead of 13: 283 / 104
+  double wfm_taus = 20.0, wfm_taus_fast = 13.0, wfm_taus_exact = 4.0;
   int wfm_coarse_sweeps = 3, wfm_kmax = 1536, wfm_tmin = 2048;
   double wfm_taus_hi = 0.0, wfm_taus_mid = 0.0;   // staged coarse warm-up (PllPlan::Wc_hi / Wc_mid) in time constants; 0, 0: one stage
+  int wfm_tail_cap = 0;                // sweeps per block of the exact tail of a warm-up (0: wfm_exact_cap)
   int wfm_exact_cap = 5;               // sweeps per block of the pilot loop's exact walks (0: to the bit-stable fixed point)
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
@@ -642,7 +647,9 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
       double a = c->wfm_taus, b = c->wfm_taus_fast, x = c->wfm_taus_exact;
       int sw = c->wfm_coarse_sweeps, km = c->wfm_kmax, tm = c->wfm_tmin, xc = c->wfm_exact_cap;
       double th = c->wfm_taus_hi, tmid = c->wfm_taus_mid;
-      const int got = sscanf(e, "%lf,%lf,%lf,%d,%d,%d,%d,%lf,%lf", &a, &b, &x, &sw, &km, &tm, &xc, &th, &tmid);
+      int tc = c->wfm_tail_cap;
+      const int got = sscanf(e, "%lf,%lf,%lf,%d,%d,%d,%d,%lf,%lf,%d", &a, &b, &x, &sw, &km, &tm, &xc, &th, &tmid, &tc);
+      if (got >= 10 && tc >= 0) c->wfm_tail_cap = tc;
       if (got >= 9 && th >= 0 && tmid >= 0) { c->wfm_taus_hi = th; c->wfm_taus_mid = tmid; }
       if (got >= 7 && xc >= 0) c->wfm_exact_cap = xc;
       if (got >= 1 && a > 0) c->wfm_taus = a;
@@ -853,6 +860,18 @@ int pysdr_pll_stats(pysdr_ctx* c, int irx, int* segments, int* patched) {
   return PYSDR_OK;
 }
 
+int pysdr_pll_join_margin(pysdr_ctx* c, int irx, int* max_words, float* max_dw) {
+  if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  RxDevState d;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (max_words) *max_words = d.pll_join_words;
+  if (max_dw) *max_dw = d.pll_join_dw;
+  return PYSDR_OK;
+}
+
 int pysdr_set_pll_segments(pysdr_ctx* c, int max_segments) {
   if (!c || max_segments < 0) return PYSDR_ERR_ARG;
   c->pll_kmax = max_segments;
@@ -1052,6 +1071,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     w.pll = plan_pll(n1, fs1, kWfmPllBwHz, c->wfm_taus, c->wfm_taus_fast, c->wfm_tmin,
                      c->pll_kmax > 0 ? std::min(c->pll_kmax, c->wfm_kmax) : c->wfm_kmax, c->d_pllseg);
     w.pll.exact_cap = c->wfm_exact_cap;
+    w.pll.tail_cap = c->wfm_tail_cap;
     if (c->wfm_coarse_sweeps > 0 && w.pll.K > 1) {
       const double tau = fs1 / (kPllZetaPlan * 2.0 * M_PI * kWfmPllBwHz);
       w.pll.Wexact = ((int)std::ceil(c->wfm_taus_exact * tau) + 63) & ~63;

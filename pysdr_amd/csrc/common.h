@@ -176,6 +176,8 @@ struct RxDevState {       // one per RX, lives in device memory
   int sq_open;
   int pll_segments;         // time-parallel PLL of the last call: segments run ...
   int pll_patched;          // ... and segments the serial patch-up pass had to redo
+  int pll_join_words;       // pilot loop: the widest join of the last call's first pass, |phase difference| in words of 2^32 (tolerance 512)
+  float pll_join_dw;        // ... and the widest integrator difference, rad/sample (tolerance 1e-9)
   int wfm_slope_ok;         // the last call ran in segments and none had to be patched: wfm_slope is usable
   int wfm_redo;             // this call's short warm-ups did not meet (stream discontinuity): run the long ones
   double wfm_slope;         // its mean pilot-phase increment per sample beyond fword0 (words of 2^32)
@@ -198,6 +200,7 @@ struct PllPlan {
   int coarse_sweeps;
   int Wc_hi, Wc_mid;        // staged coarse part (0, 0: all of it at coarse_sweeps): the Wc_hi samples in front of the exact tail get
                             // coarse_sweeps, the Wc_mid samples in front of those coarse_sweeps - 1, whatever lies before coarse_sweeps - 2 (>= 1)
+  int tail_cap;             // sweeps per block of the exact TAIL of a warm-up (0: exact_cap)
   int exact_cap;            // sweeps per block of the "exact" walks (pilot loop; 0: until a sweep reproduces its input bit for bit)
   uint32_t* seg;            // [nrx][K][4]: S.phase, S.w, E.phase, E.w (float fields as bits)
 };

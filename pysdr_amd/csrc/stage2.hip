@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
         wfm_pll_walk<false>(a, a.w[r], wb, sx, ph, w, lane, pl.coarse_sweeps);
       }
     }
-    wfm_pll_walk<false>(a, a.w[r], sx, s0, ph, w, lane, xcap);
+    wfm_pll_walk<false>(a, a.w[r], sx, s0, ph, w, lane, pl.tail_cap > 0 ? pl.tail_cap : xcap);
   }
   uint32_t* sg = pl.seg + ((size_t)r * pl.K + k) * 4;
   if (lane == 0) { sg[0] = ph; sg[1] = __float_as_uint(w); }
@@ -1021,6 +1021,8 @@ __global__ __launch_bounds__(64) void wfm_pll_check_kernel(const WfmArgs a) {
   RxDevState* st = a.state + r;
   const PllPlan& pl = a.pll;
   int redo = 0;
+  int jw = 0;
+  float jd = 0.f;
   if (pl.Wfast > 0 && st->wfm_slope_ok && pl.K > 1) {
     const uint32_t* sg = pl.seg + (size_t)r * pl.K * 4;
     int miss = 0;
@@ -1041,11 +1043,21 @@ __global__ __launch_bounds__(64) void wfm_pll_check_kernel(const WfmArgs a) {
         const int kk = base + 64 * u + lane;
         const bool mm = kk < pl.K && wfm_state_differs(e[u].x, __uint_as_float(e[u].y), b[u].x, __uint_as_float(b[u].y));
         miss += __popcll(__ballot(mm));
+        if (kk < pl.K) {
+          const int d = (int)(e[u].x - b[u].x);
+          jw = max(jw, d < 0 ? -d : d);
+          jd = fmaxf(jd, fabsf(__uint_as_float(e[u].y) - __uint_as_float(b[u].y)));
+        }
       }
     }
     redo = miss > 2;
   }
+  // how close the warm-ups came (pysdr_pll_join_margin: what a cheaper warm-up setting has to be judged by)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { jw = max(jw, __shfl_xor(jw, o)); jd = fmaxf(jd, __shfl_xor(jd, o)); }
   if (lane == 0) {
+    st->pll_join_words = jw;
+    st->pll_join_dw = jd;
     st->wfm_redo = redo;
     if (redo) st->wfm_slope_ok = 0;
   }
