@@ -784,7 +784,7 @@ def main():
     front_name = ((("mixdec_mfma_kernel (f32 MFMA, shifted-tap columns; " if mfma_on else f"mixdec_kernel<{nrx}> (") +
                    "fused NCO mix + polyphase decimate, all RX)") if not is_wfm else
                   (("mixdec_mfma_kernel<1/40>" if mfma_on else "mixdec_kernel<1,16>") +
-                   " + wfm_disc/pll + resamp_branch_kernel (FM front end: IF decimate, discriminator, pilot PLL, audio resample)"))
+                   " + wfm_disc/pll + resamp_wave_kernel (FM front end: IF decimate, discriminator, pilot PLL, audio resample)"))
     r_front = roof(front_name, k1_bytes, k1_ms if k1 else None,
                    measured_traffic(args, nrx, B, "mixdec", ["mixdec_mfma.hip", "mixdec_mfma_geom.h"] if (mfma_on and not is_wfm)
                                     else (["mixdec_mfma.hip", "mixdec_mfma_geom.h", "resamp_small.hip"] if mfma_on else ["mixdec.hip"])))

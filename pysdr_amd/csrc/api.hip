@@ -154,7 +154,8 @@ struct pysdr_ctx {
   int tile_bytes = 0, threads = 1024;  // per LDS buffer (two per workgroup); 0 = as large as fits
   int wgs_per_cu = 1, num_cus = 256;
   int grid_override = 0;               // PYSDR_MIXDEC_GRID: workgroups of the mix+decimate launches (tests: many tiles per workgroup in a small call)
-  int resamp_plain = 0;                // PYSDR_RESAMP_PLAIN=1: the audio resampler of broadcast FM one output per thread (resamp_small_kernel) instead of branch-major (A/B)
+  int resamp_plain = 0;                // PYSDR_RESAMP_PLAIN: the audio resampler of broadcast FM 0 = a wave per branch, taps in scalar registers (resamp_wave_kernel),
+                                       // 1 = one output per thread (resamp_small_kernel), 2 = a half-wave per branch (resamp_branch_kernel) (A/B)
   int mfma_enable = 1;                 // long single-RX prototypes on the matrix cores (mixdec_mfma.hip); 0: VALU form (A/B)
   int dbg_flags = 0, yflush_cap = 0;      // tuning / diagnostic switches, read from the environment once
   int am_pll_waves = -1;                  // PYSDR_AM_PLL_WAVES=1 / 0: force the wave- / lane-per-segment carrier loop (A/B runs); -1 = by size
@@ -640,7 +641,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   { const char* e = tuning_env("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0) c->yflush_cap = atoi(e); }
   { const char* e = tuning_env("PYSDR_AM_PLL_WAVES"); if (e && *e) c->am_pll_waves = atoi(e) > 0 ? 1 : 0; }
   { const char* e = tuning_env("PYSDR_MIXDEC_MFMA"); if (e && *e) c->mfma_enable = atoi(e) ? 1 : 0; }
-  { const char* e = tuning_env("PYSDR_RESAMP_PLAIN"); if (e && *e) c->resamp_plain = atoi(e) ? 1 : 0; }
+  { const char* e = tuning_env("PYSDR_RESAMP_PLAIN"); if (e && *e) c->resamp_plain = atoi(e); }
   { const char* e = tuning_env("PYSDR_MIXDEC_GRID"); if (e && atoi(e) > 0) c->grid_override = atoi(e); }
   { const char* e = tuning_env("PYSDR_WFM_PLL");
     if (e && *e) {

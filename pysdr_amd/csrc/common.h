@@ -84,7 +84,7 @@ size_t mixdec_lds_bytes(const MixDecArgs& a);
 
 // one RX, short prototype, small DOWN/UP, no raw peak (resamp_small.hip): the fs1 -> FS_OUT stage of broadcast FM
 int resamp_small_span(int up, int down, int kpad);   // LDS samples a workgroup stages; 0 = shape not eligible
-int launch_resamp_small(const MixDecArgs& a, int grid_cap, int plain, hipStream_t st);   // grid_cap > 0: at most that many workgroups (tests); plain: the one-output-per-thread form (A/B)
+int launch_resamp_small(const MixDecArgs& a, int grid_cap, int plain, hipStream_t st);   // grid_cap > 0: at most that many workgroups (tests); plain: 0 = wave per branch with scalar taps, 1 = one output per thread, 2 = half-wave per branch (A/B)
 
 // ---- mix + decimate on the matrix cores, one RX with a long prototype (mixdec_mfma.hip) ----
 struct MfmaPlan;

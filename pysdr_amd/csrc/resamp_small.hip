@@ -10,6 +10,7 @@
 // not memory.  Here ONE thread owns one output: 64 x (two 8-byte LDS reads + 4 FMAs), no cross-lane step; a workgroup's
 // 256 outputs span ~1400 consecutive inputs, staged once into LDS together with the (padded) tap table.
 // The sum runs over k = 0 .. kpad-1 in order whatever the call, tile or thread: batch == chunk by chunk bit for bit.
+#include <mutex>
 #include "common.h"
 #include "mixdec_geom.h"
 #include "hist_roll.h"
@@ -187,7 +188,86 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
   }
 }
 
+// ---- the same stage with a WAVE per polyphase branch and the taps in SCALAR registers.  resamp_branch_kernel is still bound by
+// the LDS: a broadcast read costs it what any 512-byte read costs, so a tap is 8 LDS cycles per wave (tap + sample) on a
+// unit that serves four SIMDs -- 27 of its 47 us.  With ALL 64 lanes of a wave on one branch the tap is wave-uniform: it
+// comes through the scalar cache (s_load from the constant address space) and enters the FMAs as an SGPR operand; the LDS
+// serves the samples only.  A tile is then UP x 64 outputs (8000 input samples at 24/125: 64.5 KB + 12 KB of outputs,
+// two workgroups per CU), a wave takes the branches w, w + nwaves, ...  Same sums in the same order: bit for bit the audio of
+// the other two forms (test_wbfm_audio_resampler_forms_agree_bit_for_bit).
+typedef float rs_cf2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) rs_cf2* rs_ctaps;
+
+__global__ __launch_bounds__(1024) void resamp_wave_kernel(const MixDecArgs a, int span_cap, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float2 rs_lds[];
+  const int tile_out = a.up * 64;
+  float2* const xs = rs_lds;                       // [span_cap] input span of one tile
+  float2* const os = rs_lds + span_cap;            // [tile_out] the tile's outputs, in output order
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nth >> 6, l = tid & 63;
+  if (blockIdx.x == 0 && a.hist_new != nullptr)    // the decimator's history roll rides in this launch (hist_roll.h)
+    roll_history(a.x, a.hist, a.hist_new, a.hist_len, a.n_total, a.zero, a.zero_n, tid, nth);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int i0 = tile * tile_out;
+    const int n_here = (a.n_out - i0 < tile_out) ? a.n_out - i0 : tile_out;
+    uint32_t q0, r0, q1, r1;
+    divmod_magic(a.t0 + (uint32_t)i0 * (uint32_t)a.down, (uint32_t)a.up, a.magic, q0, r0);
+    divmod_magic(a.t0 + (uint32_t)(i0 + n_here - 1) * (uint32_t)a.down, (uint32_t)a.up, a.magic, q1, r1);
+    const int lo = (int)q0 - (a.kpad - 1), hi = (int)q1;
+    __syncthreads();                               // the previous tile's reads of xs / os are done
+    if (lo >= 0 && (uint32_t)hi < a.n_total) {
+      for (int j = tid; j <= hi - lo; j += nth) xs[j] = a.x[lo + j];
+    } else {
+      for (int j = tid; j <= hi - lo; j += nth) {
+        const int rel = lo + j;
+        float2 v = make_float2(0.f, 0.f);
+        if (rel >= 0) { if ((uint32_t)rel < a.n_total) v = a.x[rel]; }
+        else if (rel >= -a.hist_len) v = a.hist[a.hist_len + rel];
+        xs[j] = v;
+      }
+    }
+    __syncthreads();
+    for (int b = wave; b < a.up; b += nwaves) {    // this wave's branches: lane l owns output l UP + b of the tile
+      const int iloc = l * a.up + b;
+      // (t0 + (i0 + iloc) DOWN) mod UP is the same for every lane and every tile: i0 and l UP are multiples of UP
+      uint32_t qb, pb;
+      divmod_magic(a.t0 + (uint32_t)iloc * (uint32_t)a.down, (uint32_t)a.up, a.magic, qb, pb);
+      const rs_ctaps tp = (rs_ctaps)(uintptr_t)a.taps + __builtin_amdgcn_readfirstlane((int)pb) * a.kpad;
+      const uint32_t q = (uint32_t)(i0 / a.up) * (uint32_t)a.down + qb;
+      const float2* xp = xs + ((int)q - lo);       // x[n_m]; tap k reads xp[-k]
+      float sr = 0.f, si = 0.f;
+      if (iloc < n_here) {
+#pragma unroll 8
+        for (int k = 0; k < a.kpad; ++k) {
+          const rs_cf2 g = tp[k];
+          const float2 v = xp[-k];
+          sr = fmaf(g.x, v.x, sr);
+          sr = fmaf(-g.y, v.y, sr);
+          si = fmaf(g.x, v.y, si);
+          si = fmaf(g.y, v.x, si);
+        }
+        const uint32_t ph = a.phase0[0] + a.fword[0] * q;
+        const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+        const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+        os[iloc] = make_float2(sr * cs - si * sn, sr * sn + si * cs);
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < n_here; j += nth) a.y[0][i0 + j] = os[j];
+  }
+}
+
 }  // namespace
+
+// LDS of the wave-per-branch form: input span of UP x 64 outputs + the outputs; 0 = not eligible
+static size_t resamp_wave_lds(int up, int down, int kpad, int* span_out) {
+  if (up > 32 || up < 2) return 0;
+  const long span = 64L * down + kpad + 4;
+  const size_t bytes = ((size_t)span + (size_t)up * 64) * sizeof(float2);
+  if (bytes > 78 * 1024) return 0;                 // two workgroups per CU
+  *span_out = (int)span;
+  return bytes;
+}
 
 // LDS of the branch-major form: input span of UP x 32 outputs + the outputs + the tap table; 0 = not eligible
 static size_t resamp_branch_lds(int up, int down, int kpad, int* span_out) {
@@ -218,7 +298,31 @@ int launch_resamp_small(const MixDecArgs& a, int grid_cap, int plain, hipStream_
   // same path -- and both paths sum every output in the same order anyway)
   int bspan = 0;
   const size_t blds = resamp_branch_lds(a.up, a.down, a.kpad, &bspan);
-  if (blds > 0 && !plain) {
+  int wspan = 0;
+  const size_t wlds = resamp_wave_lds(a.up, a.down, a.kpad, &wspan);
+  if (wlds > 0 && plain == 0) {
+    static std::mutex attr_mu;
+    static uint64_t attr_done = 0;
+    {
+      int dev = 0;
+      PYSDR_HIP_CHECK(hipGetDevice(&dev));
+      std::lock_guard<std::mutex> lk(attr_mu);
+      if (!((attr_done >> (dev & 63)) & 1ull)) {
+        PYSDR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resamp_wave_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done |= 1ull << (dev & 63);
+      }
+    }
+    const int tile_out = a.up * 64;
+    const int ntiles = (a.n_out + tile_out - 1) / tile_out;
+    int wgrid = ntiles < 512 ? ntiles : 512;
+    if (grid_cap > 0 && wgrid > grid_cap) wgrid = grid_cap;
+    const int nw = (a.up + 1) / 2;                         // two branches per wave
+    hipLaunchKernelGGL(resamp_wave_kernel, dim3(wgrid), dim3(64 * nw), wlds, st, a, wspan, ntiles);
+    PYSDR_HIP_CHECK(hipGetLastError());
+    return PYSDR_OK;
+  }
+  if (blds > 0 && plain != 1) {
     const int tile_out = a.up * kRbL;
     const int ntiles = (a.n_out + tile_out - 1) / tile_out;
     int bgrid = ntiles < 512 ? ntiles : 512;               // two workgroups per CU: one stages while the other multiplies

@@ -559,10 +559,10 @@ def test_convolver_streaming_fir_matches_scipy():
 
 
 def test_wbfm_audio_resampler_forms_agree_bit_for_bit(monkeypatch):
-    """The fs1 -> FS_OUT stage of broadcast FM (24/125, 64 taps per branch) runs branch-major (resamp_branch_kernel: a
-    half-wave per polyphase branch, the next tile's input in registers while this one is summed) -- and, under
-    PYSDR_TUNING=1 PYSDR_RESAMP_PLAIN=1, one output per thread (resamp_small_kernel).  Both sum an output's taps in the
-    same order: the audio of a 12-chunk batch is identical bit for bit, also with the launches held to three workgroups
+    """The fs1 -> FS_OUT stage of broadcast FM (24/125, 64 taps per branch) runs with a WAVE per polyphase branch and the
+    taps in scalar registers (resamp_wave_kernel; "branch" below) -- and, under PYSDR_TUNING=1, PYSDR_RESAMP_PLAIN=1 one
+    output per thread (resamp_small_kernel), = 2 a half-wave per branch with the next tile's input in registers
+    (resamp_branch_kernel).  All three sum an output's taps in the same order: the audio of a 12-chunk batch is identical bit for bit, also with the launches held to three workgroups
     (PYSDR_MIXDEC_GRID: every workgroup then walks several tiles, the register prefetch included)."""
     from oracle import wfm_oracle as wo
     from pysdr_amd import sig_proc
@@ -571,7 +571,8 @@ def test_wbfm_audio_resampler_forms_agree_bit_for_bit(monkeypatch):
     x = wo.synth_wfm(fs, B * L, 4)
     out = {}
     for name, env in (("branch", {}), ("plain", {"PYSDR_RESAMP_PLAIN": "1"}), ("branch3", {"PYSDR_MIXDEC_GRID": "3"}),
-                      ("plain3", {"PYSDR_RESAMP_PLAIN": "1", "PYSDR_MIXDEC_GRID": "3"})):
+                      ("plain3", {"PYSDR_RESAMP_PLAIN": "1", "PYSDR_MIXDEC_GRID": "3"}),
+                      ("half", {"PYSDR_RESAMP_PLAIN": "2"}), ("half3", {"PYSDR_RESAMP_PLAIN": "2", "PYSDR_MIXDEC_GRID": "3"})):
         for k in ("PYSDR_RESAMP_PLAIN", "PYSDR_MIXDEC_GRID"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("PYSDR_TUNING", "1")
@@ -586,7 +587,7 @@ def test_wbfm_audio_resampler_forms_agree_bit_for_bit(monkeypatch):
         ctx.close()
     ref = out["branch"]
     assert len(ref[0]) == int(ref[1].sum()) and len(ref[0]) > 12000
-    for name in ("plain", "branch3", "plain3"):
+    for name in ("plain", "branch3", "plain3", "half", "half3"):
         assert np.array_equal(out[name][1], ref[1]), name
         assert np.array_equal(out[name][0].view(np.uint32), ref[0].view(np.uint32)), name
     o = wo.WfmReceiver(fs, 48e3, 300e3, stereo=True, ntaps_dec=255, dtype=np.float32)
