@@ -249,6 +249,7 @@ int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, 
 static void check_plan(const PllPlan& p, int n, int nrx) {
   SAN_CHECK(p.K >= 1 && p.T >= 64 && (long long)p.K * p.T >= n && (long long)(p.K - 1) * p.T < std::max(n, 1), "PLL plan K %d T %d n %d", p.K, p.T, n);
   SAN_CHECK(p.W % 64 == 0 && p.Wfast % 64 == 0 && p.Wexact % 64 == 0 && p.T % 64 == 0, "PLL plan alignment");
+  SAN_CHECK(p.Wc_hi % 64 == 0 && p.Wc_mid % 64 == 0 && p.Wc_hi >= 0 && p.Wc_mid >= 0 && p.tail_cap >= 0, "staged warm-up plan");
   write_all(p.seg, (size_t)nrx * p.K * 4);
 }
 
