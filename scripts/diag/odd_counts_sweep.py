@@ -45,7 +45,7 @@ for mode, af in (('IQ', 10e3), ('USB', 3e3)):
     case('8 MS/s 255 taps ' + mode, cfg, 1500, 150, [51])
 # six and eight receivers on one stream (the tasks of the vector kernel are dealt out by (branch, RX half) above four)
 modes = [('USB', 3e3), ('CW', 1e3), ('NFM', 0.0), ('AM', 5e3), ('LSB', 3e3), ('IQ', 10e3), ('AM', 5e3), ('NFM', 0.0)]
-for n in (6, 8):
+for n in (2, 3, 5, 6, 7, 8):
     cfg = dict(c2, rx=[dict(frq=-1.5e6 + 0.4e6 * i, mode=m, video_bw=20e3, af_bw=af, bfo=700.0 if m == 'CW' else 0.0) for i, (m, af) in enumerate(modes[:n])])
     case('8 MS/s 255 taps, %d RX' % n, cfg, 2500, 60, [23])
 

@@ -451,7 +451,8 @@ def test_quad_mixer_matches_oracle_nco():
     assert relerr(g.quad_mixer(x), o.quad_mixer(x)) <= TOL
 
 
-@pytest.mark.parametrize("chunk,nfft,overlap", [(32768, 65536, 0.0), (4096, 8192, 0.5), (1000, 2048, 0.0)])
+@pytest.mark.parametrize("chunk,nfft,overlap", [(32768, 65536, 0.0), (4096, 8192, 0.5), (1000, 2048, 0.0),
+                                                (32768, 65536, 0.5), (32768, 65536, 0.75)])   # the four-step pair with overlapping frames
 def test_spectrum_periodogram(chunk, nfft, overlap):
     from pysdr_amd import sig_proc
     cfg = so.CONFIGS['C3']
@@ -695,7 +696,7 @@ def test_batch_of_chunks_with_odd_output_counts_equals_chunked_bit_exact(L):
 
 def test_odd_and_ragged_counts_in_every_mode_equal_chunked_bit_exact():
     """scripts/diag/odd_counts_sweep.py: IQ / LSB / RTTY / AM / CW behind the matrix-core front end (2.048 MS/s, 1001
-    taps) with 170 and 62-63 outputs per chunk, IQ / USB at 8 MS/s with 9, six and eight receivers on one stream with 15, and broadcast FM mono with chunks of 20001
+    taps) with 170 and 62-63 outputs per chunk, IQ / USB at 8 MS/s with 9, two to eight receivers on one stream with 15, and broadcast FM mono with chunks of 20001
     and 3333 samples (odd IF and audio counts): batches cut into two or three calls against the chunk-by-chunk loop,
     baseband and audio bit for bit."""
     import subprocess, sys
@@ -703,7 +704,7 @@ def test_odd_and_ragged_counts_in_every_mode_equal_chunked_bit_exact():
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "diag", "odd_counts_sweep.py")], stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, timeout=600).stdout.decode()
     lines = [l for l in out.splitlines() if "odd-count chunks" in l]
-    assert len(lines) == 16, out
+    assert len(lines) == 20, out
     assert all(l.rstrip().endswith(": OK") for l in lines), out
     assert sum(int(l.split("odd-count chunks")[1].split(":")[0]) for l in lines) > 500
 
