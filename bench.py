@@ -46,12 +46,17 @@ TUNING_ENV = ("PYSDR_TUNING", "PYSDR_MIXDEC_WGS", "PYSDR_MIXDEC_YFLUSH", "PYSDR_
               "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_PSD_STREAMS", "PYSDR_PSD_PACKED", "PYSDR_WFM_PLL", "PYSDR_MIXDEC_MFMA", "PYSDR_MIXDEC_GRID", "PYSDR_RESAMP_PLAIN",
               "PYSDR_AM_PLL_WAVES", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS", "PYSDR_MFMA_FLAGS")
 OTHER_CONFIGS = ("c1", "c2", "c4")      # the single-GPU BASELINE configurations the default line carries next to C3
+# A timed bracket carries ~1 ms that no step owns (the first steps after the idle barrier run slower: 10 / 30 / 100 / 300 steps of
+# C1 = 0.422 / 0.398 / 0.373 / 0.369 ms per step): the workloads whose step is a fraction of a millisecond time at least this
+# many steps (~60 ms) -- as other_configs children whatever K the driver passed for the C3 loop, and by default on their own.
+MIN_STEPS = {"c1": 150, "c2": 120, "c4": 60, "c4mono": 80}
 
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 30 for c3; for the short-step workloads as many as make ~60 ms, see MIN_STEPS)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(DEFAULT_CHUNKS))
     ap.add_argument("--split", default="stream", choices=["stream", "rx"])
@@ -83,7 +88,10 @@ def parse(argv=None):
                     help="the default command (workload c3, 1 GPU) also runs c1, c2 and c4 at their default batch for --steps "
                          "steps each, in child processes AFTER its own timed loop, and reports them as `other_configs` "
                          "(never as `value`); this switch skips that")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = MIN_STEPS.get(args.workload, 30)
+    return args
 
 
 # ---------------------------------------------------------------------------------------------
@@ -475,7 +483,7 @@ def other_configs(args):
     every configuration, not only the headline one ("Next round" 2).  Never `value`."""
     res = {}
     for w in OTHER_CONFIGS:
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", str(args.steps), "--warmup",
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", str(max(args.steps, MIN_STEPS.get(w, 0))), "--warmup",
                str(args.warmup), "--no-cpu-baseline", "--no-host-fed", "--no-other-configs"]
         if args.verify is not None:
             cmd.append("--verify" if args.verify else "--no-verify")
