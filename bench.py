@@ -50,6 +50,9 @@ OTHER_CONFIGS = ("c1", "c2", "c4")      # the single-GPU BASELINE configurations
 # C1 = 0.422 / 0.398 / 0.373 / 0.369 ms per step): the workloads whose step is a fraction of a millisecond time at least this
 # many steps (~60 ms) -- as other_configs children whatever K the driver passed for the C3 loop, and by default on their own.
 MIN_STEPS = {"c1": 150, "c2": 120, "c4": 60, "c4mono": 80}
+# ... and warm up for ~20 ms (five C1 steps are 2 ms of GPU work: the clocks have not come up yet -- 30 timed steps after 5 / 50 / 300
+# warm-up steps = 0.390 / 0.364 / 0.367 ms per step; C3's five steps are 15 ms, and 20 or 60 change nothing there)
+MIN_WARMUP = {"c1": 60, "c2": 40, "c4": 20, "c4mono": 25}
 
 
 def parse(argv=None):
@@ -57,7 +60,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
                     help="timed steps (default: 30 for c3; for the short-step workloads as many as make ~60 ms, see MIN_STEPS)")
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 5 for c3, MIN_WARMUP for the short-step workloads)")
     ap.add_argument("--workload", default="c3", choices=sorted(DEFAULT_CHUNKS))
     ap.add_argument("--split", default="stream", choices=["stream", "rx"])
     ap.add_argument("--chunks", type=int, default=0, help="chunks per step (batch resident in HBM); 0 = workload default")
@@ -91,6 +94,8 @@ def parse(argv=None):
     args = ap.parse_args(argv)
     if args.steps is None:
         args.steps = MIN_STEPS.get(args.workload, 30)
+    if args.warmup is None:
+        args.warmup = MIN_WARMUP.get(args.workload, 5)
     return args
 
 
@@ -484,7 +489,7 @@ def other_configs(args):
     res = {}
     for w in OTHER_CONFIGS:
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", str(max(args.steps, MIN_STEPS.get(w, 0))), "--warmup",
-               str(args.warmup), "--no-cpu-baseline", "--no-host-fed", "--no-other-configs"]
+               str(max(args.warmup, MIN_WARMUP.get(w, 0))), "--no-cpu-baseline", "--no-host-fed", "--no-other-configs"]
         if args.verify is not None:
             cmd.append("--verify" if args.verify else "--no-verify")
         t0 = time.time()
