@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Throughput of the pySDR receiver hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c1|c2|c3|c4|c4mono] [--split stream|rx]
+    python bench.py --gpus N --steps K --warmup W [--workload c1|c1synch|c2|c3|rx6|c4|c4mono] [--split stream|rx]
 
 One "step" = one pass of the hot path over one device-resident batch of `--chunks` chunks of one
 synthetic wideband stream.  Default workload = SURVEY.md 8(d) config C3: the fused mix+decimate
 kernel for all 4 sub-receivers (USB/CW/NBFM/AM), the 48 kHz detector/AF/AGC kernels, and the RF
 PSD (chunk 32768 -> 64k FFT, every sample PSD'd).  The other BASELINE configurations run through
-the same tool: c1 (am.py path: 2.048 MS/s, 1 RX AM, 1001 taps), c2 (8 MS/s, 1 RX NBFM), c4 / c4mono
-(10 MS/s broadcast FM, pilot-PLL stereo / mono).
+the same tool: c1 (am.py path: 2.048 MS/s, 1 RX AM, 1001 taps), c1synch (the same with the AM-Synch carrier PLL,
+Tables.py:34, receiver.py:649), c2 (8 MS/s, 1 RX NBFM), rx6 (C3's stream through MAX_RX = 6 sub-receivers, params.py:33,
+no PSD), c4 / c4mono (10 MS/s broadcast FM, pilot-PLL stereo / mono).
 
 N > 1: one process per GPU.  Started by `torch.distributed.run` (RANK/LOCAL_RANK/WORLD_SIZE in the
 environment) or, when those are absent, by this script itself: the parent starts N children
@@ -41,18 +42,20 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PSD_CHUNK, PSD_NFFT = 32768, 65536
-DEFAULT_CHUNKS = {"c1": 4096, "c2": 2048, "c3": 2048, "c4": 2048, "c4mono": 2048}
+DEFAULT_CHUNKS = {"c1": 4096, "c1synch": 4096, "c2": 2048, "c3": 2048, "rx6": 2048, "c4": 2048, "c4mono": 2048}
 TUNING_ENV = ("PYSDR_TUNING", "PYSDR_MIXDEC_WGS", "PYSDR_MIXDEC_YFLUSH", "PYSDR_DEBUG_FLAGS", "PYSDR_PSD_GROUP",
               "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_PSD_STREAMS", "PYSDR_PSD_PACKED", "PYSDR_WFM_PLL", "PYSDR_MIXDEC_MFMA", "PYSDR_MIXDEC_GRID", "PYSDR_RESAMP_PLAIN",
-              "PYSDR_AM_PLL_WAVES", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS", "PYSDR_MFMA_FLAGS")
-OTHER_CONFIGS = ("c1", "c2", "c4")      # the single-GPU BASELINE configurations the default line carries next to C3
+              "PYSDR_AM_PLL", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS", "PYSDR_MFMA_FLAGS")
+# the single-GPU configurations the default line carries next to C3: BASELINE.json configs[0], [1], [3], and the three the
+# reference also runs that the driver's record did not hold until round 5 (mono broadcast FM, MAX_RX = 6, AM-Synch)
+OTHER_CONFIGS = ("c1", "c2", "c4", "c4mono", "rx6", "c1synch")
 # A timed bracket carries ~1 ms that no step owns (the first steps after the idle barrier run slower: 10 / 30 / 100 / 300 steps of
 # C1 = 0.422 / 0.398 / 0.373 / 0.369 ms per step): the workloads whose step is a fraction of a millisecond time at least this
 # many steps (~60 ms) -- as other_configs children whatever K the driver passed for the C3 loop, and by default on their own.
-MIN_STEPS = {"c1": 150, "c2": 120, "c4": 60, "c4mono": 80}
+MIN_STEPS = {"c1": 150, "c1synch": 150, "c2": 120, "rx6": 80, "c4": 60, "c4mono": 80}
 # ... and warm up for ~20 ms (five C1 steps are 2 ms of GPU work: the clocks have not come up yet -- 30 timed steps after 5 / 50 / 300
 # warm-up steps = 0.390 / 0.364 / 0.367 ms per step; C3's five steps are 15 ms, and 20 or 60 change nothing there)
-MIN_WARMUP = {"c1": 60, "c2": 40, "c4": 20, "c4mono": 25}
+MIN_WARMUP = {"c1": 60, "c1synch": 60, "c2": 40, "rx6": 25, "c4": 20, "c4mono": 25}
 
 
 def parse(argv=None):
@@ -78,7 +81,11 @@ def parse(argv=None):
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive ingest-ring figure")
-    ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks timed on the CPU oracle (0 = about 10 s worth)")
+    ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks timed on the CPU oracle (0 = about --cpu-seconds worth)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="size of the CPU-oracle sample when --cpu-chunks is 0")
+    ap.add_argument("--cpu-only", action="store_true",
+                    help="time the CPU oracle on this workload and print {'cpu_baseline': ...}; never touches the GPU "
+                         "(other_configs runs one such child per configuration, side by side)")
     ap.add_argument("--psd-hz", type=float, default=20.0,
                     help="c3, 1 GPU: also time the job with ONE 64k PSD frame per SRATE/psd_hz samples -- the reference's real "
                          "duty (20 Hz timer, pySDR.py:252-256, gui.py:1264-1267) -- reported as `at_reference_psd_duty`, never as "
@@ -149,6 +156,19 @@ def workload_cfg(args):
         if w == "c3" and args.nrx:
             cfg['rx'] = RX6[:args.nrx]
         return cfg
+    if w == "rx6":                       # the reference's MAX_RX (params.py:33) on C3's stream, demod only
+        return dict(CONFIGS['C3'], rx=RX6[:6])
+    if w == "c1synch":
+        # C1 with the carrier PLL in the chain (MODES, Tables.py:34).  The synthetic stream is a loop of 8 chunks: the
+        # carrier sits on the nearest frequency that closes the loop without a phase jump (17066 cycles in 8 x 43690
+        # samples: 99997.6 Hz, the receiver stays tuned to 100 kHz = 2.4 Hz off) -- no station jumps by 146 degrees every
+        # 170 ms, and a loop that re-acquires forever would be timed on its pull-in, not on tracking
+        cfg = dict(CONFIGS['C1'])
+        nloop = 8 * int(1024 * 128 / 3)
+        f = round(100e3 * nloop / cfg['fs']) * cfg['fs'] / nloop
+        cfg['carriers'] = [dict(cfg['carriers'][0], f=f)]
+        cfg['rx'] = [dict(cfg['rx'][0], mode='AM-Synch')]
+        return cfg
     return dict(fs=10e6, fs_out=48e3, ntaps_dec=255, wfm=('WFM2' if w == "c4" else 'WFM'),
                 rx=[dict(frq=300e3, mode=('WFM2' if w == "c4" else 'WFM'), video_bw=200e3)])
 
@@ -193,7 +213,7 @@ def oracle_receivers(cfg):
     return so.make_receivers(cfg, np.float32)
 
 
-def cpu_baseline(cfg, nchunks, with_psd, seed):
+def cpu_baseline(cfg, nchunks, with_psd, seed, seconds=10.0):
     """The NumPy/SciPy oracle (kind "port": the reference's own sig_proc is absent) on a
     bounded sample of the same workload, one host core."""
     from oracle import sdr_oracle as so
@@ -209,14 +229,14 @@ def cpu_baseline(cfg, nchunks, with_psd, seed):
     sp = so.Spectrum(cfg['fs'] / 1e3, PSD_CHUNK, PSD_NFFT, 0.0, np.float32)
     for rx in rxs:                       # warm-up chunk (BLAS init, page faults)
         rx.demod_data(x[:L])
-    if nchunks <= 0:                     # size the sample to about 10 s from one timed chunk
+    if nchunks <= 0:                     # size the sample to about `seconds` from one timed chunk
         t0 = time.perf_counter()
         for rx in rxs:
             rx.demod_data(x[L:2 * L])
         if with_psd:
             for i in range(0, L - PSD_CHUNK + 1, PSD_CHUNK):
                 sp.periodogram(x[i:i + PSD_CHUNK], True)
-        nchunks = int(max(4, min(4096, 10.0 / max(time.perf_counter() - t0, 1e-4))))
+        nchunks = int(max(4, min(4096, seconds / max(time.perf_counter() - t0, 1e-4))))
     t0 = time.perf_counter()
     for k in range(nchunks):
         xc = x[(k % uniq) * L:(k % uniq + 1) * L]
@@ -462,7 +482,7 @@ def measured_traffic(args, nrx, B, kernel_prefix, sources):
     while the kernel sources still hash to what was profiled (the profile file carries the hashes)."""
     if B != DEFAULT_CHUNKS[args.workload] or args.nrx:
         return None, None
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         # C3 (the demod kernels are the same with and without the PSD) or the workload's own passes
         name = f"{tag}_pmc_traffic.json" if args.workload == "c3" else f"{tag}_{args.workload}_pmc_traffic.json"
         p = os.path.join(ROOT, "profiles", name)
@@ -482,10 +502,12 @@ def measured_traffic(args, nrx, B, kernel_prefix, sources):
 
 
 def other_configs(args):
-    """The other single-GPU BASELINE configurations (BASELINE.json configs[0], [1], [3]) through this same tool, one child
-    process each, AFTER the C3 loop has been timed and its buffers freed: throughput, step time, the front-end kernel's
-    and the job's roofline fraction and the verification stamp of each -- so that the driver's one record certifies
-    every configuration, not only the headline one ("Next round" 2).  Never `value`."""
+    """The other single-GPU configurations (BASELINE.json configs[0], [1], [3]; mono FM, MAX_RX = 6, AM-Synch) through this
+    same tool, one child process each, AFTER the C3 loop has been timed and its buffers freed: throughput, step time, the
+    front-end kernel's and the job's roofline fraction and the verification stamp of each -- so that the driver's one
+    record certifies every configuration, not only the headline one.  Their CPU baselines (the oracle on ~2 s of the
+    same chunks, one core each: BASELINE.json's config #1 IS "am.py path ... CPU NumPy reference", am.py:54-75) run as
+    CPU-only children side by side once the GPU children are done.  Never `value`."""
     res = {}
     for w in OTHER_CONFIGS:
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", str(max(args.steps, MIN_STEPS.get(w, 0))), "--warmup",
@@ -498,7 +520,7 @@ def other_configs(args):
             line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
             d = json.loads(line)
             res[w] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
-                      "workload": d["config"]["workload"],
+                      "warmup": d["warmup"], "workload": d["config"]["workload"],
                       "roofline": {"kernel": d["roofline_mixdec"]["kernel"], "frac": d["roofline_mixdec"]["frac"],
                                    "achieved": d["roofline_mixdec"]["achieved"], "unit": "GB/s",
                                    "avg_launch_ms": d["roofline_mixdec"]["avg_launch_ms"],
@@ -507,10 +529,24 @@ def other_configs(args):
                                        "algorithmic_bytes_per_sample": d["roofline_job"]["algorithmic_bytes_per_sample"]}
                       if d.get("roofline_job") else None,
                       "kernel_ms": d.get("kernel_ms"), "step_ms_stats": d.get("step_ms_stats"), "pilot_pll": d.get("pilot_pll"),
+                      "carrier_pll": d.get("carrier_pll"),
                       "verified_ranks": d.get("verified_ranks"), "verify_worst_rel": d.get("verify_worst_rel"),
                       "exit_code": p.returncode, "wall_s": round(time.time() - t0, 1)}
         except Exception as e:            # a failed child must not take the headline line with it
             res[w] = {"error": repr(e)[:300], "wall_s": round(time.time() - t0, 1)}
+    if not args.no_cpu_baseline:
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        procs = {w: subprocess.Popen([sys.executable, os.path.abspath(__file__), "--workload", w, "--cpu-only", "--cpu-seconds", "2"],
+                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT)
+                 for w in OTHER_CONFIGS}
+        for w, p in procs.items():
+            try:
+                out, _ = p.communicate(timeout=120)
+                res[w]["cpu_baseline"] = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])["cpu_baseline"]
+            except Exception as e:
+                if p.poll() is None:
+                    p.kill()
+                res[w]["cpu_baseline"] = {"error": repr(e)[:200]}
     return res
 
 
@@ -519,6 +555,10 @@ def main():
     cfg = workload_cfg(args)
     if args.cpu_worker is not None:      # child of cpu_baseline_per_rx: CPU only, never touches the GPU
         print(_cpu_worker((cfg, args.cpu_chunks, args.cpu_seed, args.cpu_worker)))
+        return 0
+    if args.cpu_only:                    # child of other_configs: the oracle on a bounded sample, no GPU, no library load
+        cb, _ = cpu_baseline(cfg, args.cpu_chunks, False, 10, args.cpu_seconds)
+        print(json.dumps({"cpu_baseline": cb}), flush=True)
         return 0
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
@@ -755,14 +795,17 @@ def main():
                 "note": "same step as `value` but ONE 64k PSD frame per SRATE/psd_hz samples, the duty pySDR's 20 Hz GUI timer "
                         "really runs at (BASELINE.md: 8.8 B/sample); `value` PSDs every sample"}
 
-    pll = None
-    if 'wfm' in cfg and rxs:
+    pll = cpll = None
+    synch = bool(rxs) and cfg['rx'][0]['mode'] == 'AM-Synch'
+    if ('wfm' in cfg or synch) and rxs:
         sg, pt = C.c_int(0), C.c_int(0)
         _lib.check(lib.pysdr_pll_stats(ctx.h, 0, C.byref(sg), C.byref(pt)), "pll_stats")
         jw, jd = C.c_int(0), C.c_float(0)
         _lib.check(lib.pysdr_pll_join_margin(ctx.h, 0, C.byref(jw), C.byref(jd)), "pll_join_margin")
-        pll = {"segments": sg.value, "patched_serially": pt.value,
-               "widest_join": {"phase_words_of_2^32": jw.value, "tolerance": 512, "integrator_rad_per_sample": jd.value, "tolerance_w": 1e-9}}
+        st = {"segments": sg.value, "patched_serially": pt.value,
+              "widest_join": {"phase_words_of_2^32": jw.value, "tolerance": 1024 if synch else 512,
+                              "integrator_rad_per_sample": jd.value, "tolerance_w": 2e-8 if synch else 1e-9}}
+        pll, cpll = (None, st) if synch else (st, None)
     tune = (C.c_int32 * 8)()
     _lib.check(lib.pysdr_get_tuning(ctx.h, tune), "get_tuning")
     sp_tune = (C.c_int32 * 4)()
@@ -857,6 +900,7 @@ def main():
                            "what": "HIP-event period between consecutive steps on the context's stream over the timed loop"}
                           if periods else None),
         "pilot_pll": pll,
+        "carrier_pll": cpll,
         "tuning": {"diag_build": int(tune[0]), "debug_flags": int(tune[1]), "mixdec_wgs_per_cu": int(tune[2]),
                    "mixdec_yflush_cap": int(tune[3]), "tile_bytes": int(tune[4]), "threads": int(tune[5]),
                    "mixdec_mfma": int(tune[7]),
@@ -888,7 +932,7 @@ def main():
         out["host_fed_ms_per_chunk"] = out["host_fed"]["ms_per_chunk"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"], used = cpu_baseline(cfg, args.cpu_chunks, with_psd, 10)
+        out["cpu_baseline"], used = cpu_baseline(cfg, args.cpu_chunks, with_psd, 10, args.cpu_seconds)
         if not args.no_cpu_mp and not is_wfm:
             out["cpu_baseline_per_rx_process"] = cpu_baseline_per_rx(args, cfg, used, with_psd, 10)
     elif rank == 0:

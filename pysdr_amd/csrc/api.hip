@@ -158,7 +158,12 @@ struct pysdr_ctx {
                                        // 1 = one output per thread (resamp_small_kernel), 2 = a half-wave per branch (resamp_branch_kernel) (A/B)
   int mfma_enable = 1;                 // long single-RX prototypes on the matrix cores (mixdec_mfma.hip); 0: VALU form (A/B)
   int dbg_flags = 0, yflush_cap = 0;      // tuning / diagnostic switches, read from the environment once
-  int am_pll_waves = -1;                  // PYSDR_AM_PLL_WAVES=1 / 0: force the wave- / lane-per-segment carrier loop (A/B runs); -1 = by size
+  // carrier-PLL segmentation (PYSDR_AM_PLL = "taus,taus_exact,coarse_sweeps,kmax,tmin" overrides for A/B runs): warm-up of 16
+  // time constants from the block mean of the signal's own phase (joins 7-40 words of 2^32 against a tolerance of 1024 in the
+  // NumPy model of the sweeps, scripts/experiments/am_pll_sweeps.py; 14 leave up to 730 on a noisy carrier 40 Hz off tune),
+  // the first 11 of them at 5 sweeps per block, the last 5 to the fixed point (8-10 sweeps)
+  double am_taus = 16.0, am_taus_exact = 5.0;
+  int am_coarse_sweeps = 5, am_kmax = 2048, am_tmin = 512;
   int pll_kmax = 0;                       // pysdr_set_pll_segments: 0 = default, 1 = serial
   // pilot-PLL segmentation (PYSDR_WFM_PLL = "taus,taus_fast,taus_exact,coarse_sweeps,kmax,tmin,exact_cap" overrides for A/B runs)
   // measured on MI355X (bench.py --workload c4, scripts/diag/pll_sweep.sh; front end ms per 2048 chunks):
@@ -552,7 +557,7 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       PYSDR_HIP_CHECK(hipMemcpyAsync(&st, c->d_state + r, sizeof(st), hipMemcpyDeviceToHost, c->stream));
       PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (x.reset_pending & 1u) { st.env = 0.f; st.gain = 1.f; st.maxbuf = 0.f; st.err = 0.f; st.sq_level = 0.f; st.sq_open = 1; }
-      if (x.reset_pending & 2u) { st.pll_theta = 0.f; st.pll_w = 0.f; st.wfm_phase = 0u; st.wfm_w = 0.f; st.wfm_slope_ok = 0; }
+      if (x.reset_pending & 2u) { st.pll_phase = 0u; st.pll_w = 0.f; st.wfm_phase = 0u; st.wfm_w = 0.f; st.wfm_slope_ok = 0; }
       st.ref = x.agc_ref; st.agc_enable = x.agc_enable;
       PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_state + r, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
       PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -639,7 +644,16 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   // tuning / ablation switches (bench.py and DESIGN.md 4.1 use them; all default to off, read only under PYSDR_TUNING=1)
   { const char* e = tuning_env("PYSDR_MIXDEC_WGS"); if (e && atoi(e) > 0) c->wgs_per_cu = atoi(e); }
   { const char* e = tuning_env("PYSDR_MIXDEC_YFLUSH"); if (e && atoi(e) > 0) c->yflush_cap = atoi(e); }
-  { const char* e = tuning_env("PYSDR_AM_PLL_WAVES"); if (e && *e) c->am_pll_waves = atoi(e) > 0 ? 1 : 0; }
+  { const char* e = tuning_env("PYSDR_AM_PLL");
+    if (e && *e) {
+      double t = 0, tx = 0; int cs = 0, km = 0, tm = 0;
+      const int nf = sscanf(e, "%lf,%lf,%d,%d,%d", &t, &tx, &cs, &km, &tm);
+      if (nf >= 1 && t > 0) c->am_taus = t;
+      if (nf >= 2 && tx >= 0) c->am_taus_exact = tx;
+      if (nf >= 3 && cs >= 0) c->am_coarse_sweeps = std::min(cs, 8);
+      if (nf >= 4 && km > 0) c->am_kmax = std::min(km, kPllSegMax);
+      if (nf >= 5 && tm >= 64) c->am_tmin = (tm + 63) & ~63;
+    } }
   { const char* e = tuning_env("PYSDR_MIXDEC_MFMA"); if (e && *e) c->mfma_enable = atoi(e) ? 1 : 0; }
   { const char* e = tuning_env("PYSDR_RESAMP_PLAIN"); if (e && *e) c->resamp_plain = atoi(e); }
   { const char* e = tuning_env("PYSDR_MIXDEC_GRID"); if (e && atoi(e) > 0) c->grid_override = atoi(e); }
@@ -1137,14 +1151,13 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   s.blkpeak = c->d_blkpeak; s.gain = c->d_gain; s.state = c->d_state;
   s.blknoise = c->d_blknoise; s.blkcnt = c->d_blkcnt;
   if (any_pll && n_out > 0) {
-    // measured: identical floats after 4096 samples = 19 tau of the 50 Hz loop at 48 kHz
-    s.pll = plan_pll(n_out, fs_out, kPllBwHz, 19.0, 0.0, 512, c->pll_kmax > 0 ? std::min(c->pll_kmax, kPllSegMax) : kPllSegMax, c->d_pllseg);
-    // One wave per segment runs the recursion 64 times over but has the simplest chain (0.98 vs 1.16 ms for 512
-    // segments: both are the latency of ONE segment's W + T dependent steps); from two waves per SIMD on the redundant
-    // arithmetic is what takes the time and one LANE per segment wins (2048 segments: 1.23 vs 1.30 ms, 4096: 1.64 vs 2.87).
-    int npll = 0;
-    for (int r = 0; r < nrx; ++r) npll += (s.det[r] == kDetPll) ? 1 : 0;
-    s.pll_wave_segments = c->am_pll_waves >= 0 ? c->am_pll_waves : ((long)s.pll.K * npll < 2048 ? 1 : 0);
+    s.pll = plan_pll(n_out, fs_out, kPllBwHz, c->am_taus, 0.0, c->am_tmin,
+                     c->pll_kmax > 0 ? std::min(c->pll_kmax, c->am_kmax) : c->am_kmax, c->d_pllseg);
+    if (c->am_coarse_sweeps > 0 && s.pll.K > 1) {
+      const double tau = fs_out / (kPllZetaPlan * 2.0 * M_PI * kPllBwHz);
+      s.pll.Wexact = ((int)std::ceil(c->am_taus_exact * tau) + 63) & ~63;
+      s.pll.coarse_sweeps = c->am_coarse_sweeps;
+    }
     rc = launch_pll(s, c->stream);
     if (rc) return rc;
   }

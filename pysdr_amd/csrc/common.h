@@ -169,15 +169,16 @@ constexpr int kBlkStride = PYSDR_BLK_STRIDE;
 struct RxDevState {       // one per RX, lives in device memory
   float env, gain, maxbuf, err, ref;
   int agc_enable;
-  float pll_theta, pll_w;   // AM-Synch carrier PLL
+  uint32_t pll_phase;       // AM-Synch carrier PLL: 32-bit phase accumulator (2^32 = one revolution)
+  float pll_w;              //                       loop integrator (rad/sample)
   uint32_t wfm_phase;       // WFM2 pilot PLL: 32-bit phase accumulator
   float wfm_w;              //                 loop integrator (rad/sample)
   float sq_level;           // NFM noise squelch: smoothed out-of-band noise
   int sq_open;
   int pll_segments;         // time-parallel PLL of the last call: segments run ...
   int pll_patched;          // ... and segments the serial patch-up pass had to redo
-  int pll_join_words;       // pilot loop: the widest join of the last call's first pass, |phase difference| in words of 2^32 (tolerance 512)
-  float pll_join_dw;        // ... and the widest integrator difference, rad/sample (tolerance 1e-9)
+  int pll_join_words;       // the widest join of the last call's first pass, |phase difference| in words of 2^32 (tolerance: pilot 512, carrier 1024)
+  float pll_join_dw;        // ... and the widest integrator difference, rad/sample (tolerance 1e-9 / 2e-8)
   int wfm_slope_ok;         // the last call ran in segments and none had to be patched: wfm_slope is usable
   int wfm_redo;             // this call's short warm-ups did not meet (stream discontinuity): run the long ones
   double wfm_slope;         // its mean pilot-phase increment per sample beyond fword0 (words of 2^32)
@@ -186,7 +187,7 @@ struct RxDevState {       // one per RX, lives in device memory
 // Time-parallel form of the serial PLLs (WFM2 pilot, AM-Synch carrier), DESIGN.md 4.2: the call's
 // samples are cut into K segments of T; segment k > 0 first runs the SAME recursion over the W
 // samples in front of it from a guessed state (a locked loop forgets its initial state: measured
-// 99 words of 2^32 after 32768 pilot samples, bit-identical floats after 4096 carrier samples),
+// 99 words of 2^32 after 32768 pilot samples, 7-40 words after 3520 carrier samples = 16 time constants),
 // then its own T samples with outputs.  seg[r][k] = {start state used, end state reached}; a
 // single-wave patch-up pass walks the chain, and where end(k-1) and start(k) disagree by more than
 // the tolerance it recomputes serially from there until the two trajectories meet again -- so the
@@ -211,7 +212,6 @@ struct Stage2Args {
   uint32_t m0_lo;                     // low 32 bits of the absolute index of output 0
   float fm_scale;
   float pll_kp, pll_ki;
-  int pll_wave_segments;              // A/B: one WAVE per carrier-loop segment (round 2) instead of one lane
   const float2* y[PYSDR_MAX_RX];      // points at element for output 0 (prefix before it)
   float2* ypll[PYSDR_MAX_RX];         // same layout, only for AM-Synch
   const float2* aftaps[PYSDR_MAX_RX]; // [4*ceil(ntaps/4)], zero padded

@@ -25,212 +25,264 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// ---- AM-Synch carrier PLL (rx.demod.am_pll, receiver.py:649): theta feeds back through
-// sin/cos and atan2, so the recursion itself is serial.  One wave walks a range in blocks of 64
-// samples loaded coalesced and broadcast with v_readlane; every lane runs the same recursion,
-// lane j keeps v = y*exp(-j*theta) of sample j for the detector stage, stored coalesced.
-// Nothing but arithmetic sits on the critical path (sin/cos by v_sin/v_cos on theta/2pi).
-// Parallelism comes from time: segments with warm-up + a patch-up pass (PllPlan, common.h).
-// one sample of the carrier loop: v = y exp(-j theta) (kept for the detector stage), then the loop update
-__device__ __forceinline__ float2 am_pll_step(float yr, float yi, float& th, float& w, float kp, float ki) {
-  const float pi = 3.14159265358979323846f, twopi = 6.28318530717958647692f;
-  const float inv2pi = 0.15915494309189533577f;
-  const float rev = th * inv2pi;
-  const float s = __builtin_amdgcn_sinf(rev), c = __builtin_amdgcn_cosf(rev);
-  const float vr = yr * c + yi * s;
-  const float vi = yi * c - yr * s;
-  const float e = atan2f(vi, vr);
-  w = w + ki * e;
-  th = th + (w + kp * e);
-  if (th >= pi) th -= twopi;
-  else if (th < -pi) th += twopi;
-  return make_float2(vr, vi);
+// Inclusive scans over the 64 lanes of a wave (DPP: row_shr 1, 2, 4, 8 inside the rows of 16, then
+// row_bcast15 / row_bcast31 carry the row totals up).
+__device__ __forceinline__ float wave_scan_add(float v) {
+#define PYSDR_DPP_F(ctrl, rm) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rm, 0xF, true))
+  v += PYSDR_DPP_F(0x111, 0xF);
+  v += PYSDR_DPP_F(0x112, 0xF);
+  v += PYSDR_DPP_F(0x114, 0xF);
+  v += PYSDR_DPP_F(0x118, 0xF);
+  // the two steps across the rows of 16 add in place: rows outside the mask keep v.  Written through update_dpp, hipcc
+  // cannot fold "v + (row masked off ? 0 : bcast)" into one DPP add (x + 0 is not x for x = -0) and issues v_mov_b32_dpp +
+  // v_add_f32 + a v_mov that zeroes the old value: 6 instructions where these are 2, on the pilot loop's critical chain
+  // (2 wait states between a VALU write and its DPP read)
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+#undef PYSDR_DPP_F
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+#define PYSDR_DPP_U(ctrl, rm, bc) (uint32_t) __builtin_amdgcn_update_dpp(0, (int)v, ctrl, rm, 0xF, bc)
+  v += PYSDR_DPP_U(0x111, 0xF, true);
+  v += PYSDR_DPP_U(0x112, 0xF, true);
+  v += PYSDR_DPP_U(0x114, 0xF, true);
+  v += PYSDR_DPP_U(0x118, 0xF, true);
+  v += PYSDR_DPP_U(0x142, 0xA, false);
+  v += PYSDR_DPP_U(0x143, 0xC, false);
+#undef PYSDR_DPP_U
+  return v;
 }
 
+// ---- AM-Synch carrier PLL (rx.demod.am_pll, receiver.py:649; oracle/sdr_oracle.py CarrierPLL):
+//     v = y exp(-j theta), e = atan2(Im v, Re v), w += ki e, theta += w + kp e (wrapped), output Re v.
+// e is wrap(arg y - theta): the loop is LINEAR in the phase domain, and that is what this form uses.
+//  (i)   phi = arg y is taken once per sample, in parallel, off the chain (am_phase_kernel), as a word of 2^32 per
+//        revolution; theta lives on the same 32-bit accumulator, so both wraps are the integer overflow and the sum
+//        of phase increments is exact in any order;
+//  (ii)  a block of 64 samples (one per lane) is solved by FIXED-POINT SWEEPS like the pilot loop's (wfm_pll_walk):
+//        from a guess of the 64 phases every lane takes its own e_j; the integrator after sample j is w0 + ki *
+//        (inclusive wave scan of e), the increment rint((w_j + kp e_j) 2^32/2pi), the phase in front of sample j
+//        theta0 + (exclusive scan of the increments).  Sample 0 is exact from the start, sweep k makes samples 0..k
+//        exact, and the walk stops when a sweep reproduces its input bit for bit -- on the recursion's own
+//        trajectory for ANY input (64 sweeps at worst); 64 kp = 0.59, so a locked loop takes 8-10 sweeps of ~20
+//        vector instructions where the sample-by-sample walk took 64 x ~100 through sin, cos and atan2
+//        (scripts/experiments/am_pll_sweeps.py: the model of these sweeps in NumPy);
+//  (iii) parallelism across a call comes from time: segments with a warm-up + a patch-up pass (PllPlan, common.h).
+// Against the oracle's float32 walk: theta within 2e-6 rad (the float32 walk rounds theta to 2.4e-7 rad every step and
+// wanders by that much around the exact recursion), Re v within 2e-7 of full scale (it depends on theta through
+// sin(e) ~ 0).  History: one wave walking sample by sample 193 ns per sample; one LANE per segment (round 3) the same
+// chain 64 segments at a time; this form ~10 ns per sample and segment.
+constexpr float kRad2Word = 683565275.57643158f;          // 2^32 / 2pi
+constexpr float kWord2Rad = 1.4629180792671596e-9f;       // 2pi / 2^32
+
+// grid (ceil(n / 256), nrx): the phase word of every new sample, into the .y of the PLL buffer (its .x gets Re v)
+__global__ __launch_bounds__(256) void am_phase_kernel(const Stage2Args a) {
+  const int r = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (a.det[r] != kDetPll || i >= a.n_out) return;
+  const float2 v = a.y[r][i];
+  reinterpret_cast<uint32_t*>(a.ypll[r] + i)[1] = (uint32_t)__float2int_rn(__fmul_rn(atan2f(v.y, v.x), kRad2Word));
+}
+
+// The loop over [i_begin, i_end) from the state (ph0, w0) in front of sample i_begin; 64 samples per block.
+// max_it <= 8: a COARSE walk for the early part of a warm-up -- that many sweeps per block, no questions asked (what
+// they leave behind, ~0.6^s / s! of the first guess's error, is forgotten by the exact tail of the warm-up);
+// otherwise sweeps until one reproduces its input.  Lanes past the end of a last, partial block compute on zeros:
+// the scans only carry sums upwards, so nothing of theirs reaches a live lane.
 template <bool EMIT>
-__device__ __forceinline__ void am_pll_walk(const Stage2Args& a, const float2* __restrict__ y,
-                                            float2* __restrict__ o, int i_begin, int i_end, float& th,
-                                            float& w, int lane) {
+__device__ __forceinline__ void am_pll_walk(const Stage2Args& a, int r, int i_begin, int i_end, uint32_t& ph0,
+                                            float& w0, int lane, int max_it = 66) {
+  typedef float pl_v2f __attribute__((ext_vector_type(2)));
+  const float2* __restrict__ y = a.y[r];
+  float2* __restrict__ o = a.ypll[r];
   const float kp = a.pll_kp, ki = a.pll_ki;
-  const float pi = 3.14159265358979323846f, twopi = 6.28318530717958647692f;
-  const float inv2pi = 0.15915494309189533577f;
-  float2 y_next = (i_begin + lane < i_end) ? y[i_begin + lane] : make_float2(0.f, 0.f);
+  // The next block's phase words (and, where outputs are due, its samples) are loaded from inline asm one block ahead
+  // and waited for by hand at the END of the block: a prefetch hipcc knows about costs s_waitcnt vmcnt(0) in front of
+  // the first sweep of every block (it cannot count across the back edge) = a memory latency per block on the chain.
+  // "+v": the register is zeroed BEFORE the asm and the load overwrites it in place, so no copy that merges a loaded
+  // and a zero value can land between the load and the hand-placed wait (tests/test_isa_checks.py).
+  uint32_t f_next = 0u;
+  pl_v2f y_next = (pl_v2f){0.f, 0.f};
+  if (i_begin + lane < i_end) {
+    if (EMIT)
+      asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dword %1, %3, off\n\ts_waitcnt vmcnt(0)"
+                   : "+v"(y_next), "+v"(f_next) : "v"(y + i_begin + lane), "v"(&o[i_begin + lane].y) : "memory");
+    else
+      asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "+v"(f_next) : "v"(&o[i_begin + lane].y) : "memory");
+  }
   for (int i0 = i_begin; i0 < i_end; i0 += 64) {
-    const float2 yv = y_next;
+    const uint32_t phi = f_next;
+    const pl_v2f yv = y_next;
     const int nidx = i0 + 64 + lane;
-    y_next = (nidx < i_end) ? y[nidx] : make_float2(0.f, 0.f);     // in flight during the steps below
-    float2 mine = make_float2(0.f, 0.f);
-    const int count = (i_end - i0 < 64) ? i_end - i0 : 64;
-#pragma unroll 4
-    for (int j = 0; j < count; ++j) {
-      // (am_pll_step written out: through the call hipcc no longer unrolls this loop by 4)
-      const float yr = lane_bcast(yv.x, j), yi = lane_bcast(yv.y, j);
-      const float rev = th * inv2pi;
-      const float s = __builtin_amdgcn_sinf(rev), c = __builtin_amdgcn_cosf(rev);
-      const float vr = yr * c + yi * s;
-      const float vi = yi * c - yr * s;
-      const float e = atan2f(vi, vr);
-      w = w + ki * e;
-      th = th + (w + kp * e);
-      if (th >= pi) th -= twopi;
-      else if (th < -pi) th += twopi;
-      if (lane == j) mine = make_float2(vr, vi);
+    f_next = 0u;
+    y_next = (pl_v2f){0.f, 0.f};
+    if (nidx < i_end) {                                    // in flight during the sweeps below
+      if (EMIT) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(y_next) : "v"(y + nidx) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "+v"(f_next) : "v"(&o[nidx].y) : "memory");
     }
-    if (EMIT && lane < count) o[i0 + lane] = mine;
+    const int count = (i_end - i0 < 64) ? i_end - i0 : 64;
+    // in words of 2^32: e and its scan as floats, the integrator's rate w0 R once per block
+    const float w0r = __fmul_rn(w0, kRad2Word);
+    uint32_t ph = ph0 + (uint32_t)lane * (uint32_t)__float2int_rn(w0r);   // guess: free running at the integrator's rate
+    uint32_t tot = 0u;
+    float sj = 0.f;
+    auto sweep = [&](uint32_t pin) -> uint32_t {
+      const float e = (float)(int)(phi - pin);             // the detector: wrap(phi - theta), the wrap is the overflow
+      sj = wave_scan_add(e);
+      const uint32_t corr = (uint32_t)__float2int_rn(__fmaf_rn(kp, e, __fmaf_rn(ki, sj, w0r)));
+      tot = wave_scan_add(corr);
+      return ph0 + tot - corr;
+    };
+    // two sweeps per trip: the phases alternate between two registers instead of being copied back every sweep
+    if (max_it <= 8) {
+      for (int it = 0;; it += 2) {
+        const uint32_t p1 = sweep(ph);
+        if (it + 1 >= max_it) { ph = p1; break; }
+        ph = sweep(p1);
+        if (it + 2 >= max_it) break;
+      }
+    } else {
+      const unsigned long long mine = count >= 64 ? ~0ull : (1ull << count) - 1ull;
+      for (int it = 0;;) {
+        const uint32_t p1 = sweep(ph);
+        if (!(__ballot(p1 != ph) & mine) || ++it >= max_it) { ph = p1; break; }
+        ph = sweep(p1);
+        if (!(__ballot(ph != p1) & mine) || ++it >= max_it) break;
+      }
+    }
+    // the next block's loads (issued a block of sweeps ago) and the previous block's store
+    if (EMIT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(f_next), "+v"(y_next) :: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(f_next) :: "memory");
+    if (EMIT && lane < count) {
+      const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+      const float s = __builtin_amdgcn_sinf(rev), c = __builtin_amdgcn_cosf(rev);
+      // only Re v is stored (the detector stage reads nothing else), into .x: the warm-ups of neighbouring segments
+      // are reading the .y words meanwhile -- no location is both read and written here
+      reinterpret_cast<float*>(o + i0 + lane)[0] = yv.x * c + yv.y * s;
+    }
+    ph0 = ph0 + (uint32_t)__builtin_amdgcn_readlane((int)tot, count - 1);
+    w0 = __fmaf_rn(ki * kWord2Rad, lane_bcast(sj, count - 1), w0);
   }
 }
 
-// tolerances of the patch-up pass: the carrier loop's trajectories merge to identical floats
-// (scripts/experiments/pll_warmup.py); 2e-6 rad of phase = 2e-6 of the detector output
-__device__ __forceinline__ bool am_state_differs(float th_a, float w_a, float th_b, float w_b) {
-  const float pi = 3.14159265358979323846f, twopi = 6.28318530717958647692f;
-  float d = th_a - th_b;
-  if (d >= pi) d -= twopi;
-  else if (d < -pi) d += twopi;
-  return !(fabsf(d) <= 2.0e-6f && fabsf(w_a - w_b) <= 2.0e-8f);
+// 1024 words of 2^32 = 1.5e-6 rad of carrier phase (x sin(e) ~ 0 in the output); the integrator within 2e-8 rad/sample.
+// Two walks of one record from different starts end a few words apart once both have converged (measured 7-40 at 16
+// time constants, scripts/experiments/am_pll_sweeps.py): the blocks of the two sum the integrator in different places.
+__device__ __forceinline__ bool am_state_differs(uint32_t ph_a, float w_a, uint32_t ph_b, float w_b) {
+  const int d = (int)(ph_a - ph_b);
+  return !(d <= 1024 && d >= -1024 && fabsf(w_a - w_b) <= 2.0e-8f);
 }
 
-// grid (K, nrx): segment k of RX r
+// grid (K, nrx): segment k of RX r.  Segment k > 0 starts W samples early from a guess: the integrator as the call
+// began, the phase the block mean of the signal's own (the loop sits on the carrier: off by the noise of 64 samples
+// instead of up to pi, which saves ~4 time constants of warm-up).
 __global__ __launch_bounds__(64) void am_pll_seg_kernel(const Stage2Args a) {
   const int r = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
   if (a.det[r] != kDetPll) return;
   const PllPlan& pl = a.pll;
-  const RxDevState* st = a.state + r;
+  RxDevState* st = a.state + r;
   const int n = a.n_out;
   const int s0 = k * pl.T, s1 = (s0 + pl.T < n) ? s0 + pl.T : n;
-  float th = st->pll_theta, w = st->pll_w;
+  uint32_t ph = st->pll_phase;
+  float w = st->pll_w;
   int wb = s0 - pl.W;
   if (k > 0 && wb > 0) {
-    // guessed state W samples ahead of the segment: free-running at the call's initial rate
-    th = 0.f;
+    const uint32_t* f = reinterpret_cast<const uint32_t*>(a.ypll[r] + wb + lane) + 1;      // wb + 64 <= s0 <= n
+    const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*f);
+    const uint32_t inc0 = (uint32_t)__float2int_rn(__fmul_rn(w, kRad2Word));
+    const float dev = (float)(int)(*f - f0 - (uint32_t)lane * inc0);
+    const float mean = lane_bcast(wave_scan_add(dev), 63) * (1.0f / 64.0f);
+    ph = f0 + (uint32_t)__float2int_rn(mean);
   } else {
     wb = 0;                                  // the true state of the call: exact, however short
   }
-  if (wb < s0) am_pll_walk<false>(a, a.y[r], a.ypll[r], wb, s0, th, w, lane);
+  if (wb < s0) {
+    // coarse sweeps first, the last Wexact samples to the fixed point (both bounds on multiples of 64)
+    const int sx = (pl.coarse_sweeps > 0 && s0 - pl.Wexact > wb) ? s0 - pl.Wexact : wb;
+    if (wb < sx) am_pll_walk<false>(a, r, wb, sx, ph, w, lane, pl.coarse_sweeps);
+    am_pll_walk<false>(a, r, sx, s0, ph, w, lane);
+  }
   uint32_t* sg = pl.seg + ((size_t)r * pl.K + k) * 4;
-  if (lane == 0) { sg[0] = __float_as_uint(th); sg[1] = __float_as_uint(w); }
-  am_pll_walk<true>(a, a.y[r], a.ypll[r], s0, s1, th, w, lane);
-  if (lane == 0) { sg[2] = __float_as_uint(th); sg[3] = __float_as_uint(w); }
+  if (lane == 0) { sg[0] = ph; sg[1] = __float_as_uint(w); }
+  am_pll_walk<true>(a, r, s0, s1, ph, w, lane);
+  if (lane == 0) {
+    sg[2] = ph; sg[3] = __float_as_uint(w);
+    if (pl.K == 1) {                         // every live call: nothing to join, no patch-up launch
+      st->pll_phase = ph; st->pll_w = w;
+      st->pll_segments = 1; st->pll_patched = 0;
+      st->pll_join_words = 0; st->pll_join_dw = 0.f;
+    }
+  }
 }
 
-// grid (ceil(K / 64), nrx): ONE LANE per segment.  The wave-per-segment kernel above runs the recursion 64 times over
-// (every lane the same), so with thousands of segments the time-parallel loop was bound by VALU throughput (4096
-// segments x 4672 samples x ~100 instructions: 7 ms per RX); here a wave carries 64 segments, the chain of one segment
-// is as long as before (W + T steps of ~190 ns) and the machine is nearly idle beside it.  Same steps in the same
-// order per segment: bit for bit the result of am_pll_seg_kernel.  Every lane reads and writes its own run of samples
-// (64 contiguous bytes per 8 steps, the next 8 samples in flight during the current 8).
-__global__ __launch_bounds__(64) void am_pll_lanes_kernel(const Stage2Args a) {
-  const int r = blockIdx.y, lane = threadIdx.x, k = blockIdx.x * 64 + lane;
-  if (a.det[r] != kDetPll) return;
-  const PllPlan& pl = a.pll;
-  const RxDevState* st = a.state + r;
-  const int n = a.n_out, T = pl.T, W = pl.W;
-  const bool live = k < pl.K;
-  // (a lane beyond the last segment gets an EMPTY range, s1 = 0: every `i >= 0 && i < s1` below is then false, so it
-  //  neither loads -- its warm-up range would reach up to 63 segments past the end of y -- nor walks)
-  const int s0 = k * T, s1 = live ? ((s0 + T < n) ? s0 + T : n) : 0;
-  const float kp = a.pll_kp, ki = a.pll_ki;
-  float th = st->pll_theta, w = st->pll_w;
-  if (k > 0 && s0 - W > 0) th = 0.f;         // guessed state W samples ahead; otherwise the walk starts at sample 0 from the true one
-  const float2* __restrict__ y = a.y[r];
-  float2* __restrict__ o = a.ypll[r];
-  uint32_t* sg = pl.seg + ((size_t)r * pl.K + (live ? k : 0)) * 4;
-  // The next block's samples are loaded from inline asm and waited for by hand at the END of the block: loads that
-  // hipcc knows about cost an s_waitcnt vmcnt(0) in front of every step (it cannot count across the loop's back edge),
-  // i.e. one memory latency per 8 steps on the chain.
-  // The two blocks of registers swap roles from one block of 8 steps to the next (the loop body is written out for A -> B and
-  // B -> A): with a `cur = nxt` copy at the end of a trip hipcc hoisted six of the eight copies ABOVE the hand-placed wait --
-  // legal for a "+v" tied operand, and a read of a register whose load may still be in flight (tests/test_isa_checks.py looks
-  // at the generated ISA for exactly this; the hardware does not interlock on vmcnt).
-  typedef float pl_v2f __attribute__((ext_vector_type(2)));
-  pl_v2f ba[8], bb[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int i = s0 - W + q;
-    const float2 v = (i >= 0 && i < s1) ? y[i] : make_float2(0.f, 0.f);
-    ba[q] = (pl_v2f){v.x, v.y};
-  }
-  auto block = [&](pl_v2f (&cur)[8], pl_v2f (&nxt)[8], int t) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = s0 + t + 8 + q;
-      // "+v": the register is zeroed BEFORE the asm and the load overwrites it in place, so no copy that merges a
-      // loaded and a zero value can land between the load and the hand-placed wait
-      nxt[q] = (pl_v2f){0.f, 0.f};
-      if (t + 8 < T && i >= 0 && i < s1)
-        asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(nxt[q]) : "v"(y + i) : "memory");
-    }
-    if (t == 0 && live) { sg[0] = __float_as_uint(th); sg[1] = __float_as_uint(w); }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = s0 + t + q;
-      if (i >= 0 && i < s1) {
-        const float2 v = am_pll_step(cur[q].x, cur[q].y, th, w, kp, ki);
-        cur[q] = (pl_v2f){v.x, v.y};
-      }
-    }
-    if (t >= 0) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int i = s0 + t + q;
-        if (i < s1) o[i] = make_float2(cur[q].x, cur[q].y);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]), "+v"(nxt[5]), "+v"(nxt[6]), "+v"(nxt[7])
-                 :: "memory");
-  };
-  for (int t = -W; t < T; t += 16) {       // W and T are multiples of 64
-    block(ba, bb, t);
-    block(bb, ba, t + 8);
-  }
-  if (live) { sg[2] = __float_as_uint(th); sg[3] = __float_as_uint(w); }
-}
-
-// grid (nrx): walk the chain of segments, redo what does not join up
+// grid (nrx): walk the chain of segments, redo what does not join up; the widest join for pysdr_pll_join_margin
 __global__ __launch_bounds__(64) void am_pll_patch_kernel(const Stage2Args a) {
   const int r = blockIdx.x, lane = threadIdx.x;
   if (a.det[r] != kDetPll) return;
   const PllPlan& pl = a.pll;
   const int K = pl.K, n = a.n_out;
   const uint32_t* sg = pl.seg + (size_t)r * K * 4;
-  float th_fin = __uint_as_float(sg[(size_t)(K - 1) * 4 + 2]), w_fin = __uint_as_float(sg[(size_t)(K - 1) * 4 + 3]);
-  int patched = 0;
+  uint32_t ph_fin = sg[(size_t)(K - 1) * 4 + 2];
+  float w_fin = __uint_as_float(sg[(size_t)(K - 1) * 4 + 3]);
+  int patched = 0, jw = 0;
+  float jd = 0.f;
   int k = 1;
+  bool first = true;                                           // the margin is that of the first pass over the joins
   while (k < K) {
     int bad = K;
-    for (int base = k; base < K && bad == K; base += 64) {
-      const int kk = base + lane;
-      bool mm = false;
-      if (kk < K)
-        mm = am_state_differs(__uint_as_float(sg[(size_t)(kk - 1) * 4 + 2]), __uint_as_float(sg[(size_t)(kk - 1) * 4 + 3]),
-                              __uint_as_float(sg[(size_t)kk * 4 + 0]), __uint_as_float(sg[(size_t)kk * 4 + 1]));
-      const unsigned long long bal = __ballot(mm);
-      if (bal) bad = base + __builtin_ctzll(bal);
+    for (int base = k; base < K && (bad == K || first); base += 512) {   // eight joins per lane in flight
+      uint2 e[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = base + 64 * u + lane;
+        e[u] = b[u] = make_uint2(0u, 0u);
+        if (kk < K) {
+          e[u] = *reinterpret_cast<const uint2*>(sg + (size_t)(kk - 1) * 4 + 2);
+          b[u] = *reinterpret_cast<const uint2*>(sg + (size_t)kk * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = base + 64 * u + lane;
+        const bool mm = kk < K && am_state_differs(e[u].x, __uint_as_float(e[u].y), b[u].x, __uint_as_float(b[u].y));
+        const unsigned long long bal = __ballot(mm);
+        if (bal && bad == K) bad = base + 64 * u + __builtin_ctzll(bal);
+        if (first && kk < K) {
+          const int d = (int)(e[u].x - b[u].x);
+          jw = max(jw, d < 0 ? -d : d);
+          jd = fmaxf(jd, fabsf(__uint_as_float(e[u].y) - __uint_as_float(b[u].y)));
+        }
+      }
     }
+    first = false;
     if (bad >= K) break;
-    float th = __uint_as_float(sg[(size_t)(bad - 1) * 4 + 2]), w = __uint_as_float(sg[(size_t)(bad - 1) * 4 + 3]);
+    uint32_t ph = sg[(size_t)(bad - 1) * 4 + 2];
+    float w = __uint_as_float(sg[(size_t)(bad - 1) * 4 + 3]);
     int j = bad;
     bool joined = false;
     while (j < K) {
       const int s0 = j * pl.T, s1 = (s0 + pl.T < n) ? s0 + pl.T : n;
-      am_pll_walk<true>(a, a.y[r], a.ypll[r], s0, s1, th, w, lane);
+      am_pll_walk<true>(a, r, s0, s1, ph, w, lane);
       ++patched;
       ++j;
-      if (j < K && !am_state_differs(th, w, __uint_as_float(sg[(size_t)j * 4 + 0]), __uint_as_float(sg[(size_t)j * 4 + 1]))) {
+      if (j < K && !am_state_differs(ph, w, sg[(size_t)j * 4 + 0], __uint_as_float(sg[(size_t)j * 4 + 1]))) {
         joined = true;                        // segment j was started from (nearly) this state: it stands
         break;
       }
     }
-    if (!joined) { th_fin = th; w_fin = w; break; }
+    if (!joined) { ph_fin = ph; w_fin = w; break; }
     k = j + 1;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { jw = max(jw, __shfl_xor(jw, o)); jd = fmaxf(jd, __shfl_xor(jd, o)); }
   if (lane == 0) {
     RxDevState* st = a.state + r;
-    st->pll_theta = th_fin;
+    st->pll_phase = ph_fin;
     st->pll_w = w_fin;
     st->pll_segments = K;
     st->pll_patched = patched;
+    st->pll_join_words = jw;
+    st->pll_join_dw = jd;
   }
 }
 
@@ -832,35 +884,6 @@ __global__ __launch_bounds__(256) void wfm_disc_kernel(const WfmArgs a) {
 // per sample on the critical path): 37 ns; fixed-point sweeps over the 64 samples of a block
 // (below): ~10 ns; and segments of a call run side by side (wfm_pll_seg_kernel).
 
-// Inclusive scans over the 64 lanes of a wave (DPP: row_shr 1, 2, 4, 8 inside the rows of 16, then
-// row_bcast15 / row_bcast31 carry the row totals up).
-__device__ __forceinline__ float wave_scan_add(float v) {
-#define PYSDR_DPP_F(ctrl, rm) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rm, 0xF, true))
-  v += PYSDR_DPP_F(0x111, 0xF);
-  v += PYSDR_DPP_F(0x112, 0xF);
-  v += PYSDR_DPP_F(0x114, 0xF);
-  v += PYSDR_DPP_F(0x118, 0xF);
-  // the two steps across the rows of 16 add in place: rows outside the mask keep v.  Written through update_dpp, hipcc
-  // cannot fold "v + (row masked off ? 0 : bcast)" into one DPP add (x + 0 is not x for x = -0) and issues v_mov_b32_dpp +
-  // v_add_f32 + a v_mov that zeroes the old value: 6 instructions where these are 2, on the pilot loop's critical chain
-  // (2 wait states between a VALU write and its DPP read)
-  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
-#undef PYSDR_DPP_F
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
-#define PYSDR_DPP_U(ctrl, rm, bc) (uint32_t) __builtin_amdgcn_update_dpp(0, (int)v, ctrl, rm, 0xF, bc)
-  v += PYSDR_DPP_U(0x111, 0xF, true);
-  v += PYSDR_DPP_U(0x112, 0xF, true);
-  v += PYSDR_DPP_U(0x114, 0xF, true);
-  v += PYSDR_DPP_U(0x118, 0xF, true);
-  v += PYSDR_DPP_U(0x142, 0xA, false);
-  v += PYSDR_DPP_U(0x143, 0xC, false);
-#undef PYSDR_DPP_U
-  return v;
-}
-
 // The pilot loop over a range, 64 samples (one per lane) at a time, by FIXED-POINT SWEEPS instead of
 // 64 dependent steps: given a guess of the 64 phases every lane computes its sample's error signal
 // e = mpx cos(theta) * norm in parallel; the integrator after sample j is w0 + ki * (inclusive scan
@@ -892,7 +915,7 @@ __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restric
     const float m = m_next;
     const int nidx = i0 + 64 + lane;
     m_next = 0.f;
-    if (nidx < i_end)                                      // in flight during the sweeps below ("+v": see am_pll_lanes_kernel)
+    if (nidx < i_end)                                      // in flight during the sweeps below ("+v": see am_pll_walk)
       asm volatile("global_load_dword %0, %1, off" : "+v"(m_next) : "v"(&o[nidx].x) : "memory");
     const int count = (i_end - i0 < 64) ? i_end - i0 : 64;
     // once per block instead of once per sweep: the sample times the detector's normalisation, zero in the dead lanes of
@@ -1141,14 +1164,14 @@ __global__ __launch_bounds__(64) void wfm_pll_patch_kernel(const WfmArgs a) {
 }  // namespace
 
 int launch_pll(const Stage2Args& a, hipStream_t st) {
-  // one segment (every live call): the wave-wide walk with coalesced loads; more: one lane per segment
-  if (a.pll.K > 1 && !a.pll_wave_segments)
-    hipLaunchKernelGGL(am_pll_lanes_kernel, dim3((a.pll.K + 63) / 64, a.nrx), dim3(64), 0, st, a);
-  else
-    hipLaunchKernelGGL(am_pll_seg_kernel, dim3(a.pll.K, a.nrx), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(am_phase_kernel, dim3((a.n_out + 255) / 256, a.nrx), dim3(256), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(am_pll_patch_kernel, dim3(a.nrx), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(am_pll_seg_kernel, dim3(a.pll.K, a.nrx), dim3(64), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
+  if (a.pll.K > 1) {                          // (a one-segment call writes its end state itself)
+    hipLaunchKernelGGL(am_pll_patch_kernel, dim3(a.nrx), dim3(64), 0, st, a);
+    PYSDR_HIP_CHECK(hipGetLastError());
+  }
   return PYSDR_OK;
 }
 

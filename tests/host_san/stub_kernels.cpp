@@ -260,17 +260,15 @@ int launch_pll(const Stage2Args& a, hipStream_t) {
       SAN_CHECK(a.ypll[r] != nullptr, "AM-Synch rx %d has no PLL buffer", r);
       read_all(a.y[r], (size_t)a.n_out);
       write_all(a.ypll[r], (size_t)a.n_out);
-      // am_pll_lanes_kernel: grid = ceil(K / 64) waves, one lane per segment; lane k may load y[i] for every i in
-      // [s0 - W, s1) with i >= 0 && i < s1 -- the lanes behind the last segment of the last wave must get an empty
-      // range (with s1 = s0 they read up to 63 segments past the end of y)
+      // am_pll_seg_kernel: grid (K, nrx), one wave per segment; segment k > 0 with s0 - W > 0 reads the phase words of
+      // [s0 - W, s1) -- the first 64 of them for its start guess, so W >= 64 must hold -- and segment 0 those of [0, s1)
       const int K = a.pll.K, T = a.pll.T, W = a.pll.W;
-      for (int k = 0; k < (K + 63) / 64 * 64; ++k) {
-        const bool live = k < K;
-        const long long s0 = (long long)k * T;
-        const long long s1 = live ? std::min<long long>(s0 + T, a.n_out) : 0;     // the kernel's rule
-        const long long lo = std::max<long long>(s0 - W, 0), hi = s1;             // indices with i >= 0 && i < s1
-        if (hi > lo) SAN_CHECK(hi <= a.n_out, "carrier-loop lane %d reads y[%lld..%lld) of %d", k, lo, hi, a.n_out);
-        if (!live) SAN_CHECK(hi <= lo, "dead lane %d has a range", k);
+      SAN_CHECK(W >= 64 && a.pll.Wexact <= W && a.pll.coarse_sweeps >= 0 && a.pll.coarse_sweeps <= 8, "carrier-loop plan W %d Wexact %d coarse %d", W, a.pll.Wexact, a.pll.coarse_sweeps);
+      for (int k = 0; k < K; ++k) {
+        const long long s0 = (long long)k * T, s1 = std::min<long long>(s0 + T, a.n_out);
+        const long long wb = (k > 0 && s0 - W > 0) ? s0 - W : 0;
+        SAN_CHECK(s1 > s0 && s1 <= a.n_out, "carrier-loop segment %d is [%lld, %lld) of %d", k, s0, s1, a.n_out);
+        if (wb > 0) SAN_CHECK(wb + 64 <= s0 && s0 <= a.n_out, "carrier-loop segment %d guesses from [%lld, %lld) of %d", k, wb, wb + 64, a.n_out);
       }
     }
   read_all(a.state, (size_t)a.nrx);

@@ -127,8 +127,8 @@ def test_wfm2_unlocked_loop_degenerates_to_the_serial_walk():
 
 
 def test_am_synch_carrier_pll_time_parallel_equals_the_serial_oracle():
-    """AM-Synch over 24 chunks in one call (24.5k outputs, 48 segments of 512 with a 4160-sample
-    warm-up) against the serial CarrierPLL of the oracle, chunk by chunk."""
+    """AM-Synch over 24 chunks in one call (24.5k outputs, 48 segments of 512 with a 3520-sample
+    warm-up; until round 4: 4160) against the serial CarrierPLL of the oracle, chunk by chunk."""
     cfg = dict(so.CONFIGS['C1'])
     cfg['ntaps_dec'] = 255
     cfg['rx'] = [dict(frq=100e3 - 7.0, mode='AM-Synch', video_bw=10e3, af_bw=5e3)]    # 7 Hz off tune
@@ -153,47 +153,72 @@ def test_am_synch_carrier_pll_time_parallel_equals_the_serial_oracle():
     assert abs(st.gain - o.agc.gain) <= 1e-5 * o.agc.gain
 
 
-def _am_synch_batch(x, B, L, cfg):
+def _am_synch_batch(x, B, L, cfg, serial=False):
     P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[7e6], mode='AM-Synch', nfilt=255, max_batch_chunks=B)
     P.VIDEO_BW = 10e3
     g = sig_proc.Receiver(P, 100e3 - 7.0, 0, '1')
     g.mode, g.af_bw = 'AM-Synch', 5e3
     ctx = P._pysdr_stream
+    if serial:
+        _lib.check(_lib.lib().pysdr_set_pll_segments(ctx.h, 1), "set_pll_segments")
     ctx.process_batch(x, B, L, on_device=False)
     am = ctx.fetch(0, B)[0].copy()
     seg, pat = pll_stats(ctx)
+    jw, jd = C.c_int(0), C.c_float(0)
+    _lib.check(_lib.lib().pysdr_pll_join_margin(ctx.h, 0, C.byref(jw), C.byref(jd)), "pll_join_margin")
     ctx.process_batch(x, B, L, on_device=False)          # second call: starts from the carried loop state
     am2 = ctx.fetch(0, B)[0].copy()
-    return am, am2, seg, pat, (g.agc.gain, g.agc.maxbuf)
+    return am, am2, seg, pat, (g.agc.gain, g.agc.maxbuf), (jw.value, jd.value)
 
 
-def test_am_synch_one_lane_per_segment_equals_one_wave_per_segment(monkeypatch):
-    """The carrier loop with one LANE per segment (am_pll_lanes_kernel: 64 segments per wave, the default beyond
-    2048 segments per call, forced here with PYSDR_AM_PLL_WAVES=0) against the round-2 kernel that spends a whole wave on every segment (PYSDR_AM_PLL_WAVES=1): the same
-    steps in the same order per segment, so the audio must be equal bit for bit -- 150 chunks = 153.6k outputs =
-    300 segments (four full waves and a ragged fifth, a last segment shorter than T), two calls in a row."""
+def test_am_synch_segments_equal_the_one_segment_walk_and_the_serial_oracle():
+    """Round 5: the carrier loop by block fixed-point sweeps on a 32-bit phase accumulator (am_pll_walk, stage2.hip; the
+    one-lane / one-wave per segment kernels this test used to compare bit for bit are gone).  150 chunks = 153.6k
+    outputs in ONE call = 300 segments of 512, every one but the first few started 16
+    loop time constants early from a guess, against (i) the SAME sweeps as one segment from the true state
+    (pysdr_set_pll_segments(ctx, 1): nothing guessed, nothing joined) and (ii) the serial float32 CarrierPLL of the
+    oracle, chunk by chunk -- same data, same bars as before (1e-5 of the AGC-normalised audio), two calls in a row."""
     cfg = dict(so.CONFIGS['C1'])
     cfg['ntaps_dec'] = 255
     cfg['rx'] = [dict(frq=100e3 - 7.0, mode='AM-Synch', video_bw=10e3, af_bw=5e3)]
     B = 150
     L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
     x = so.synth_iq(cfg, B * L, 5)
-    monkeypatch.setenv("PYSDR_TUNING", "1")              # the switch below is read only under the master switch
-    monkeypatch.setenv("PYSDR_AM_PLL_WAVES", "0")
-    a1, a2, seg, pat, agc = _am_synch_batch(x, B, L, cfg)
-    monkeypatch.setenv("PYSDR_AM_PLL_WAVES", "1")
-    b1, b2, seg_w, pat_w, agc_w = _am_synch_batch(x, B, L, cfg)
-    assert seg == seg_w and seg >= 290, (seg, seg_w)
-    assert pat == pat_w and pat <= 2, (pat, pat_w)
-    assert np.array_equal(a1, b1) and np.array_equal(a2, b2)
-    assert agc == agc_w
+    a1, a2, seg, pat, agc, (jw, jd) = _am_synch_batch(x, B, L, cfg)
+    b1, b2, seg_s, pat_s, agc_s, _ = _am_synch_batch(x, B, L, cfg, serial=True)
+    assert (seg_s, pat_s) == (1, 0)
+    assert seg >= 290 and pat <= 2, (seg, pat)
+    # the warm-ups met their neighbours with room to spare (tolerance 1024 words of 2^32 / 2e-8 rad per sample)
+    assert jw <= 512 and jd <= 1e-8, (jw, jd)
+    assert relerr(a1, b1) <= TOL and relerr(a2, b2) <= TOL
+    assert abs(agc[0] - agc_s[0]) <= 1e-5 * agc_s[0]
     assert np.max(np.abs(a1[2048:])) > 0.1 and not np.array_equal(a1, a2)
     # ... and both are the serial CarrierPLL of the oracle, chunk by chunk, over the two calls
     o = so.make_receivers(cfg, np.float32)[0]
     want = np.concatenate([o.demod_data(x[(k % B) * L:(k % B + 1) * L]) for k in range(2 * B)])
     assert len(want) == len(a1) + len(a2)
-    assert relerr(a1[1024:], want[1024:len(a1)]) <= TOL
-    assert relerr(a2, want[len(a1):]) <= TOL
+    for got in ((a1, a2), (b1, b2)):
+        assert relerr(got[0][1024:], want[1024:len(a1)]) <= TOL
+        assert relerr(got[1], want[len(a1):]) <= TOL
+
+
+def test_am_synch_unlocked_loop_degenerates_to_the_serial_walk():
+    """Noise and no carrier: the loop never locks, most warm-ups end somewhere else than their neighbours did, the
+    patch-up pass redoes those segments serially from the exact state until a segment's own start happens to lie
+    within the join tolerance (1.5e-6 rad) of it -- the audio is the one-segment walk's within the parity bar,
+    whatever it is worth, and the second call continues from the same carried state."""
+    cfg = dict(so.CONFIGS['C1'])
+    cfg['ntaps_dec'] = 255
+    B = 40
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    rng = np.random.default_rng(11)
+    x = (0.05 * (rng.standard_normal(B * L) + 1j * rng.standard_normal(B * L))).astype(np.complex64)
+    a1, a2, seg, pat, agc, _ = _am_synch_batch(x, B, L, cfg)
+    b1, b2, seg_s, pat_s, agc_s, _ = _am_synch_batch(x, B, L, cfg, serial=True)
+    assert (seg_s, pat_s) == (1, 0)
+    assert seg >= 30 and pat >= seg // 2, (seg, pat)
+    assert relerr(a1, b1) <= TOL and relerr(a2, b2) <= TOL, (relerr(a1, b1), relerr(a2, b2))
+    assert abs(agc[0] - agc_s[0]) <= 1e-5 * agc_s[0]
 
 
 def test_full_size_c4_time_parallel_equals_the_serial_walk():
