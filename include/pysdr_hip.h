@@ -54,7 +54,7 @@ typedef struct {
   double  srate;       /* P.SRATE, input complex sample rate (Hz)              */
   int32_t up, down;    /* P.UP, P.DOWN = up_dn(SRATE, FS_OUT)                  */
   int32_t in_chunk;    /* P.IN_CHUNK_SIZE, nominal samples per chunk           */
-  int32_t max_chunks;  /* capacity: chunks per pysdr_process_batch call        */
+  int32_t max_chunks;  /* capacity: chunks per pysdr_process_batch call, <= 16384 */
   int32_t ntaps_dec;   /* P.FILT_LEN, prototype length at srate*up             */
   int32_t ntaps_af;    /* AF filter length at FS_OUT                           */
   int32_t device;      /* HIP device ordinal                                   */

@@ -347,7 +347,12 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   // LDS-DMA takes any 4-byte aligned source: scripts/diag/glds_align_test.hip).
   const int mshape = (nrx == 1 && c->mfma_enable) ? mixdec_mfma_shape(up, down, d.kdec) : -1;
   MfmaPlan plan;
-  if (mshape >= 0 && mixdec_mfma_plan(mshape, s0, m0, n, &plan)) {
+  if (mshape >= 0 && !mixdec_mfma_plan(mshape, s0, m0, n, &plan)) {
+    // (falling through to the vector form here would sum THIS call in another order than its neighbours: an error instead)
+    set_last_error("decimator: call of %zu samples too long for the matrix-core form (2^30 samples per call)", n);
+    return PYSDR_ERR_ARG;
+  }
+  if (mshape >= 0) {
     MixMfmaArgs b;
     memset(&b, 0, sizeof(b));
     b.x = d_x;
@@ -630,6 +635,11 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   if (cfg->up < 1 || cfg->down < 1 || cfg->in_chunk < 1 || cfg->max_chunks < 1 ||
       cfg->ntaps_dec < 1 || cfg->ntaps_af < 1 || cfg->ntaps_af > 2048 || cfg->srate <= 0) {
     set_last_error("pysdr_create: invalid cfg");
+    return PYSDR_ERR_ARG;
+  }
+  if (cfg->max_chunks > 16384) {
+    // agc_scan_kernel holds two words per AGC block of a call (+ 1/16 padding) in LDS: 160 KB end at ~19 k blocks
+    set_last_error("pysdr_create: max_chunks %d > 16384 (the AGC scan keeps a call's blocks in LDS)", cfg->max_chunks);
     return PYSDR_ERR_ARG;
   }
   int rc = use_device(cfg->device);

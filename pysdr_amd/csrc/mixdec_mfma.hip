@@ -30,10 +30,11 @@
 //               phase (v_sin / v_cos of the exact 32-bit phase) and stores straight to memory.
 //   order     an output's sum runs over its window in a fixed order that depends only on its ABSOLUTE index
 //               (row = m div (UP*S), column = m mod (UP*S)): batch == chunk by chunk bit for bit, like the vector
-//               form.  Zero columns contribute fma(0, x, acc) = acc exactly for finite x; samples outside the
-//               call + history are never loaded (the images are zeroed once per launch and only ever hold
-//               finite stream samples afterwards).  A non-finite INPUT sample poisons all S*UP outputs of its
-//               rows instead of only those whose taps reach it -- the one observable difference.
+//               form.  Zero columns contribute fma(0, x, acc) = acc exactly for finite x; slots for samples outside
+//               the call + history hold zeros (zeroed once per launch, and again by every edge tile that is staged
+//               over an older one).  A non-finite INPUT sample poisons all S*UP outputs of its
+//               rows instead of only those whose taps reach it -- the one observable difference
+//               (tests/test_gpu_parity.py::test_non_finite_input_on_the_matrix_core_path).
 // DESIGN.md 4.1b has the measurements that led here; MM_NO_* / MM_*_PRIO / MM_C?_* are compile-time A/B switches for
 // scripts/diag/mfma_ablate.sh (work-skipping ones give WRONG results and exist for timing only).
 #include "common.h"
@@ -109,6 +110,11 @@ __device__ __forceinline__ void mm_stage(const MixMfmaArgs& a, int origin_rel, u
     const bool ok = (w != G::P / 2) && rel >= -a.hist_len && rel + 1 < (int)a.n_total;
     const float2* src = (rel >= 0) ? (a.x + rel) : (a.hist + (a.hist_len + rel));
     if (ok) mm_glds16<G::NT>(src, img + (unsigned)pc * 1024u);
+    // a pair outside [history | call] is ZEROED, not skipped: the slot still holds a sample of the tile that used this
+    // image NBUF trips ago, and a stale NaN / Inf there would reach valid outputs through the zero columns (0 * NaN)
+    // (the pair that starts on the last sample of an odd-length call is written below, by one lane)
+    else if (w != G::P / 2 && rel != (int)a.n_total - 1)
+      *(mm_lds_f4)(size_t)(img + (unsigned)q * 16u) = (mm_f4){0.f, 0.f, 0.f, 0.f};
   }
   mm_m0_restore(keep);
   // the last sample of an odd-length call starts a pair whose second half does not exist
@@ -161,12 +167,16 @@ struct MmChunk {
     ck = div_magic((uint32_t)i_lo, a.chunk_len, a.magic_chunk);
     ck_end = (int)((ck + 1u) * a.chunk_len);
   }
-  // the image [origin, origin + span) clipped to the call: true when it lies inside ONE chunk (ck)
+  // true when the image [origin, origin + span) lies inside the call AND inside ONE chunk (ck): then the consumers take
+  // the raw peak of the samples they read anyway.  An image the call clips -- the first tiles reach back into the
+  // history, i.e. into the PREVIOUS call's last samples, the last ones past the end -- goes through the copy waves' scan,
+  // which clips to [0, n_total) (unclipped, a burst in the last ~KT samples of a call was also counted
+  // into chunk 0 of the next one, and auto_mute held one chunk too long)
   __device__ __forceinline__ bool advance(const MixMfmaArgs& a, int origin, int span) {
     const int i_lo = origin > 0 ? origin : 0;
     const int i_end = (origin + span < (int)a.n_total) ? origin + span : (int)a.n_total;
     while (i_lo >= ck_end) { ck += 1u; ck_end += (int)a.chunk_len; }
-    return i_end <= ck_end || i_end <= i_lo;
+    return origin >= 0 && origin + span <= (int)a.n_total && i_end <= ck_end;
   }
 };
 

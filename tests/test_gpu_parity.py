@@ -336,6 +336,91 @@ def test_long_prototype_does_not_depend_on_the_cut(fs, ntaps, grid, monkeypatch)
     assert relerr(iq1, want) <= TOL
 
 
+@pytest.mark.parametrize("fs,ntaps", [(2.048e6, 1001), (1.024e6, 1001), (1.024e6, 255)])
+def test_raw_chunk_peaks_belong_to_their_own_chunk(fs, ntaps):
+    """`peak_in` (what rx.auto_mute judges, receiver.py:238-245) is max |x|^2 over the samples of ITS chunk
+    and of nothing else.  The matrix-core front end reads the tail of the previous call as history; its first tiles
+    used to count those samples into chunk 0, so a burst in the last 300 samples of a call also muted the next one.
+    The largest sample of every chunk sits next to a chunk / call boundary here (the last 300 or the first 40 samples
+    of the chunk), one RX with the long prototype (MFMA path; 255 taps: the vector form), and the peaks must equal
+    NumPy's per-chunk maximum exactly -- chunk by chunk, as one batch, and cut at random places."""
+    cfg = dict(so.CONFIGS['C1'], fs=fs, ntaps_dec=ntaps,
+               carriers=[dict(f=0.05 * fs, kind='am', amp=0.1, tone=1000.0, depth=0.5)],
+               rx=[dict(frq=0.05 * fs, mode='AM', video_bw=10e3, af_bw=5e3)])
+    L = so.chunk_sizes(fs, 48e3)[3]
+    B = 10
+    x = so.synth_iq(cfg, B * L, 33).copy()
+    rng = np.random.default_rng(8)
+    for k in range(B):
+        if k % 3 == 1:
+            continue                                      # no burst of its own BEHIND a chunk that ends in one: its peak is the carrier's
+        j = (k + 1) * L - 1 - int(rng.integers(0, 300)) if k % 3 == 0 else k * L + int(rng.integers(0, 40))
+        x[j] = np.complex64((0.6 + 0.03 * k) * np.exp(1j * k))
+    want = np.array([np.max(np.abs(x[k * L:(k + 1) * L].astype(np.complex128)) ** 2) for k in range(B)])
+    P1, g1 = make_gpu_receivers(cfg)
+    pk1 = []
+    for k in range(B):
+        g1[0].demod_data(x[k * L:(k + 1) * L])
+        pk1.append(g1[0].peak_in)
+    assert np.allclose(pk1, want, rtol=1e-6, atol=0), (pk1, want)
+    P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    P2._pysdr_stream.process_batch(x, B, L, on_device=False)
+    pk2 = P2._pysdr_stream.fetch(0, B)[3]
+    assert np.array_equal(np.asarray(pk2, np.float32), np.asarray(pk1, np.float32)), (pk2, pk1)
+    # two batches (4 + 6 chunks): chunk 0 of the second call has no burst and follows one whose burst sits in its last 300 samples
+    P3, g3 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    pk3 = []
+    for lo, hi in ((0, 4), (4, B)):
+        P3._pysdr_stream.process_batch(x[lo * L:hi * L], hi - lo, L, on_device=False)
+        pk3.extend(P3._pysdr_stream.fetch(0, hi - lo)[3])
+    assert np.array_equal(np.asarray(pk3, np.float32), np.asarray(pk1, np.float32)), (pk3, pk1)
+    # odd lengths: every call is ONE chunk of its own length (demod_data), the peak is that call's maximum
+    cuts = np.sort(rng.choice(np.arange(1, B * L), 7, replace=False))
+    P4, g4 = make_gpu_receivers(cfg, max_batch_chunks=4)
+    for a, b in zip(np.r_[0, cuts], np.r_[cuts, B * L]):
+        for c in range(a, b, 4 * L):
+            e = min(c + 4 * L, b)
+            g4[0].demod_data(x[c:e])
+            w = np.max(np.abs(x[c:e].astype(np.complex128)) ** 2)
+            assert abs(g4[0].peak_in - w) <= 1e-6 * w, (c, e, g4[0].peak_in, w)
+
+
+def test_non_finite_input_on_the_matrix_core_path():
+    """The one documented difference of the matrix-core front end (mixdec_mfma.hip): a non-finite
+    INPUT sample makes every output whose ROW of windows holds it non-finite (0 * NaN in the zero columns of the
+    shifted-tap operand), not only the outputs whose taps reach it as in the oracle and the vector form.  Pinned here:
+    the damage is confined to the neighbourhood of the sample (one row block of the tile = a few dozen outputs either
+    side of where the oracle is hit), everything else of the call AND the next call is untouched bit for bit, and
+    the stale sample does not survive in an LDS image slot."""
+    cfg = dict(so.CONFIGS['C1'])
+    L = so.chunk_sizes(cfg['fs'], 48e3)[3]
+    B = 6
+    x = so.synth_iq(cfg, B * L, 34)
+    xn = x.copy()
+    j = 2 * L + 12345
+    xn[j] = np.complex64(complex(np.nan, 0.0))
+    P1, g1 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    P1._pysdr_stream.process_batch(x, B, L, on_device=False)
+    iq_clean = P1._pysdr_stream.fetch(0, B)[1].copy()
+    P1._pysdr_stream.process_batch(x, B, L, on_device=False)
+    iq_clean2 = P1._pysdr_stream.fetch(0, B)[1].copy()
+    P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    P2._pysdr_stream.process_batch(xn, B, L, on_device=False)
+    iq_bad = P2._pysdr_stream.fetch(0, B)[1].copy()
+    P2._pysdr_stream.process_batch(x, B, L, on_device=False)
+    iq_after = P2._pysdr_stream.fetch(0, B)[1].copy()
+    bad = ~np.isfinite(iq_bad)
+    m_hit = j * 3 // 128                                   # the output whose newest sample is about x[j]
+    idx = np.flatnonzero(bad)
+    assert idx.size > 0
+    # the oracle's reach: 1001 taps at 3/128 = 24 outputs behind the sample; the matrix form: its row of windows
+    # (S*UP outputs per window, 16 windows per row block) -- everything non-finite lies within 128 outputs of the sample
+    assert idx.min() >= m_hit - 128 and idx.max() <= m_hit + 128, (m_hit, idx.min(), idx.max())
+    assert idx.size <= 160
+    assert np.array_equal(iq_bad[~bad], iq_clean[~bad])
+    assert np.array_equal(iq_after, iq_clean2)            # nothing of it is left in the context
+
+
 @pytest.mark.parametrize("L", [20000, 3000, 170666 // 4])
 def test_batch_of_short_chunks_equals_chunked_bit_exact(L):
     """The same identity with chunks far shorter than the kernels' tiles: an AGC block is then 18 -
