@@ -45,7 +45,7 @@ PSD_CHUNK, PSD_NFFT = 32768, 65536
 DEFAULT_CHUNKS = {"c1": 4096, "c1synch": 4096, "c2": 2048, "c3": 2048, "rx6": 2048, "c4": 2048, "c4mono": 2048}
 TUNING_ENV = ("PYSDR_TUNING", "PYSDR_MIXDEC_WGS", "PYSDR_MIXDEC_YFLUSH", "PYSDR_DEBUG_FLAGS", "PYSDR_PSD_GROUP",
               "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_PSD_STREAMS", "PYSDR_PSD_PACKED", "PYSDR_WFM_PLL", "PYSDR_MIXDEC_MFMA", "PYSDR_MIXDEC_GRID", "PYSDR_RESAMP_PLAIN",
-              "PYSDR_AM_PLL", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS", "PYSDR_MFMA_FLAGS")
+              "PYSDR_AM_PLL", "PYSDR_OVERLAP", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS", "PYSDR_MFMA_FLAGS")
 # the single-GPU configurations the default line carries next to C3: BASELINE.json configs[0], [1], [3], and the three the
 # reference also runs that the driver's record did not hold until round 5 (mono broadcast FM, MAX_RX = 6, AM-Synch)
 OTHER_CONFIGS = ("c1", "c2", "c4", "c4mono", "rx6", "c1synch")
@@ -75,6 +75,9 @@ def parse(argv=None):
     ap.add_argument("--overlap-psd", action="store_true", help="PSD on its own stream, unordered w.r.t. the demod")
     ap.add_argument("--serial-psd", action="store_true", help="PSD strictly behind the whole demod (incl. stage 2)")
     ap.add_argument("--no-demod", action="store_true", help="diagnostic: PSD only")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="A/B: every call on ONE stream (pysdr_set_overlap(ctx, 0)); default: the audio-rate half of a call runs "
+                         "beside the front end of the next one")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: no HIP events inside the calls of the timed loop (what the live kernel timing costs)")
     ap.add_argument("--tile-bytes", type=int, default=0)
@@ -609,6 +612,8 @@ def main():
                           device=device, max_batch_chunks=B)
         ctx = sig_proc._context_for(P)
     nsamp = B * L
+    if args.no_overlap:
+        _lib.check(lib.pysdr_set_overlap(ctx.h, 0), "set_overlap")
     if args.tile_bytes or args.threads:
         _lib.check(lib.pysdr_set_tile(ctx.h, args.tile_bytes, args.threads or 1024), "set_tile")
 
@@ -903,7 +908,7 @@ def main():
         "carrier_pll": cpll,
         "tuning": {"diag_build": int(tune[0]), "debug_flags": int(tune[1]), "mixdec_wgs_per_cu": int(tune[2]),
                    "mixdec_yflush_cap": int(tune[3]), "tile_bytes": int(tune[4]), "threads": int(tune[5]),
-                   "mixdec_mfma": int(tune[7]),
+                   "mixdec_mfma": int(tune[7]), "overlap_calls": int(lib.pysdr_get_overlap(ctx.h)),
                    "psd_group": int(sp_tune[0]) if sp is not None else None,
                    "psd_rocfft": int(sp_tune[1]) if sp is not None else None,
                    "psd_streams": int(sp_tune[2]) if sp is not None else None,

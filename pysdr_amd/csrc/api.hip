@@ -101,6 +101,7 @@ struct RxHost {
   float agc_ref = 0.5f;
   float sq_thresh = 0.f;
   float2* d_y = nullptr;        // [hy + mmax]
+  float2* d_y_alt = nullptr;    // the second buffer of the pair, allocated when the context overlaps its calls (pysdr_set_overlap)
   float2* d_ypll = nullptr;     // [hy + mmax], allocated on first AM-Synch use
   float2* d_a = nullptr;        // [mmax]
   float* d_am = nullptr;        // [2*mmax]
@@ -112,6 +113,7 @@ struct RxHost {
   bool wfm_dirty = true;
   Decim wfm_audio;                 // per-RX resampler fs1 -> FS_OUT
   float2* d_y1 = nullptr;          // [2 + m1max] IF-rate IQ (1-sample history in slot 1)
+  float2* d_y1_alt = nullptr;      // its pair (pysdr_set_overlap)
   float2* d_w = nullptr;           // [m1max] composite * (1 + 2j sin 2theta)
 };
 
@@ -123,6 +125,21 @@ struct pysdr_ctx {
   RxHost rx[PYSDR_MAX_RX];
   std::mutex mu;
   hipStream_t stream = nullptr;
+  // pysdr_set_overlap: the audio-rate half of a call (PLL walks, detector + AF FIR, AGC, and for broadcast FM everything
+  // behind the IF decimator) runs on stream2 BESIDE the front end of the next call on `stream`.  What the front end writes
+  // and the second half reads -- the FS_OUT-rate IQ y, the IF-rate IQ y1 -- then alternates between two buffers (`par`),
+  // each half's history prefix is rolled into the OTHER buffer, and two events order the halves: ev_front (front end of
+  // call k done -> its second half may start) and ev_s2[par] (second half of call k done -> the front end of call k + 2
+  // may overwrite buffer par).  Off: stream2 is not used, par stays put, nothing is recorded -- the single-stream form.
+  hipStream_t stream2 = nullptr;
+  bool overlap = false;
+  int overlap_env = -1;          // PYSDR_OVERLAP=0/1 (under PYSDR_TUNING): pysdr_set_overlap is overruled (A/B runs, the test suite in both forms)
+  int par = 0;                   // buffer of the pair the NEXT call's front end writes
+  int last_par = 0;              // ... and the one the last call wrote (pysdr_fetch reads its IQ)
+  hipEvent_t ev_s2[2] = {nullptr, nullptr};
+  bool s2_pending[2] = {false, false};
+  int n_ingest = 0;              // ingest rings on this context (they run it single-stream)
+  hipStream_t s2() const { return overlap ? stream2 : stream; }
   int hy = 0, mmax = 0;
   size_t cap_samples = 0;
   Decim main;                    // SRATE -> FS_OUT (UP/DOWN) for the narrow-band modes
@@ -243,6 +260,7 @@ struct pysdr_ingest {
   std::vector<std::vector<int>> chunk_nout;     // [nslots][chunks of the slot's last submit]
   std::vector<int> cx;                    // [nslots*MAX_RX]
   unsigned long long seq = 0;
+  bool counted = false;                   // this ring is in its context's n_ingest
 };
 
 namespace {
@@ -334,7 +352,7 @@ inline bool is_wfm(int m) { return m == PYSDR_WFM || m == PYSDR_WFM2; }
 struct DecimResult { int n_out; uint32_t t0; unsigned long long m0; };
 int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, float2* const* y,
               const uint32_t* phase0, const uint32_t* fword, unsigned* peak, size_t chunk_len,
-              int y_cap, DecimResult* res) {
+              int y_cap, DecimResult* res, hipStream_t st) {
   const int up = d.up, down = d.down;
   const unsigned long long s0 = d.s_abs, s1 = s0 + n;
   const unsigned long long m0 = (s0 * up + down - 1) / down, m1 = (s1 * up + down - 1) / down;
@@ -372,7 +390,7 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
     b.hist_new = d.d_hist[d.hist_cur ^ 1];
     b.zero = peak ? c->d_peak2[c->peak_cur ^ 1] : nullptr;
     b.zero_n = peak ? c->cfg.max_chunks : 0;
-    int rc = launch_mixdec_mfma(mshape, b, c->grid_override > 0 ? c->grid_override : c->num_cus, c->stream);
+    int rc = launch_mixdec_mfma(mshape, b, c->grid_override > 0 ? c->grid_override : c->num_cus, st);
     if (rc) return rc;
     if (peak) c->peak_clean[c->peak_cur ^ 1] = true;
     d.hist_cur ^= 1;
@@ -461,11 +479,11 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   a.hist_new = d.d_hist[d.hist_cur ^ 1];
   a.zero = peak ? c->d_peak2[c->peak_cur ^ 1] : nullptr;
   a.zero_n = peak ? c->cfg.max_chunks : 0;
-  int rc = small ? launch_resamp_small(a, c->grid_override, c->resamp_plain, c->stream)
-                 : launch_mixdec(a, c->threads, c->grid_override > 0 ? c->grid_override : c->num_cus * wgs, c->stream);
+  int rc = small ? launch_resamp_small(a, c->grid_override, c->resamp_plain, st)
+                 : launch_mixdec(a, c->threads, c->grid_override > 0 ? c->grid_override : c->num_cus * wgs, st);
   if (rc) return rc;
   if (small && n_out <= 0) {          // the resampler starts no kernel for a call without outputs: the roll on its own
-    rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, a.zero, a.zero_n, c->stream);
+    rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, a.zero, a.zero_n, st);
     if (rc) return rc;
   }
   if (peak) c->peak_clean[c->peak_cur ^ 1] = true;
@@ -497,7 +515,8 @@ struct RxSnap {
   uint32_t fword = 0, phase = 0, bfo_fword = 0;
   float sq_thresh = 0.f;
   int taps_real = 0;
-  float2 *d_y = nullptr, *d_ypll = nullptr, *d_a = nullptr, *d_y1 = nullptr, *d_w = nullptr;
+  float2 *d_y = nullptr, *d_ypll = nullptr, *d_a = nullptr, *d_y1 = nullptr, *d_w = nullptr;   // d_y / d_y1: THIS call's buffer of the pair
+  float2 *d_y_next = nullptr, *d_y1_next = nullptr;      // the next call's (the same one unless the calls overlap): gets the history prefix
   float* d_am = nullptr;
   float2* d_aftaps = nullptr;
 };
@@ -511,6 +530,24 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
   snap->nrx = c->nrx;
   snap->nwfm = 0;
   for (int r = 0; r < c->nrx; ++r) snap->nwfm += is_wfm(c->rx[r].mode) ? 1 : 0;
+  // Overlapping calls: whatever a setter left to do (taps, resets, buffers) is done with BOTH streams drained -- it is
+  // rare, and everything below may then go on `stream` as in the single-stream form (drained again at the end, so that
+  // the second half on stream2 sees it).
+  bool drained = false;
+  if (c->overlap) {
+    bool dirty = false;
+    for (int r = 0; r < c->nrx; ++r) {
+      const RxHost& x = c->rx[r];
+      dirty |= x.taps_dirty || x.af_dirty || x.agc_dirty || x.reset_pending != 0 || (is_wfm(x.mode) && x.wfm_dirty) ||
+               (x.mode == PYSDR_AM_SYNCH && x.d_ypll == nullptr) || x.d_y_alt == nullptr || (x.d_y1 != nullptr && x.d_y1_alt == nullptr);
+    }
+    if (dirty) {
+      PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream2));
+      PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+      c->s2_pending[0] = c->s2_pending[1] = false;
+      drained = true;
+    }
+  }
   if (snap->nwfm != 0 && snap->nwfm != c->nrx) {
     // the reference's mode is global (P.MODE) and the rate-reduction order differs for
     // broadcast FM (receiver.py:718-719): one context runs one pipeline
@@ -535,6 +572,7 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       if (!x.d_y1) {
         PYSDR_HIP_CHECK(hipMalloc(&x.d_y1, ((size_t)c->m1max + 2) * sizeof(float2)));
         PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y1, 0, ((size_t)c->m1max + 2) * sizeof(float2), c->stream));
+        drained = drained || c->overlap;      // (the pair's second buffer follows below)
         PYSDR_HIP_CHECK(hipMalloc(&x.d_w, (size_t)c->m1max * sizeof(float2)));
         rc = decim_init(x.wfm_audio, c->up2, c->down2, (int)x.wfm_resamp.size(), 1, c->stream);
         if (rc) return rc;
@@ -579,12 +617,28 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       PYSDR_HIP_CHECK(hipMalloc(&x.d_ypll, n * sizeof(float2)));
       PYSDR_HIP_CHECK(hipMemsetAsync(x.d_ypll, 0, n * sizeof(float2), c->stream));
     }
+    if (c->overlap && x.d_y_alt == nullptr) {
+      const size_t ny = (size_t)c->hy + c->mmax;
+      PYSDR_HIP_CHECK(hipMalloc(&x.d_y_alt, ny * sizeof(float2)));
+      PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y_alt, 0, ny * sizeof(float2), c->stream));
+    }
+    if (c->overlap && x.d_y1 != nullptr && x.d_y1_alt == nullptr) {
+      PYSDR_HIP_CHECK(hipMalloc(&x.d_y1_alt, ((size_t)c->m1max + 2) * sizeof(float2)));
+      PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y1_alt, 0, ((size_t)c->m1max + 2) * sizeof(float2), c->stream));
+    }
     RxSnap& q = snap->rx[r];
     q.mode = x.mode; q.fword = x.fword; q.phase = x.phase; q.bfo_fword = x.bfo_fword;
     q.sq_thresh = x.sq_thresh; q.taps_real = x.taps_real;
-    q.d_y = x.d_y; q.d_ypll = x.d_ypll; q.d_a = x.d_a; q.d_am = x.d_am; q.d_aftaps = x.d_aftaps;
-    q.d_y1 = x.d_y1; q.d_w = x.d_w;
+    q.d_ypll = x.d_ypll; q.d_a = x.d_a; q.d_am = x.d_am; q.d_aftaps = x.d_aftaps;
+    q.d_w = x.d_w;
+    // this call's buffer of each pair and the next call's (the other one when the calls overlap)
+    const int p = c->par, pn = c->overlap ? (p ^ 1) : p;
+    q.d_y = p ? x.d_y_alt : x.d_y;
+    q.d_y_next = pn ? x.d_y_alt : x.d_y;
+    q.d_y1 = p ? x.d_y1_alt : x.d_y1;
+    q.d_y1_next = pn ? x.d_y1_alt : x.d_y1;
   }
+  if (drained) PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
   return PYSDR_OK;
 }
 
@@ -665,6 +719,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
       if (nf >= 5 && tm >= 64) c->am_tmin = (tm + 63) & ~63;
     } }
   { const char* e = tuning_env("PYSDR_MIXDEC_MFMA"); if (e && *e) c->mfma_enable = atoi(e) ? 1 : 0; }
+  { const char* e = tuning_env("PYSDR_OVERLAP"); if (e && *e) c->overlap_env = atoi(e) ? 1 : 0; }
   { const char* e = tuning_env("PYSDR_RESAMP_PLAIN"); if (e && *e) c->resamp_plain = atoi(e); }
   { const char* e = tuning_env("PYSDR_MIXDEC_GRID"); if (e && atoi(e) > 0) c->grid_override = atoi(e); }
   { const char* e = tuning_env("PYSDR_WFM_PLL");
@@ -724,6 +779,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
     for (int i = 0; i < 4; ++i) CK(hipEventCreate(&c->ev[k][i]));
   CK(hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming));
 #undef CK
+  if (c->overlap_env == 1) { rc = pysdr_set_overlap(c, 1); if (rc) { pysdr_destroy(c); return rc; } }
   *out = c;
   return PYSDR_OK;
 }
@@ -732,10 +788,13 @@ void pysdr_destroy(pysdr_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   pysdr_comm_destroy(c);
   for (int r = 0; r < PYSDR_MAX_RX; ++r) {
     RxHost& x = c->rx[r];
     if (x.d_y) (void)hipFree(x.d_y);
+    if (x.d_y_alt) (void)hipFree(x.d_y_alt);
+    if (x.d_y1_alt) (void)hipFree(x.d_y1_alt);
     if (x.d_ypll) (void)hipFree(x.d_ypll);
     if (x.d_a) (void)hipFree(x.d_a);
     if (x.d_am) (void)hipFree(x.d_am);
@@ -758,6 +817,8 @@ void pysdr_destroy(pysdr_ctx* c) {
   for (int k = 0; k < pysdr_ctx::kSlots; ++k)
     for (int i = 0; i < 4; ++i) if (c->ev[k][i]) (void)hipEventDestroy(c->ev[k][i]);
   if (c->ev_front) (void)hipEventDestroy(c->ev_front);
+  for (int i = 0; i < 2; ++i) if (c->ev_s2[i]) (void)hipEventDestroy(c->ev_s2[i]);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -866,8 +927,8 @@ int pysdr_squelch_get(pysdr_ctx* c, int irx, float* level, int* open) {
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
-  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
-  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->s2()));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->s2()));
   if (level) *level = d.sq_level;
   if (open) *open = d.sq_open;
   return PYSDR_OK;
@@ -878,8 +939,8 @@ int pysdr_pll_stats(pysdr_ctx* c, int irx, int* segments, int* patched) {
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
-  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
-  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->s2()));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->s2()));
   if (segments) *segments = d.pll_segments;
   if (patched) *patched = d.pll_patched;
   return PYSDR_OK;
@@ -890,8 +951,8 @@ int pysdr_pll_join_margin(pysdr_ctx* c, int irx, int* max_words, float* max_dw) 
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
-  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
-  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->s2()));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->s2()));
   if (max_words) *max_words = d.pll_join_words;
   if (max_dw) *max_dw = d.pll_join_dw;
   return PYSDR_OK;
@@ -908,8 +969,8 @@ int pysdr_agc_get(pysdr_ctx* c, int irx, pysdr_agc_state* st) {
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
-  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
-  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->s2()));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->s2()));
   st->agc = d.env; st->gain = d.gain; st->maxbuf = d.maxbuf; st->ref = d.ref; st->err = d.err;
   return PYSDR_OK;
 }
@@ -974,8 +1035,35 @@ int pysdr_sync(pysdr_ctx* c) {
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (c->overlap) {
+    PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream2));
+    c->s2_pending[0] = c->s2_pending[1] = false;
+  }
   return PYSDR_OK;
 }
+
+int pysdr_set_overlap(pysdr_ctx* c, int enable) {
+  if (!c) return PYSDR_ERR_ARG;
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  if (enable && c->n_ingest > 0) {
+    set_last_error("pysdr_set_overlap: the context feeds an ingest ring, which queues its result copies behind each call on one stream");
+    return PYSDR_ERR_STATE;
+  }
+  // both halves drained: the switch happens between two calls, whatever is queued
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (c->stream2) PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream2));
+  c->s2_pending[0] = c->s2_pending[1] = false;
+  if (c->overlap_env >= 0 && c->n_ingest == 0) enable = c->overlap_env;
+  if (enable && !c->stream2) {
+    PYSDR_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_s2[i], hipEventDisableTiming));
+  }
+  c->overlap = enable != 0;
+  return PYSDR_OK;
+}
+
+int pysdr_get_overlap(pysdr_ctx* c) { return (c && c->overlap) ? 1 : 0; }
 
 int pysdr_wfm_params(double srate, double fs_out, int* d1, int* up2, int* down2) {
   if (srate <= 0 || fs_out <= 0) return PYSDR_ERR_ARG;
@@ -1038,6 +1126,14 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   if (rc) return rc;
   const int nrx = snap.nrx;
   const bool wfm = snap.nwfm > 0;
+  // the two halves of the call: `stream` takes the front end, S2 everything behind it (the same stream unless the calls overlap)
+  hipStream_t S2 = c->s2();
+  const int par = c->par;
+  if (c->overlap && c->s2_pending[par]) {
+    // the second half of the call before last is the last reader of this call's buffers
+    PYSDR_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_s2[par], 0));
+    c->s2_pending[par] = false;
+  }
 
   const int up = c->cfg.up, down = c->cfg.down;
   const unsigned long long s0 = wfm ? c->wfm_front.s_abs : c->main.s_abs;
@@ -1057,7 +1153,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   int n1 = 0;
   if (!wfm) {
     for (int r = 0; r < nrx; ++r) yptr[r] = snap.rx[r].d_y + c->hy;
-    rc = decim_run(c, c->main, d_x, n, nrx, yptr, ph, fw, c->d_peak, chunk_len, c->mmax, &res);
+    rc = decim_run(c, c->main, d_x, n, nrx, yptr, ph, fw, c->d_peak, chunk_len, c->mmax, &res, c->stream);
     if (rc) return rc;
     c->wfm_front.s_abs = c->main.s_abs;       // both pipelines count the same input stream
   } else {
@@ -1065,10 +1161,15 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     // then each RX's own fs1 -> FS_OUT resampler
     for (int r = 0; r < nrx; ++r) yptr[r] = snap.rx[r].d_y1 + 2;
     DecimResult r1;
-    rc = decim_run(c, c->wfm_front, d_x, n, nrx, yptr, ph, fw, c->d_peak, chunk_len, c->m1max, &r1);
+    rc = decim_run(c, c->wfm_front, d_x, n, nrx, yptr, ph, fw, c->d_peak, chunk_len, c->m1max, &r1, c->stream);
     if (rc) return rc;
     c->main.s_abs = c->wfm_front.s_abs;
     n1 = r1.n_out;
+    // broadcast FM: the front end is the IF decimator; discriminator, pilot loop and audio resampler belong to the second half
+    if (c->overlap) {
+      PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream));
+      PYSDR_HIP_CHECK(hipStreamWaitEvent(S2, c->ev_front, 0));
+    }
     WfmArgs w;
     memset(&w, 0, sizeof(w));
     w.nrx = nrx; w.n1 = n1;
@@ -1085,6 +1186,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     for (int r = 0; r < nrx; ++r) {
       w.y1[r] = snap.rx[r].d_y1 + 2;
       w.y1base[r] = snap.rx[r].d_y1;
+      w.y1dst[r] = snap.rx[r].d_y1_next;
       w.w[r] = snap.rx[r].d_w;
       w.stereo[r] = (snap.rx[r].mode == PYSDR_WFM2) ? 1 : 0;
     }
@@ -1106,13 +1208,13 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
         w.pll.Wc_mid = ((int)std::ceil(c->wfm_taus_mid * tau) + 63) & ~63;
       }
     }
-    rc = launch_wfm(w, c->stream);
+    rc = launch_wfm(w, S2);
     if (rc) return rc;
     const uint32_t zero = 0u;
     for (int r = 0; r < nrx; ++r) {
       float2* y1 = snap.rx[r].d_y + c->hy;
       rc = decim_run(c, c->rx[r].wfm_audio, snap.rx[r].d_w, (size_t)n1, 1, &y1, &zero, &zero, nullptr, 0,
-                     c->mmax, &res);
+                     c->mmax, &res, S2);
       if (rc) return rc;
     }
   }
@@ -1122,8 +1224,15 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   // kernel behind it starts that much later: scripts/diag/timeline.sh), so ONE event serves both the profile and the
   // ordering, and none is recorded when nobody asked for either.
   c->front_marker = nullptr;
-  if (c->profile) { PYSDR_HIP_CHECK(hipEventRecord(ev[1], c->stream)); c->front_marker = ev[1]; }
-  else if (c->front_wanted) { PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream)); c->front_marker = c->ev_front; }
+  if (wfm && c->overlap) {
+    // (recorded above, behind the IF decimator; the profile's second mark then sits where the pilot chain ends, on S2)
+    c->front_marker = c->ev_front;
+    if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[1], S2));
+  } else {
+    if (c->profile) { PYSDR_HIP_CHECK(hipEventRecord(ev[1], c->stream)); c->front_marker = ev[1]; }
+    else if (c->front_wanted || c->overlap) { PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream)); c->front_marker = c->ev_front; }
+    if (c->overlap) PYSDR_HIP_CHECK(hipStreamWaitEvent(S2, c->front_marker, 0));
+  }
 
   Stage2Args s;
   memset(&s, 0, sizeof(s));
@@ -1168,24 +1277,31 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
       s.pll.Wexact = ((int)std::ceil(c->am_taus_exact * tau) + 63) & ~63;
       s.pll.coarse_sweeps = c->am_coarse_sweeps;
     }
-    rc = launch_pll(s, c->stream);
+    rc = launch_pll(s, S2);
     if (rc) return rc;
   }
-  rc = launch_demod_fir(s, c->stream); if (rc) return rc;
+  rc = launch_demod_fir(s, S2); if (rc) return rc;
   // the gains, and beside them (same launch) the history roll of the FS_OUT-rate buffers: the AF FIR was their last reader
   EpilogueArgs e;
   memset(&e, 0, sizeof(e));
   e.nrx = nrx; e.n_out = n_out; e.hy = c->hy;
   for (int r = 0; r < nrx; ++r) {
     e.ybase[r] = snap.rx[r].d_y;
+    e.ydst[r] = snap.rx[r].d_y_next;
     e.ypllbase[r] = (s.det[r] == kDetPll) ? snap.rx[r].d_ypll : nullptr;
   }
-  rc = launch_agc_scan(s, e, c->stream); if (rc) return rc;
+  rc = launch_agc_scan(s, e, S2); if (rc) return rc;
   // WFM (mono) emits the real part of the complex pipeline
   for (int r = 0; r < nrx; ++r) if (snap.rx[r].mode == PYSDR_WFM) s.out_complex[r] = 0;
-  rc = launch_apply(s, c->stream); if (rc) return rc;
-  if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[3], c->stream));
+  rc = launch_apply(s, S2); if (rc) return rc;
+  if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[3], S2));
   c->ncalls++;
+  c->last_par = par;
+  if (c->overlap) {
+    PYSDR_HIP_CHECK(hipEventRecord(c->ev_s2[par], S2));
+    c->s2_pending[par] = true;
+    c->par = par ^ 1;
+  }
 
   {
     // the NCO phase belongs to the process thread; the lock only orders it against pysdr_rx_add
@@ -1224,13 +1340,16 @@ int pysdr_fetch(pysdr_ctx* c, int irx, float* am, float* iq, int cap, int* n_out
   if ((am || iq) && cap < n) { set_last_error("pysdr_fetch: cap %d < n_out %d", cap, n); return PYSDR_ERR_ARG; }
   const int cx = c->last_complex[irx];
   // The epilogue rolled the last hy outputs into the prefix but left [hy, hy+n) intact.
+  // (on the stream of the call's second half: it is ordered behind the front end, whose raw peaks and IQ these are)
+  hipStream_t S2 = c->s2();
+  const float2* yb = c->last_par ? c->rx[irx].d_y_alt : c->rx[irx].d_y;
   if (am && n > 0)
-    PYSDR_HIP_CHECK(hipMemcpyAsync(am, c->rx[irx].d_am, (size_t)n * (cx ? 2 : 1) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    PYSDR_HIP_CHECK(hipMemcpyAsync(am, c->rx[irx].d_am, (size_t)n * (cx ? 2 : 1) * sizeof(float), hipMemcpyDeviceToHost, S2));
   if (iq && n > 0)
-    PYSDR_HIP_CHECK(hipMemcpyAsync(iq, c->rx[irx].d_y + c->hy, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    PYSDR_HIP_CHECK(hipMemcpyAsync(iq, yb + c->hy, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, S2));
   if (peaks && c->last_nchunks > 0)
-    PYSDR_HIP_CHECK(hipMemcpyAsync(peaks, c->d_peak, (size_t)c->last_nchunks * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    PYSDR_HIP_CHECK(hipMemcpyAsync(peaks, c->d_peak, (size_t)c->last_nchunks * sizeof(float), hipMemcpyDeviceToHost, S2));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(S2));
   if (n_out) *n_out = n;
   if (am_is_complex) *am_is_complex = cx;
   if (chunk_nout) last_chunk_counts(c, chunk_nout);
@@ -1546,7 +1665,7 @@ int pysdr_spectrum_order(pysdr_spectrum* sp, pysdr_ctx* c, int direction) {
     return PYSDR_OK;
   }
   if (!sp->ev_order) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&sp->ev_order, hipEventDisableTiming));
-  hipStream_t first = direction == 0 ? c->stream : sp->stream;
+  hipStream_t first = direction == 0 ? c->s2() : sp->stream;     // (the second half of a call ends last)
   hipStream_t then = direction == 0 ? sp->stream : c->stream;
   PYSDR_HIP_CHECK(hipEventRecord(sp->ev_order, first));
   PYSDR_HIP_CHECK(hipStreamWaitEvent(then, sp->ev_order, 0));
@@ -1596,6 +1715,7 @@ void pysdr_ingest_destroy(pysdr_ingest* g) {
   if (g->c) (void)hipSetDevice(g->c->cfg.device);
   if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
   if (g->c && g->c->stream) (void)hipStreamSynchronize(g->c->stream);
+  if (g->c && g->counted) { g->c->n_ingest--; g->counted = false; }
   for (auto p : g->h_in) if (p) (void)hipHostFree(p);
   for (auto p : g->h_am) if (p) (void)hipHostFree(p);
   for (auto p : g->h_iq) if (p) (void)hipHostFree(p);
@@ -1623,8 +1743,13 @@ int pysdr_ingest_create_batched(pysdr_ctx* c, int nslots, int chunks_per_slot, p
   }
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
+  // A ring queues the result copies of a slot behind its call and the next slot's call behind those, all on ONE stream:
+  // the context runs single-stream from here on (the ring's rate is the PCIe link's, two orders below the kernels')
+  c->n_ingest++;
+  if (c->overlap) { rc = pysdr_set_overlap(c, 0); if (rc) { c->n_ingest--; return rc; } }
   pysdr_ingest* g = new pysdr_ingest();
   g->c = c; g->nslots = nslots; g->chunks_per_slot = chunks_per_slot;
+  g->counted = true;
   g->cap = (size_t)c->cfg.in_chunk * (size_t)chunks_per_slot;
   g->ocap = (int)((g->cap * (size_t)c->cfg.up) / (size_t)c->cfg.down) + 8;
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_last_error("pysdr_ingest_create: %s -> %s", #e, hipGetErrorString(_e)); pysdr_ingest_destroy(g); return PYSDR_ERR_HIP; } } while (0)
@@ -1698,7 +1823,7 @@ int pysdr_ingest_submit(pysdr_ingest* g, int slot, size_t n) {
     if (nout > 0) {
       PYSDR_HIP_CHECK(hipMemcpyAsync(g->h_am[(size_t)slot * PYSDR_MAX_RX + r], c->rx[r].d_am,
                                      (size_t)nout * (cx ? 2 : 1) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-      PYSDR_HIP_CHECK(hipMemcpyAsync(g->h_iq[(size_t)slot * PYSDR_MAX_RX + r], c->rx[r].d_y + c->hy,
+      PYSDR_HIP_CHECK(hipMemcpyAsync(g->h_iq[(size_t)slot * PYSDR_MAX_RX + r], (c->last_par ? c->rx[r].d_y_alt : c->rx[r].d_y) + c->hy,
                                      (size_t)nout * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
     }
   }

@@ -242,6 +242,8 @@ int launch_apply(const Stage2Args& a, hipStream_t st);
 struct EpilogueArgs {
   int nrx, n_out, hy;
   float2* ybase[PYSDR_MAX_RX];        // buffer start (prefix at [0,hy))
+  float2* ydst[PYSDR_MAX_RX];         // where the NEXT call's prefix lives: ybase, or the other buffer of the pair when the
+                                      // front end of the next call already writes beside this call's stage 2 (pysdr_set_overlap)
   float2* ypllbase[PYSDR_MAX_RX];     // may be null
 };
 // block gains (one workgroup per RX) + the history roll of the FS_OUT-rate buffers (two workgroups per RX), one launch
@@ -258,7 +260,8 @@ struct WfmArgs {
   float kp, ki, norm, rad2word;       // pilot PLL constants
   uint32_t fword0;                    // 19 kHz at fs1
   const float2* y1[PYSDR_MAX_RX];     // IF IQ, element 0 = first new sample (1-sample prefix)
-  float2* y1base[PYSDR_MAX_RX];       // buffer start (for the prefix roll)
+  float2* y1base[PYSDR_MAX_RX];       // buffer start
+  float2* y1dst[PYSDR_MAX_RX];        // buffer start of the NEXT call's IF buffer (= y1base unless the calls overlap): gets the prefix
   float2* w[PYSDR_MAX_RX];            // out: mpx*(1 + 2j*sin(2*theta)) (WFM: imag 0)
   int stereo[PYSDR_MAX_RX];
   RxDevState* state;

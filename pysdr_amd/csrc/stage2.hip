@@ -631,13 +631,14 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= a.nrx) {
     const int job = blockIdx.x - a.nrx;
-    float2* base = (job < eh.nrx) ? eh.ybase[job] : eh.ypllbase[job - eh.nrx];
+    const float2* base = (job < eh.nrx) ? eh.ybase[job] : eh.ypllbase[job - eh.nrx];
+    float2* dst = (job < eh.nrx) ? eh.ydst[job] : eh.ypllbase[job - eh.nrx];
     if (base == nullptr) return;
     float2* sh = reinterpret_cast<float2*>(agc_lds);
     // element j of the new prefix = old element n_out + j  (prefix occupies [0,hy))
     for (int j = tid; j < eh.hy; j += 256) sh[j] = base[eh.n_out + j];
     __syncthreads();
-    for (int j = tid; j < eh.hy; j += 256) base[j] = sh[j];
+    for (int j = tid; j < eh.hy; j += 256) dst[j] = sh[j];
     return;
   }
   const int r = blockIdx.x;
@@ -1112,7 +1113,7 @@ __global__ __launch_bounds__(64) void wfm_pll_check_kernel(const WfmArgs a) {
 __global__ __launch_bounds__(64) void wfm_pll_patch_kernel(const WfmArgs a) {
   const int r = blockIdx.x, lane = threadIdx.x;
   // roll the 1-sample IF history for the next call (the discriminator kernel is done: same stream)
-  if (lane == 0 && a.n1 > 0) a.y1base[r][1] = a.y1[r][a.n1 - 1];
+  if (lane == 0 && a.n1 > 0) a.y1dst[r][1] = a.y1[r][a.n1 - 1];
   if (!a.stereo[r] || a.n1 <= 0) return;
   const PllPlan& pl = a.pll;
   const int K = pl.K, n = a.n1;

@@ -14,7 +14,7 @@ class RunTimeParams:
     def __init__(self, fs=1e6, fsout=48e3, fc=(0.0,), mode='AM', foffset=100e3, nfilt=1001,
                  vid_bw=0.0, af_bw=0.0, bfo=0.0, duration=1e38, sdr_type='sdrplay',
                  auto_mute=False, src=None, audio=1, af_filt_len=255, device=0,
-                 max_batch_chunks=1):
+                 max_batch_chunks=1, overlap_calls=True):
         self.SRATE = float(fs)
         self.SDR_TYPE = sdr_type
         fc = np.atleast_1d(np.asarray(fc, np.float64))
@@ -86,6 +86,7 @@ class RunTimeParams:
         self.AF_FILT_LEN = int(af_filt_len)
         self.GPU_DEVICE = int(device)
         self.MAX_BATCH_CHUNKS = int(max_batch_chunks)
+        self.OVERLAP_CALLS = bool(overlap_calls)         # batch contexts: two overlapped halves per call (pysdr_set_overlap)
 
     def rx_offset(self, irx):
         """LO offset of sub-receiver ``irx`` (``receiver.py:829-834``)."""

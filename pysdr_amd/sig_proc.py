@@ -55,6 +55,11 @@ class _StreamContext:
         h = C.c_void_p()
         check(L.pysdr_create(C.byref(self.cfg), C.byref(h)), "pysdr_create")
         self.h = h
+        # A context sized for batches (replay, the benchmark) runs the audio-rate half of a call beside the mix +
+        # decimate of the next one (pysdr_set_overlap: two HIP streams, results unchanged); a live one-chunk context
+        # has nothing to overlap with -- every call is fetched before the next one exists
+        if self.max_chunks > 1 and bool(getattr(P, 'OVERLAP_CALLS', True)):
+            check(L.pysdr_set_overlap(self.h, 1), "pysdr_set_overlap")
         self.receivers = []
         self.seq = 0                 # chunks processed
         self.cache = {}              # irx -> (am, iq, peak)

@@ -21,7 +21,7 @@ if [ "$what" = asan ] || [ "$what" = all ]; then
   PYSDR_TUNING=1 PYSDR_MIXDEC_MFMA=0 ASAN_OPTIONS=detect_leaks=1 "$OUT/san_asan" > /dev/null   # long single-RX prototypes on the vector form
   # every tuning variable parsed (the staged / capped pilot-loop warm-up plan, the other resampler forms, small grids, groups)
   PYSDR_TUNING=1 PYSDR_WFM_PLL="20,13,4,3,1536,2048,5,4,4,4" PYSDR_RESAMP_PLAIN=2 PYSDR_MIXDEC_GRID=3 PYSDR_PSD_GROUP=64 PYSDR_PSD_STREAMS=3 \
-    PYSDR_PSD_PACKED=0 PYSDR_MIXDEC_YFLUSH=2 PYSDR_AM_PLL_WAVES=0 ASAN_OPTIONS=detect_leaks=1 "$OUT/san_asan" > /dev/null
+    PYSDR_PSD_PACKED=0 PYSDR_MIXDEC_YFLUSH=2 PYSDR_AM_PLL="14,4,4,1024,256" PYSDR_OVERLAP=1 ASAN_OPTIONS=detect_leaks=1 "$OUT/san_asan" > /dev/null
   ASAN_OPTIONS=detect_leaks=1 "$OUT/san_asan" race
 fi
 if [ "$what" = tsan ] || [ "$what" = all ]; then

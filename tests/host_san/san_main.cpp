@@ -35,6 +35,8 @@ static std::vector<double> taps(int n, double scale = 1.0) {
   return h;
 }
 
+static int g_overlap = 0;      // second pass of main(): every context runs its calls in two overlapped halves (pysdr_set_overlap)
+
 static pysdr_ctx* make_ctx(const Rate& r, int max_chunks, int ntaps_dec, int ntaps_af) {
   pysdr_cfg cfg;
   std::memset(&cfg, 0, sizeof(cfg));
@@ -42,6 +44,10 @@ static pysdr_ctx* make_ctx(const Rate& r, int max_chunks, int ntaps_dec, int nta
   cfg.max_chunks = max_chunks; cfg.ntaps_dec = ntaps_dec; cfg.ntaps_af = ntaps_af;
   pysdr_ctx* c = nullptr;
   OK(pysdr_create(&cfg, &c));
+  if (g_overlap) {
+    OK(pysdr_set_overlap(c, 1));
+    if (!pysdr_get_overlap(c)) { std::fprintf(stderr, "overlap did not switch on\n"); std::exit(1); }
+  }
   return c;
 }
 
@@ -114,6 +120,10 @@ static void narrowband(const Rate& r, int ntaps_dec) {
   // ingest ring: slot state machine
   pysdr_ingest* g = nullptr;
   OK(pysdr_ingest_create_batched(c, 3, 2, &g));
+  // a ring runs its context single-stream: creating one switches the overlap off, and it stays off while the ring lives
+  if (pysdr_get_overlap(c)) { std::fprintf(stderr, "ingest ring on an overlapped context\n"); std::exit(1); }
+  FAILS(pysdr_set_overlap(c, 1));
+  OK(pysdr_set_overlap(c, 0));
   { pysdr_ingest* bad = nullptr; FAILS(pysdr_ingest_create_batched(c, 3, max_chunks + 1, &bad)); }
   float* buf = nullptr;
   size_t cap = 0;
@@ -139,6 +149,10 @@ static void narrowband(const Rate& r, int ntaps_dec) {
   FAILS(pysdr_ingest_submit(g, 0, cap + 1));
   FAILS(pysdr_ingest_submit(g, 7, 1));
   pysdr_ingest_destroy(g);
+  OK(pysdr_set_overlap(c, g_overlap));                                           // the ring is gone: allowed again
+  run_calls(c, r, nrx, max_chunks, {L, 3});                                      // ... and the stream goes on from whichever buffer of the pair is current
+  OK(pysdr_set_overlap(c, 0));
+  run_calls(c, r, nrx, max_chunks, {L});
   pysdr_destroy(c);
 }
 
@@ -268,6 +282,8 @@ int main(int argc, char** argv) {
   int ndev = 0;
   OK(pysdr_device_count(&ndev));
   FAILS(pysdr_create(nullptr, nullptr));
+  FAILS(pysdr_set_overlap(nullptr, 1));
+  for (g_overlap = 0; g_overlap < 2; ++g_overlap) {
   for (const Rate& r : kRates) {
     if (r.fs == 10e6) continue;
     narrowband(r, 255);
@@ -289,6 +305,7 @@ int main(int argc, char** argv) {
     if ((pysdr::g_mfma_launches > before) != expect) { std::fprintf(stderr, "broadcast FM: matrix-core launches %d\n", pysdr::g_mfma_launches - before); return 1; }
   }
   spectrum();
+  }
   std::puts("HOST_SAN_OK");
   return 0;
 }

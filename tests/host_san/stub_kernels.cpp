@@ -11,6 +11,7 @@
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
 
 #include "common.h"
 #include "mixdec_geom.h"
@@ -310,12 +311,15 @@ int launch_apply(const Stage2Args& a, hipStream_t) {
 
 static int stub_epilogue(const EpilogueArgs& a) {
   SAN_CHECK(a.hy <= 4096, "hy %d", a.hy);
-  for (int r = 0; r < a.nrx; ++r)
-    for (float2* base : {a.ybase[r], a.ypllbase[r]})
-      if (base) {
-        read_all(base, (size_t)a.hy + a.n_out);
-        std::memmove(base, base + a.n_out, (size_t)a.hy * sizeof(float2));
+  for (int r = 0; r < a.nrx; ++r) {
+    SAN_CHECK(a.ydst[r] != nullptr, "rx %d: no destination for the next call's prefix", r);
+    const std::pair<float2*, float2*> jobs[2] = {{a.ybase[r], a.ydst[r]}, {a.ypllbase[r], a.ypllbase[r]}};
+    for (const auto& j : jobs)
+      if (j.first) {
+        read_all(j.first, (size_t)a.hy + a.n_out);
+        std::memmove(j.second, j.first + a.n_out, (size_t)a.hy * sizeof(float2));     // (the pair's other buffer when the calls overlap)
       }
+  }
   return PYSDR_OK;
 }
 
@@ -325,7 +329,8 @@ int launch_wfm(const WfmArgs& a, hipStream_t) {
     SAN_CHECK(a.y1[r] == a.y1base[r] + 2, "IF buffer layout");
     read_all(a.y1[r] - 1, (size_t)a.n1 + 1);
     write_all(a.w[r], (size_t)a.n1);
-    if (a.n1 > 0) a.y1base[r][1] = a.y1[r][a.n1 - 1];
+    SAN_CHECK(a.y1dst[r] != nullptr, "IF prefix destination");
+    if (a.n1 > 0) a.y1dst[r][1] = a.y1[r][a.n1 - 1];
   }
   read_all(a.state, (size_t)a.nrx);
   return PYSDR_OK;
