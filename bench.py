@@ -76,8 +76,9 @@ def parse(argv=None):
     ap.add_argument("--serial-psd", action="store_true", help="PSD strictly behind the whole demod (incl. stage 2)")
     ap.add_argument("--no-demod", action="store_true", help="diagnostic: PSD only")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="A/B: every call on ONE stream (pysdr_set_overlap(ctx, 0)); default: the audio-rate half of a call runs "
-                         "beside the front end of the next one")
+                    help="A/B: every call on ONE stream (pysdr_set_overlap(ctx, 0)); default 1: the audio-rate half of a call with a serial "
+                         "loop in it (AM-Synch, WFM2) runs beside the front end of the next one")
+    ap.add_argument("--overlap-all", action="store_true", help="A/B: pysdr_set_overlap(ctx, 2), every call in two overlapped halves")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: no HIP events inside the calls of the timed loop (what the live kernel timing costs)")
     ap.add_argument("--tile-bytes", type=int, default=0)
@@ -612,8 +613,8 @@ def main():
                           device=device, max_batch_chunks=B)
         ctx = sig_proc._context_for(P)
     nsamp = B * L
-    if args.no_overlap:
-        _lib.check(lib.pysdr_set_overlap(ctx.h, 0), "set_overlap")
+    if args.no_overlap or args.overlap_all:
+        _lib.check(lib.pysdr_set_overlap(ctx.h, 2 if args.overlap_all else 0), "set_overlap")
     if args.tile_bytes or args.threads:
         _lib.check(lib.pysdr_set_tile(ctx.h, args.tile_bytes, args.threads or 1024), "set_tile")
 
@@ -908,7 +909,7 @@ def main():
         "carrier_pll": cpll,
         "tuning": {"diag_build": int(tune[0]), "debug_flags": int(tune[1]), "mixdec_wgs_per_cu": int(tune[2]),
                    "mixdec_yflush_cap": int(tune[3]), "tile_bytes": int(tune[4]), "threads": int(tune[5]),
-                   "mixdec_mfma": int(tune[7]), "overlap_calls": int(lib.pysdr_get_overlap(ctx.h)),
+                   "mixdec_mfma": int(tune[7]), "overlap_calls": int(lib.pysdr_get_overlap(ctx.h)), "last_call_overlapped": int(lib.pysdr_last_call_overlapped(ctx.h)),
                    "psd_group": int(sp_tune[0]) if sp is not None else None,
                    "psd_rocfft": int(sp_tune[1]) if sp is not None else None,
                    "psd_streams": int(sp_tune[2]) if sp is not None else None,

@@ -145,13 +145,17 @@ int pysdr_process(pysdr_ctx* ctx, const float* iq_interleaved, size_t n, pysdr_o
  * (receiver.py:541-559) and the throughput benchmark. */
 int pysdr_process_batch(pysdr_ctx* ctx, const void* iq, int nchunks, size_t chunk_len, int on_device);
 /* Batch pipelining (a build feature, no reference call site; the analogue in the reference is MP_SCHEME 2/3 running the
- * demodulators beside the chunk acquisition, receiver.py:726-739): with enable != 0 the audio-rate half of a call (PLL
- * walks, detector + AF filter, AGC; for broadcast FM everything behind the IF decimator) is queued on a second HIP
- * stream and runs BESIDE the mix + decimate of the next call; results, state and every other entry point are unchanged
- * (pysdr_fetch / pysdr_sync wait for both halves).  Off by default.  A context that feeds an ingest ring runs
- * single-stream: pysdr_ingest_create* switches this off, and switching it on then fails with PYSDR_ERR_STATE. */
+ * demodulators beside the chunk acquisition, receiver.py:726-739): the audio-rate half of a call (PLL walks, detector +
+ * AF filter, AGC; for broadcast FM everything behind the IF decimator) is queued on a second HIP stream and runs BESIDE
+ * the mix + decimate of the next call; results, state and every other entry point are unchanged (pysdr_fetch /
+ * pysdr_sync wait for both halves).  enable = 0 off (default), 1 = in the calls where it pays -- those with a serial
+ * loop in them (AM-Synch carrier PLL, WFM2 pilot PLL: a long latency-bound second half that needs no LDS; elsewhere the AF
+ * FIR cannot start while the front end's persistent workgroups hold the LDS, and the halves take turns anyway), 2 = in
+ * every call (A/B).  A context that feeds an ingest ring runs single-stream: pysdr_ingest_create* switches this off, and
+ * switching it on then fails with PYSDR_ERR_STATE.  pysdr_last_call_overlapped: the form the last call really took. */
 int pysdr_set_overlap(pysdr_ctx* ctx, int enable);
 int pysdr_get_overlap(pysdr_ctx* ctx);
+int pysdr_last_call_overlapped(pysdr_ctx* ctx);
 /* Copy results of the last process call to the host.  am/iq may be NULL.
  * chunk_nout[nchunks] (may be NULL) receives the per-chunk output counts,
  * peaks[nchunks] the raw-chunk max |x|^2. */

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "pysdr_set_pll_segments": (_i, [_vp, _i]),
     "pysdr_set_overlap": (_i, [_vp, _i]),
     "pysdr_get_overlap": (_i, [_vp]),
+    "pysdr_last_call_overlapped": (_i, [_vp]),
     "pysdr_pll_join_margin": (_i, [_vp, _i, _pi, _pf]),
     "pysdr_set_agc": (_i, [_vp, _i, _i, _f]),
     "pysdr_set_squelch": (_i, [_vp, _i, _f]),

@@ -131,15 +131,21 @@ struct pysdr_ctx {
   // each half's history prefix is rolled into the OTHER buffer, and two events order the halves: ev_front (front end of
   // call k done -> its second half may start) and ev_s2[par] (second half of call k done -> the front end of call k + 2
   // may overwrite buffer par).  Off: stream2 is not used, par stays put, nothing is recorded -- the single-stream form.
+  // WHICH calls: those that run a serial loop (AM-Synch carrier PLL, WFM2 pilot PLL), whose second half is long, latency
+  // bound and needs no LDS.  Elsewhere the second half is the AF FIR, which cannot start while the persistent workgroups
+  // of a front end hold their CUs' LDS: the halves take turns whatever the streams say, and the events only cost
+  // (measured, profiles/r05_overlap_ab.txt: C1 +1.8 %, 6 RX +0.8 %, C2 -1 %, C3 -2 %; carrier PLL +7-15 %, pilot PLL +7 %).
+  // overlap = 2 (A/B, tests) overlaps every call.  A change of form between two calls drains both streams.
   hipStream_t stream2 = nullptr;
-  bool overlap = false;
-  int overlap_env = -1;          // PYSDR_OVERLAP=0/1 (under PYSDR_TUNING): pysdr_set_overlap is overruled (A/B runs, the test suite in both forms)
+  int overlap = 0;               // pysdr_set_overlap: 0 off, 1 where it pays (above), 2 every call
+  bool use2 = false;             // the form of the LAST call (what pysdr_fetch and the state getters must wait for)
+  int overlap_env = -1;          // PYSDR_OVERLAP=0/1/2 (under PYSDR_TUNING): pysdr_set_overlap is overruled (A/B runs, the test suite in every form)
   int par = 0;                   // buffer of the pair the NEXT call's front end writes
   int last_par = 0;              // ... and the one the last call wrote (pysdr_fetch reads its IQ)
   hipEvent_t ev_s2[2] = {nullptr, nullptr};
   bool s2_pending[2] = {false, false};
   int n_ingest = 0;              // ingest rings on this context (they run it single-stream)
-  hipStream_t s2() const { return overlap ? stream2 : stream; }
+  hipStream_t s2() const { return use2 ? stream2 : stream; }
   int hy = 0, mmax = 0;
   size_t cap_samples = 0;
   Decim main;                    // SRATE -> FS_OUT (UP/DOWN) for the narrow-band modes
@@ -522,6 +528,7 @@ struct RxSnap {
 };
 struct CallSnap {
   int nrx = 0, nwfm = 0;
+  bool use2 = false;             // this call runs in two overlapped halves
   RxSnap rx[PYSDR_MAX_RX];
 };
 
@@ -534,7 +541,32 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
   // rare, and everything below may then go on `stream` as in the single-stream form (drained again at the end, so that
   // the second half on stream2 sees it).
   bool drained = false;
-  if (c->overlap) {
+  snap->use2 = c->overlap >= 2;
+  for (int r = 0; r < c->nrx && c->overlap == 1; ++r)
+    snap->use2 |= (c->rx[r].mode == PYSDR_AM_SYNCH || c->rx[r].mode == PYSDR_WFM2);
+  if (snap->use2 != c->use2) {
+    // the form changes between two calls: both streams drained, the pair's current buffer holds the history either way
+    PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->stream2) PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream2));
+    c->s2_pending[0] = c->s2_pending[1] = false;
+    if (snap->use2 && !c->stream2) {
+      // The second stream exists from the first call that uses it, not from pysdr_set_overlap: the runtime maps streams
+      // onto a handful of hardware queues, and an IDLE fifth stream beside a spectrum's two made the PSD's streams share
+      // one (measured, same box: C3's PSD call 2.39 -> 2.95 ms, at a low priority 3.6 ms; scripts/diag/ab_r04.sh).
+      // LOW priority: when both halves are ready the dispatcher places the front end's workgroups first.  They are
+      // persistent (one per CU, most of its LDS) over a static share of the tiles: one that starts late because an AF-FIR
+      // workgroup sat on its CU's LDS ends late, and the launch with it (measured at equal priority: C1 front end
+      // 0.299 -> 0.342 ms, 6 RX 0.528 -> 0.702 -- the calls took LONGER overlapped than in a row)
+      int lo = 0, hi = 0;
+      PYSDR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      const char* pe = tuning_env("PYSDR_OVERLAP_PRIO");
+      const int prio = (pe && *pe) ? atoi(pe) : lo;
+      PYSDR_HIP_CHECK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio));
+      for (int i = 0; i < 2; ++i) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_s2[i], hipEventDisableTiming));
+    }
+    c->use2 = snap->use2;
+  }
+  if (snap->use2) {
     bool dirty = false;
     for (int r = 0; r < c->nrx; ++r) {
       const RxHost& x = c->rx[r];
@@ -572,7 +604,7 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       if (!x.d_y1) {
         PYSDR_HIP_CHECK(hipMalloc(&x.d_y1, ((size_t)c->m1max + 2) * sizeof(float2)));
         PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y1, 0, ((size_t)c->m1max + 2) * sizeof(float2), c->stream));
-        drained = drained || c->overlap;      // (the pair's second buffer follows below)
+        drained = drained || snap->use2;      // (the pair's second buffer follows below)
         PYSDR_HIP_CHECK(hipMalloc(&x.d_w, (size_t)c->m1max * sizeof(float2)));
         rc = decim_init(x.wfm_audio, c->up2, c->down2, (int)x.wfm_resamp.size(), 1, c->stream);
         if (rc) return rc;
@@ -617,12 +649,12 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       PYSDR_HIP_CHECK(hipMalloc(&x.d_ypll, n * sizeof(float2)));
       PYSDR_HIP_CHECK(hipMemsetAsync(x.d_ypll, 0, n * sizeof(float2), c->stream));
     }
-    if (c->overlap && x.d_y_alt == nullptr) {
+    if (snap->use2 && x.d_y_alt == nullptr) {
       const size_t ny = (size_t)c->hy + c->mmax;
       PYSDR_HIP_CHECK(hipMalloc(&x.d_y_alt, ny * sizeof(float2)));
       PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y_alt, 0, ny * sizeof(float2), c->stream));
     }
-    if (c->overlap && x.d_y1 != nullptr && x.d_y1_alt == nullptr) {
+    if (snap->use2 && x.d_y1 != nullptr && x.d_y1_alt == nullptr) {
       PYSDR_HIP_CHECK(hipMalloc(&x.d_y1_alt, ((size_t)c->m1max + 2) * sizeof(float2)));
       PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y1_alt, 0, ((size_t)c->m1max + 2) * sizeof(float2), c->stream));
     }
@@ -632,7 +664,7 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
     q.d_ypll = x.d_ypll; q.d_a = x.d_a; q.d_am = x.d_am; q.d_aftaps = x.d_aftaps;
     q.d_w = x.d_w;
     // this call's buffer of each pair and the next call's (the other one when the calls overlap)
-    const int p = c->par, pn = c->overlap ? (p ^ 1) : p;
+    const int p = c->par, pn = snap->use2 ? (p ^ 1) : p;
     q.d_y = p ? x.d_y_alt : x.d_y;
     q.d_y_next = pn ? x.d_y_alt : x.d_y;
     q.d_y1 = p ? x.d_y1_alt : x.d_y1;
@@ -719,7 +751,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
       if (nf >= 5 && tm >= 64) c->am_tmin = (tm + 63) & ~63;
     } }
   { const char* e = tuning_env("PYSDR_MIXDEC_MFMA"); if (e && *e) c->mfma_enable = atoi(e) ? 1 : 0; }
-  { const char* e = tuning_env("PYSDR_OVERLAP"); if (e && *e) c->overlap_env = atoi(e) ? 1 : 0; }
+  { const char* e = tuning_env("PYSDR_OVERLAP"); if (e && *e) c->overlap_env = std::max(0, std::min(2, atoi(e))); }
   { const char* e = tuning_env("PYSDR_RESAMP_PLAIN"); if (e && *e) c->resamp_plain = atoi(e); }
   { const char* e = tuning_env("PYSDR_MIXDEC_GRID"); if (e && atoi(e) > 0) c->grid_override = atoi(e); }
   { const char* e = tuning_env("PYSDR_WFM_PLL");
@@ -779,7 +811,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
     for (int i = 0; i < 4; ++i) CK(hipEventCreate(&c->ev[k][i]));
   CK(hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming));
 #undef CK
-  if (c->overlap_env == 1) { rc = pysdr_set_overlap(c, 1); if (rc) { pysdr_destroy(c); return rc; } }
+  if (c->overlap_env >= 1) { rc = pysdr_set_overlap(c, c->overlap_env); if (rc) { pysdr_destroy(c); return rc; } }
   *out = c;
   return PYSDR_OK;
 }
@@ -1035,7 +1067,7 @@ int pysdr_sync(pysdr_ctx* c) {
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
-  if (c->overlap) {
+  if (c->stream2) {
     PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream2));
     c->s2_pending[0] = c->s2_pending[1] = false;
   }
@@ -1043,7 +1075,7 @@ int pysdr_sync(pysdr_ctx* c) {
 }
 
 int pysdr_set_overlap(pysdr_ctx* c, int enable) {
-  if (!c) return PYSDR_ERR_ARG;
+  if (!c || enable < 0 || enable > 2) return PYSDR_ERR_ARG;
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   if (enable && c->n_ingest > 0) {
@@ -1055,15 +1087,12 @@ int pysdr_set_overlap(pysdr_ctx* c, int enable) {
   if (c->stream2) PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream2));
   c->s2_pending[0] = c->s2_pending[1] = false;
   if (c->overlap_env >= 0 && c->n_ingest == 0) enable = c->overlap_env;
-  if (enable && !c->stream2) {
-    PYSDR_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_s2[i], hipEventDisableTiming));
-  }
-  c->overlap = enable != 0;
+  c->overlap = enable;
   return PYSDR_OK;
 }
 
-int pysdr_get_overlap(pysdr_ctx* c) { return (c && c->overlap) ? 1 : 0; }
+int pysdr_get_overlap(pysdr_ctx* c) { return c ? c->overlap : 0; }
+int pysdr_last_call_overlapped(pysdr_ctx* c) { return (c && c->use2) ? 1 : 0; }
 
 int pysdr_wfm_params(double srate, double fs_out, int* d1, int* up2, int* down2) {
   if (srate <= 0 || fs_out <= 0) return PYSDR_ERR_ARG;
@@ -1127,9 +1156,10 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   const int nrx = snap.nrx;
   const bool wfm = snap.nwfm > 0;
   // the two halves of the call: `stream` takes the front end, S2 everything behind it (the same stream unless the calls overlap)
-  hipStream_t S2 = c->s2();
+  const bool use2 = snap.use2;
+  hipStream_t S2 = use2 ? c->stream2 : c->stream;
   const int par = c->par;
-  if (c->overlap && c->s2_pending[par]) {
+  if (use2 && c->s2_pending[par]) {
     // the second half of the call before last is the last reader of this call's buffers
     PYSDR_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_s2[par], 0));
     c->s2_pending[par] = false;
@@ -1166,7 +1196,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
     c->main.s_abs = c->wfm_front.s_abs;
     n1 = r1.n_out;
     // broadcast FM: the front end is the IF decimator; discriminator, pilot loop and audio resampler belong to the second half
-    if (c->overlap) {
+    if (use2) {
       PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream));
       PYSDR_HIP_CHECK(hipStreamWaitEvent(S2, c->ev_front, 0));
     }
@@ -1224,14 +1254,14 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   // kernel behind it starts that much later: scripts/diag/timeline.sh), so ONE event serves both the profile and the
   // ordering, and none is recorded when nobody asked for either.
   c->front_marker = nullptr;
-  if (wfm && c->overlap) {
+  if (wfm && use2) {
     // (recorded above, behind the IF decimator; the profile's second mark then sits where the pilot chain ends, on S2)
     c->front_marker = c->ev_front;
     if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[1], S2));
   } else {
     if (c->profile) { PYSDR_HIP_CHECK(hipEventRecord(ev[1], c->stream)); c->front_marker = ev[1]; }
-    else if (c->front_wanted || c->overlap) { PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream)); c->front_marker = c->ev_front; }
-    if (c->overlap) PYSDR_HIP_CHECK(hipStreamWaitEvent(S2, c->front_marker, 0));
+    else if (c->front_wanted || use2) { PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream)); c->front_marker = c->ev_front; }
+    if (use2) PYSDR_HIP_CHECK(hipStreamWaitEvent(S2, c->front_marker, 0));
   }
 
   Stage2Args s;
@@ -1297,7 +1327,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[3], S2));
   c->ncalls++;
   c->last_par = par;
-  if (c->overlap) {
+  if (use2) {
     PYSDR_HIP_CHECK(hipEventRecord(c->ev_s2[par], S2));
     c->s2_pending[par] = true;
     c->par = par ^ 1;

@@ -25,6 +25,16 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// The PLL walks are one dependent chain per wave and a few thousand instructions long: what they cost is latency, not
+// issue slots.  When the calls overlap (pysdr_set_overlap) they share their SIMDs with the waves of the NEXT call's mix +
+// decimate kernel, and at equal priority the arbiter gave them a slot every ~30 cycles: 105 -> 373 us for the carrier
+// loop, 2 x 185 -> 850 us for the pilot loop, LONGER than the front end they were meant to hide behind
+// (scripts/diag/overlap_trace.sh).  At a raised priority they keep their own pace and take ~2 % of the slots.
+#ifndef PLLX_PRIO
+#define PLLX_PRIO 3
+#endif
+__device__ __forceinline__ void pll_wave_priority() { __builtin_amdgcn_s_setprio(PLLX_PRIO); }
+
 // Inclusive scans over the 64 lanes of a wave (DPP: row_shr 1, 2, 4, 8 inside the rows of 16, then
 // row_bcast15 / row_bcast31 carry the row totals up).
 __device__ __forceinline__ float wave_scan_add(float v) {
@@ -202,6 +212,7 @@ __device__ __forceinline__ bool am_state_differs(uint32_t ph_a, float w_a, uint3
 __global__ __launch_bounds__(64) void am_pll_seg_kernel(const Stage2Args a) {
   const int r = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
   if (a.det[r] != kDetPll) return;
+  pll_wave_priority();
   const PllPlan& pl = a.pll;
   RxDevState* st = a.state + r;
   const int n = a.n_out;
@@ -1006,6 +1017,7 @@ __device__ __forceinline__ bool wfm_state_differs(uint32_t ph_a, float w_a, uint
 __global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
   const int r = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
   if (!a.stereo[r]) return;
+  pll_wave_priority();
   const PllPlan& pl = a.pll;
   const RxDevState* st = a.state + r;
   const int n = a.n1;

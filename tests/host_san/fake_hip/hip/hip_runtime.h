@@ -51,6 +51,8 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new 
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 1; *hi = -1; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned f, int) { return hipStreamCreateWithFlags(s, f); }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new fake_event{{}, false}; return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }

@@ -35,7 +35,7 @@ static std::vector<double> taps(int n, double scale = 1.0) {
   return h;
 }
 
-static int g_overlap = 0;      // second pass of main(): every context runs its calls in two overlapped halves (pysdr_set_overlap)
+static int g_overlap = 0;      // passes of main(): 0 single-stream, 2 every call in two overlapped halves, 1 the calls with a serial loop (pysdr_set_overlap)
 
 static pysdr_ctx* make_ctx(const Rate& r, int max_chunks, int ntaps_dec, int ntaps_af) {
   pysdr_cfg cfg;
@@ -45,8 +45,9 @@ static pysdr_ctx* make_ctx(const Rate& r, int max_chunks, int ntaps_dec, int nta
   pysdr_ctx* c = nullptr;
   OK(pysdr_create(&cfg, &c));
   if (g_overlap) {
-    OK(pysdr_set_overlap(c, 1));
-    if (!pysdr_get_overlap(c)) { std::fprintf(stderr, "overlap did not switch on\n"); std::exit(1); }
+    FAILS(pysdr_set_overlap(c, 3));
+    OK(pysdr_set_overlap(c, g_overlap));
+    if (!pysdr_get_overlap(c)) { std::fprintf(stderr, "overlap did not switch on\n"); std::exit(1); }     // (PYSDR_OVERLAP may overrule WHICH form)
   }
   return c;
 }
@@ -283,7 +284,8 @@ int main(int argc, char** argv) {
   OK(pysdr_device_count(&ndev));
   FAILS(pysdr_create(nullptr, nullptr));
   FAILS(pysdr_set_overlap(nullptr, 1));
-  for (g_overlap = 0; g_overlap < 2; ++g_overlap) {
+  for (int pass = 0; pass < 3; ++pass) {
+  g_overlap = pass == 0 ? 0 : (pass == 1 ? 2 : 1);
   for (const Rate& r : kRates) {
     if (r.fs == 10e6) continue;
     narrowband(r, 255);
