@@ -324,33 +324,78 @@ def cpu_baseline_per_rx(args, cfg, nchunks, with_psd, seed):
 
 
 def host_fed_rate(ctx, cfg, L, cps, nslots_run=24):
+    """The PCIe-inclusive figure (row N4; receiver.py:596 `readStream(rxStream, [self.xx], n)`, soapy.py:33-48): host
+    arrays in, audio + baseband IQ out, through the ingest ring.  Two legs and what bounds them:
+      value            the host COPIES every chunk into the pinned slot first (numpy, one thread) -- the stand-in for a
+                       driver whose readStream() fills a buffer of its own that the caller then copies;
+      slots_prefilled  the source has written into the slot it was GIVEN (readStream's contract: it fills the caller's
+                       buffer, and the ring hands out its pinned slots as that buffer): submit + collect only;
+      memcpy_GBps / h2d_GBps   the two one-thread / one-DMA rates behind them, measured here on this box (the first moved
+                       between driver boxes 4.0 -> 5.2 GS/s worth; the second is the link's ceiling for ANY ingest)."""
+    from pysdr_amd import _lib
     from pysdr_amd.ingest import IngestRing
+    lib = _lib.lib()
     x = synth_batch(cfg, 8 * L, 10)
     ring = IngestRing(ctx, 3, cps)
-    slot, pending = 0, None
+    nbytes = cps * L * 8
 
-    def one(slot):
+    def fill(slot):
         buf = ring.buffer(slot)
         for k in range(cps):
             buf[k * L:(k + 1) * L] = x[(k % 8) * L:(k % 8 + 1) * L]
-        ring.submit(slot, cps * L)
 
-    for w in range(3):
-        one(w)
-        ring.collect(w)
+    def run(copy_in):
+        slot, pending = 0, None
+        for w in range(3):
+            fill(w)
+            ring.submit(w, cps * L)
+            ring.collect(w)
+        t_fill = t_sub = t_col = 0.0
+        t0 = time.perf_counter()
+        for j in range(nslots_run):
+            ta = time.perf_counter()
+            if copy_in:
+                fill(slot)
+            tb = time.perf_counter()
+            ring.submit(slot, cps * L)
+            tc = time.perf_counter()
+            if pending is not None:
+                ring.collect(pending)
+            td = time.perf_counter()
+            t_fill += tb - ta; t_sub += tc - tb; t_col += td - tc
+            pending, slot = slot, (slot + 1) % 3
+        ring.collect(pending)
+        dt = (time.perf_counter() - t0) / (nslots_run * cps)
+        return dt, {"fill_ms": t_fill / nslots_run * 1e3, "submit_ms": t_sub / nslots_run * 1e3,
+                    "collect_wait_and_copy_out_ms": t_col / nslots_run * 1e3}
+
+    dt, per_slot = run(True)
+    dt2, per_slot2 = run(False)
+    # the two rates behind the legs: one thread copying into a pinned slot, one DMA of a pinned slot to the device
     t0 = time.perf_counter()
-    for j in range(nslots_run):
-        one(slot)
-        if pending is not None:
-            ring.collect(pending)
-        pending, slot = slot, (slot + 1) % 3
-    ring.collect(pending)
-    dt = (time.perf_counter() - t0) / (nslots_run * cps)
+    for _ in range(4):
+        fill(0)
+    memcpy_gbps = 4 * nbytes / (time.perf_counter() - t0) / 1e9
+    d_tmp = C.c_void_p()
+    h2d_gbps = None
+    dev = int(ctx.cfg.device)
+    if lib.pysdr_dev_alloc(dev, nbytes, C.byref(d_tmp)) == 0:
+        src = C.c_void_p(ring.buffer(0).ctypes.data)
+        lib.pysdr_dev_upload(dev, d_tmp, src, nbytes)
+        t0 = time.perf_counter()
+        for _ in range(8):
+            lib.pysdr_dev_upload(dev, d_tmp, src, nbytes)
+        h2d_gbps = 8 * nbytes / (time.perf_counter() - t0) / 1e9
+        lib.pysdr_dev_free(dev, d_tmp)
     ring.close()
-    return {"ms_per_chunk": dt * 1e3, "value": L / dt / 1e6, "unit": "MS/s", "chunks_per_slot": cps,
+    return {"ms_per_chunk": dt * 1e3, "value": L / dt / 1e6, "unit": "MS/s", "chunks_per_slot": cps, "per_slot_ms": per_slot,
+            "slots_prefilled": {"value": L / dt2 / 1e6, "unit": "MS/s", "ms_per_chunk": dt2 * 1e3, "per_slot_ms": per_slot2},
+            "memcpy_GBps": memcpy_gbps, "h2d_GBps": h2d_gbps, "slot_MB": nbytes / 1e6,
+            "pcie_ceiling_MSps": (h2d_gbps * 1e3 / 8.0) if h2d_gbps else None,
             "note": "host arrays in, audio + baseband out over PCIe: pinned ring slots, one H2D copy + one launch "
-                    "sequence + 2*NUM_RX+1 D2H copies per slot, results collected one slot late; includes the host "
-                    "memcpy into the slot that stands for readStream()"}
+                    "sequence + 2*NUM_RX+1 D2H copies per slot, results collected one slot late; `value` includes the host "
+                    "memcpy into the slot that stands for a readStream() with a buffer of its own, `slots_prefilled` is the "
+                    "ring alone (the source wrote into the slot it was given)"}
 
 
 
