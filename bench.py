@@ -952,7 +952,7 @@ def main():
                           if periods else None),
         "pilot_pll": pll,
         "carrier_pll": cpll,
-        "tuning": {"diag_build": int(tune[0]), "debug_flags": int(tune[1]), "mixdec_wgs_per_cu": int(tune[2]),
+        "tuning": {"diag_build": int(tune[0]), "build_flags_hash": int(lib.pysdr_build_flags_hash()), "debug_flags": int(tune[1]), "mixdec_wgs_per_cu": int(tune[2]),
                    "mixdec_yflush_cap": int(tune[3]), "tile_bytes": int(tune[4]), "threads": int(tune[5]),
                    "mixdec_mfma": int(tune[7]), "overlap_calls": int(lib.pysdr_get_overlap(ctx.h)), "last_call_overlapped": int(lib.pysdr_last_call_overlapped(ctx.h)),
                    "psd_group": int(sp_tune[0]) if sp is not None else None,

@@ -153,6 +153,9 @@ int pysdr_process_batch(pysdr_ctx* ctx, const void* iq, int nchunks, size_t chun
  * FIR cannot start while the front end's persistent workgroups hold the LDS, and the halves take turns anyway), 2 = in
  * every call (A/B).  A context that feeds an ingest ring runs single-stream: pysdr_ingest_create* switches this off, and
  * switching it on then fails with PYSDR_ERR_STATE.  pysdr_last_call_overlapped: the form the last call really took. */
+/* 0 for a library built from the sources as they are; otherwise a 31-bit hash of the extra compiler flags (A/B switches
+ * from PYSDR_*_FLAGS under PYSDR_TUNING=1, or the diagnostic build's) it was built with -- echoed by bench.py. */
+int pysdr_build_flags_hash(void);
 int pysdr_set_overlap(pysdr_ctx* ctx, int enable);
 int pysdr_get_overlap(pysdr_ctx* ctx);
 int pysdr_last_call_overlapped(pysdr_ctx* ctx);

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "pysdr_agc_get": (_i, [_vp, _i, C.POINTER(AgcState)]),
     "pysdr_pll_stats": (_i, [_vp, _i, _pi, _pi]),
     "pysdr_set_pll_segments": (_i, [_vp, _i]),
+    "pysdr_build_flags_hash": (_i, []),
     "pysdr_set_overlap": (_i, [_vp, _i]),
     "pysdr_get_overlap": (_i, [_vp]),
     "pysdr_last_call_overlapped": (_i, [_vp]),

@@ -1017,6 +1017,14 @@ extern "C" int pysdr_diag_stamps(pysdr_ctx* c, unsigned long long* host) {
 }
 #endif
 
+int pysdr_build_flags_hash(void) {
+#ifdef PYSDR_EXTRA_FLAGS_HASH
+  return (int)(PYSDR_EXTRA_FLAGS_HASH);
+#else
+  return 0;
+#endif
+}
+
 int pysdr_get_tuning(pysdr_ctx* c, int32_t out[8]) {
   if (!c || !out) return PYSDR_ERR_ARG;
 #ifdef PYSDR_DIAG

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for fl in "" "-DAGCX_NO_CHAIN" "-DAGCX_NO_ZERO" "-DAGCX_NO_LOAD" "-DAGCX_NO_CHAIN -DAGCX_NO_ZERO -DAGCX_NO_LOAD"; do
-  PYSDR_STAGE2_FLAGS="$fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { echo "build failed: $fl"; grep error /tmp/build.log | head -3; continue; }
+  PYSDR_STAGE2_FLAGS="-DPYSDR_ABLATE $fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { echo "build failed: $fl"; grep error /tmp/build.log | head -3; continue; }
   for w in ${WL:-c1 c2}; do
     O=gpurun_out/agc_kt/$w; rm -rf $O; mkdir -p $O
     rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 bench.py --workload $w --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 10 --warmup 3 > $O/bench.json 2> $O/err.txt

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for fl in "" "-DFIRX_NO_STAGE" "-DFIRX_NO_SUM" "-DFIRX_NO_ATOMICS" "-DFIRX_NO_STAGE -DFIRX_NO_ATOMICS" "-DFIRX_NO_SUM -DFIRX_NO_ATOMICS"; do
-  PYSDR_STAGE2_FLAGS="$fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { echo "build failed: $fl"; grep error /tmp/build.log | head -3; continue; }
+  PYSDR_STAGE2_FLAGS="-DPYSDR_ABLATE $fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { echo "build failed: $fl"; grep error /tmp/build.log | head -3; continue; }
   for w in c1 "c3 --no-psd" c4; do
     O=gpurun_out/fir_kt; rm -rf $O; mkdir -p $O
     rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 bench.py --workload $w --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 10 --warmup 3 > $O/bench.json 2> $O/err.txt

@@ -1,7 +1,7 @@
 # A/B builds of mixdec_mfma.hip (flag sets as arguments) timed with bench.py c1 and c4 (front-end ms; C4 also per kernel)
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for fl in "$@"; do
-  PYSDR_MFMA_FLAGS="$fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { echo "build failed: $fl"; grep -i "error" /tmp/build.log | head -3; continue; }
+  PYSDR_MFMA_FLAGS="-DPYSDR_ABLATE $fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { echo "build failed: $fl"; grep -i "error" /tmp/build.log | head -3; continue; }
   for w in ${WL:-c1 c4}; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline --no-host-fed --no-verify --no-other-configs --steps 15 --warmup 3 2>/dev/null | python -c "
 import sys, json

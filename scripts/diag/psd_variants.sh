@@ -4,7 +4,7 @@
 BASE="-fno-slp-vectorize -fno-signed-zeros"
 for fl in "$@"; do
   echo "=== flags: '$fl'"
-  PYSDR_PSD_FLAGS="$BASE $fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { tail -5 /tmp/build.log; continue; }
+  PYSDR_PSD_FLAGS="$BASE -DPYSDR_ABLATE $fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { tail -5 /tmp/build.log; continue; }
   for mode in "--no-demod" ""; do
     timeout 300 python bench.py $mode --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 20 --warmup 4 2>/dev/null | python -c "
 import sys, json

@@ -41,6 +41,25 @@ def test_two_ranks_on_one_device_verify_themselves_against_the_oracle():
     assert sorted(r["stream_seed"] for r in ranks) == [10, 11]
 
 
+def test_a_world_of_eight_on_one_device():
+    """BASELINE config #5 IS a world of eight (8 streams x 4 RX, seeds 10-17, one stream per rank: SURVEY 8(d) C5,
+    am.py:85-114); no 8-GPU node has been available to any round, so the one thing that can be proven is that the
+    line such a run prints holds together: eight rank processes (all on device 0: device = local_rank % ndev), each
+    with its own stream, each verified against the oracle on its own seed, a clock per rank, the exit code gating."""
+    p, out = _bench("--gpus", "8", "--chunks", "16", "--steps", "2", "--verify", "--no-cpu-baseline", "--no-host-fed",
+                    "--no-other-configs", timeout=900)
+    assert p.returncode == 0, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["rccl_ranks"] == 0
+    assert out["verified_ranks"] == 8 and out["verify_worst_rel"] <= 1e-5
+    ranks = out["verify"]["ranks"]
+    assert sorted(r["rank"] for r in ranks) == list(range(8))
+    assert sorted(r["stream_seed"] for r in ranks) == list(range(10, 18))
+    assert len(out["per_rank_ms"]) == 8 and all(t > 0 for t in out["per_rank_ms"])
+    # whole-job rate = 8 streams' samples over the slowest rank's clock
+    assert out["config"]["parallelism"].startswith("stream-sharded x8")
+    assert abs(out["value"] - 8 * out["config"]["samples_per_step"] / (out["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * out["value"]
+
+
 def test_a_wrong_answer_fails_the_line():
     """--verify is a gate, not a decoration: with the checker's tolerance forced to zero the same run exits non-zero."""
     code = ("import sys; sys.argv = ['bench.py', '--chunks', '16', '--steps', '1', '--warmup', '1', '--verify', "

@@ -58,11 +58,16 @@ def test_partitions():
     assert multi.partition_streams(8, 3) == [[0, 1, 2], [3, 4, 5], [6, 7]]
     assert multi.partition_rx(4, 2) == [[0, 2], [1, 3]]
     assert multi.partition_rx(4, 8)[5] == []
+    assert multi.partition_streams(4, 8) == [[0], [1], [2], [3], [], [], [], []]
     assert multi.max_over_ranks(2.5) == 2.5
     assert multi.gather_audio({(0, 0): np.ones(3)})[(0, 0)].sum() == 3
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_world_matches_single_process(tmp_path, world):
+    """world = 2: two ranks, two streams each.  world = 8 (BASELINE config #5's world, am.py:85-114): 4 streams over 8
+    ranks -- ranks 4-7 hold NO stream (partition_streams' empty shares) and still take part in every collective; the
+    split-RX variant deals 4 sub-receivers over 8 ranks the same way."""
     import pickle
     from oracle import sdr_oracle as so
     from tests.test_golden import small_cfg
@@ -71,14 +76,14 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     wfile = tmp_path / "worker.py"
     wfile.write_text(WORKER)
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    PYSDR_ROOT=ROOT, PYSDR_OUT=out, OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(wfile)], env=env, cwd=ROOT))
     for p in procs:
         assert p.wait(timeout=300) == 0
     res = pickle.load(open(out, "rb"))
-    assert res["slow"] == 2.0
+    assert res["slow"] == float(world)
     cfg = small_cfg()
     L = so.chunk_sizes(cfg["fs"], cfg["fs_out"])[3]
     for s in range(4):
