@@ -1,4 +1,5 @@
 # where agc_scan_kernel's time goes: builds of stage2.hip with parts switched off (results WRONG), kernel averages from rocprofv3
+export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for fl in "" "-DAGCX_NO_CHAIN" "-DAGCX_NO_ZERO" "-DAGCX_NO_LOAD" "-DAGCX_NO_CHAIN -DAGCX_NO_ZERO -DAGCX_NO_LOAD"; do

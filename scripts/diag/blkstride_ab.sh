@@ -1,4 +1,5 @@
 # distance between the per-block accumulators (words): 64 (shipped) against 32 / 16, AF FIR + gains kernels on C1 / C3 (no PSD)
+export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for st in ${STRIDES:-64 32 16 64}; do

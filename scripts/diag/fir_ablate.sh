@@ -1,4 +1,5 @@
 # where demod_fir_kernel's time goes (results of the FIRX_NO_* builds are WRONG): kernel averages on C1 / C3 (no PSD) / C4
+export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for fl in "" "-DFIRX_NO_STAGE" "-DFIRX_NO_SUM" "-DFIRX_NO_ATOMICS" "-DFIRX_NO_STAGE -DFIRX_NO_ATOMICS" "-DFIRX_NO_SUM -DFIRX_NO_ATOMICS"; do

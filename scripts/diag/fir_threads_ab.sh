@@ -1,4 +1,5 @@
 # AF FIR: threads per workgroup (x 8 outputs = tile) 128 / 256 / 512, kernel averages on C1 / C2 / C3 (no PSD) / C4
+export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for t in 256 128 512 256; do

@@ -1,4 +1,5 @@
 # LDS-DMA loads of the two mix + decimate kernels: nontemporal against plain, all four configurations (+ demod-only C3), two rounds
+export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for rep in 1 2; do
 for fl in "plain" "nt"; do

@@ -1,4 +1,5 @@
 # A/B builds of mixdec_mfma.hip (flag sets as arguments) timed with bench.py c1 and c4 (front-end ms; C4 also per kernel)
+export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for fl in "$@"; do
   PYSDR_MFMA_FLAGS="-DPYSDR_ABLATE $fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { echo "build failed: $fl"; grep -i "error" /tmp/build.log | head -3; continue; }

@@ -1,4 +1,5 @@
 # A/B of compile-time variants of mixdec_mfma.hip ON the GPU box: for every flag set given as an argument ("" = shipped)
+export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 # rebuild the diagnostic library, print the stamp summary of workgroup 3, and the C1 / C4 kernel times from bench.py
 # (the diagnostic library serves both: without PYSDR_DEBUG_FLAGS it skips nothing).
 #   bash scripts/diag/mfma_variants.sh "" "-DMM_NO_PK" "-DMM_PROD_PRIO=3"

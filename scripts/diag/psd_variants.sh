@@ -1,4 +1,5 @@
 # A/B of compile-time variants of psdfft.hip ON the GPU box: for every flag set given as an argument ("" = shipped) rebuild
+export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 # the library and time the PSD alone (bench.py --no-demod) and inside C3.
 #   bash scripts/diag/psd_variants.sh "" "-DPSDX_NO_SCALE" "-DPSDX_NO_LO"
 BASE="-fno-slp-vectorize -fno-signed-zeros"

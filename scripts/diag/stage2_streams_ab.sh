@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for fl in "" "-DS2X_PLAIN_STREAMS" "" "-DS2X_PLAIN_STREAMS"; do
   PYSDR_STAGE2_FLAGS="$fl" python -m pysdr_amd.build --force > /tmp/build.log 2>&1 || { echo "build failed: $fl"; continue; }

@@ -1,4 +1,5 @@
 # output stores of the two mix + decimate kernels: nontemporal (shipped) against plain, all four configurations, twice
+export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for rep in 1 2; do
 for fl in "nt" "plain"; do
