@@ -103,6 +103,7 @@ struct RxHost {
   float2* d_y = nullptr;        // [hy + mmax]
   float2* d_y_alt = nullptr;    // the second buffer of the pair, allocated when the context overlaps its calls (pysdr_set_overlap)
   float2* d_ypll = nullptr;     // [hy + mmax], allocated on first AM-Synch use
+  float2* d_ypll_alt = nullptr; // its pair (pysdr_set_overlap)
   float2* d_a = nullptr;        // [mmax]
   float* d_am = nullptr;        // [2*mmax]
   float2* d_aftaps = nullptr;   // [ntaps_af rounded up to 4], zero padded
@@ -115,6 +116,40 @@ struct RxHost {
   float2* d_y1 = nullptr;          // [2 + m1max] IF-rate IQ (1-sample history in slot 1)
   float2* d_y1_alt = nullptr;      // its pair (pysdr_set_overlap)
   float2* d_w = nullptr;           // [m1max] composite * (1 + 2j sin 2theta)
+  float2* d_w_alt = nullptr;       // its pair (pysdr_set_overlap)
+};
+
+// What one pysdr_process_batch call uses of the receivers' host-side state.  Taken under
+// c->mu by apply_pending, so that a setter running on another thread (gui.py:1713,1938)
+// between two lines of the launch sequence can only affect the NEXT call: the taps on the
+// device, the NCO word, the detector kind and the buffers it needs always belong together.
+struct RxSnap {
+  int mode = PYSDR_AM;
+  uint32_t fword = 0, phase = 0, bfo_fword = 0;
+  float sq_thresh = 0.f;
+  int taps_real = 0;
+  float2 *d_y = nullptr, *d_ypll = nullptr, *d_a = nullptr, *d_y1 = nullptr, *d_w = nullptr;   // d_y / d_ypll / d_y1 / d_w: THIS call's buffer of each pair
+  float2 *d_y_next = nullptr, *d_ypll_next = nullptr, *d_y1_next = nullptr;   // the next call's (the same one unless the calls overlap): gets the history prefix
+  float* d_am = nullptr;
+  float2* d_aftaps = nullptr;
+};
+struct CallSnap {
+  int nrx = 0, nwfm = 0;
+  bool use2 = false;             // this call's tail is deferred (pysdr_set_overlap)
+  RxSnap rx[PYSDR_MAX_RX];
+};
+
+// The tail of a call (T in pysdr_ctx): everything it needs that the front part of the call worked out.
+struct TailJob {
+  bool valid = false;
+  CallSnap snap;
+  bool wfm = false;
+  bool wait_pll = false;         // the call's loop walks run on stream2: the tail waits for ev_pll[par]
+  int par = 0, nchunks = 0, n1 = 0;
+  size_t chunk_len = 0, n = 0;
+  unsigned long long s0 = 0;
+  Stage2Args s;                  // narrow-band: complete.  Broadcast FM: the output counts come from the audio resampler, which is part of the tail
+  hipEvent_t ev_end = nullptr;   // the profile's last mark of that call (nullptr: not profiled)
 };
 
 }  // namespace
@@ -125,27 +160,36 @@ struct pysdr_ctx {
   RxHost rx[PYSDR_MAX_RX];
   std::mutex mu;
   hipStream_t stream = nullptr;
-  // pysdr_set_overlap: the audio-rate half of a call (PLL walks, detector + AF FIR, AGC, and for broadcast FM everything
-  // behind the IF decimator) runs on stream2 BESIDE the front end of the next call on `stream`.  What the front end writes
-  // and the second half reads -- the FS_OUT-rate IQ y, the IF-rate IQ y1 -- then alternates between two buffers (`par`),
-  // each half's history prefix is rolled into the OTHER buffer, and two events order the halves: ev_front (front end of
-  // call k done -> its second half may start) and ev_s2[par] (second half of call k done -> the front end of call k + 2
-  // may overwrite buffer par).  Off: stream2 is not used, par stays put, nothing is recorded -- the single-stream form.
-  // WHICH calls: those that run a serial loop (AM-Synch carrier PLL, WFM2 pilot PLL), whose second half is long, latency
-  // bound and needs no LDS.  Elsewhere the second half is the AF FIR, which cannot start while the persistent workgroups
-  // of a front end hold their CUs' LDS: the halves take turns whatever the streams say, and the events only cost
-  // (measured, profiles/r05_overlap_ab.txt: C1 +1.8 %, 6 RX +0.8 %, C2 -1 %, C3 -2 %; carrier PLL +7-15 %, pilot PLL +7 %).
-  // overlap = 2 (A/B, tests) overlaps every call.  A change of form between two calls drains both streams.
+  // pysdr_set_overlap: a call is three groups of launches --
+  //   F  the front end (mix + decimate; + the short parallel kernels in front of a serial loop: arg y for the carrier
+  //      loop, the discriminator for broadcast FM),
+  //   P  the segment walks of a serial loop (AM-Synch carrier PLL, WFM2 pilot PLL): a few thousand single-wave chains,
+  //      latency bound, no LDS, a third to a half of such a call's time,
+  //   T  the tail (audio resampler of broadcast FM, detector + AF FIR, AGC, output): LDS-tiled and throughput bound --
+  // and in the single-stream form they run F P T, F P T, ...  Overlapped, P(k) goes on `stream2` and `stream` runs
+  //   F(k)  [wait P(k-1)]  T(k-1)  F(k+1)  [wait P(k)]  T(k) ...
+  // i.e. the TAIL OF A CALL IS DEFERRED until the front end of the next one has been queued (or until anything asks
+  // for its results: flush_tail), so that the walks of call k run beside T(k-1) and F(k+1).  What F writes and T reads a
+  // call later -- the FS_OUT-rate IQ y, the IF-rate IQ y1, the loops' buffers -- alternates between two buffers (`par`);
+  // each history prefix is rolled into the OTHER buffer.  Two events order it: ev_front (F(k) done -> P(k) may start) and
+  // ev_pll[par] (P(k) done -> T(k) may start); everything else is stream order.
+  // Round 5's first form put P AND T on stream2; measured (profiles/r05_overlap_*.txt): the AF FIR cannot start while the
+  // persistent workgroups of a front end hold their CUs' LDS, so T took turns with F whatever the streams said, and a P
+  // that shares its SIMDs with matrix-core waves runs 2.2-2.5x longer (a vector instruction waits for the MFMA in
+  // front of it) -- P + T behind one another on stream2 was then LONGER than F, and the front end idled.
+  // WHICH calls: those with a serial loop in them (overlap = 1); overlap = 2 defers every call's tail (tests: nothing
+  // runs on stream2 then, the buffers and the deferral are exercised all the same).  A change of form between two calls
+  // flushes and drains.
   hipStream_t stream2 = nullptr;
-  int overlap = 0;               // pysdr_set_overlap: 0 off, 1 where it pays (above), 2 every call
-  bool use2 = false;             // the form of the LAST call (what pysdr_fetch and the state getters must wait for)
+  int overlap = 0;               // pysdr_set_overlap: 0 off, 1 the calls with a serial loop, 2 every call
   int overlap_env = -1;          // PYSDR_OVERLAP=0/1/2 (under PYSDR_TUNING): pysdr_set_overlap is overruled (A/B runs, the test suite in every form)
-  int par = 0;                   // buffer of the pair the NEXT call's front end writes
-  int last_par = 0;              // ... and the one the last call wrote (pysdr_fetch reads its IQ)
-  hipEvent_t ev_s2[2] = {nullptr, nullptr};
-  bool s2_pending[2] = {false, false};
+  bool use2 = false;             // the form of the LAST call
+  int par = 0;                   // buffer of each pair the NEXT call's front end writes
+  int last_par = 0;              // ... and the one the last finished call wrote (pysdr_fetch reads its IQ)
+  hipEvent_t ev_pll[2] = {nullptr, nullptr};
   int n_ingest = 0;              // ingest rings on this context (they run it single-stream)
-  hipStream_t s2() const { return use2 ? stream2 : stream; }
+  int tail_first = -1;           // PYSDR_OVERLAP_ORDER=0/1 (A/B): the deferred tail behind / in front of the next call's walks; -1: by mode
+  TailJob tail;                  // the deferred tail of the last call (tail.valid)
   int hy = 0, mmax = 0;
   size_t cap_samples = 0;
   Decim main;                    // SRATE -> FS_OUT (UP/DOWN) for the narrow-band modes
@@ -184,9 +228,10 @@ struct pysdr_ctx {
   // carrier-PLL segmentation (PYSDR_AM_PLL = "taus,taus_exact,coarse_sweeps,kmax,tmin" overrides for A/B runs): warm-up of 16
   // time constants from the block mean of the signal's own phase (joins 7-40 words of 2^32 against a tolerance of 1024 in the
   // NumPy model of the sweeps, scripts/experiments/am_pll_sweeps.py; 14 leave up to 730 on a noisy carrier 40 Hz off tune),
-  // the first 11 of them at 5 sweeps per block, the last 5 to the fixed point (8-10 sweeps)
+  // the first 11 of them at 4 sweeps per block (5: joins 5 -> 6 words on the bench's carrier, 58 -> 316 in the model's noisy
+  // one, segment kernel 105 -> 97 us; 3: the noisy model leaves 2700), the last 5 to the fixed point (8-10 sweeps)
   double am_taus = 16.0, am_taus_exact = 5.0;
-  int am_coarse_sweeps = 5, am_kmax = 2048, am_tmin = 512;
+  int am_coarse_sweeps = 4, am_kmax = 2048, am_tmin = 512;
   int pll_kmax = 0;                       // pysdr_set_pll_segments: 0 = default, 1 = serial
   // pilot-PLL segmentation (PYSDR_WFM_PLL = "taus,taus_fast,taus_exact,coarse_sweeps,kmax,tmin,exact_cap" overrides for A/B runs)
   // measured on MI355X (bench.py --workload c4, scripts/diag/pll_sweep.sh; front end ms per 2048 chunks):
@@ -512,79 +557,48 @@ int wfm_setup(pysdr_ctx* c) {
   return decim_init(c->wfm_front, 1, c->d1, c->cfg.ntaps_dec, PYSDR_MAX_RX, c->stream);
 }
 
-// What one pysdr_process_batch call uses of the receivers' host-side state.  Taken under
-// c->mu by apply_pending, so that a setter running on another thread (gui.py:1713,1938)
-// between two lines of the launch sequence can only affect the NEXT call: the taps on the
-// device, the NCO word, the detector kind and the buffers it needs always belong together.
-struct RxSnap {
-  int mode = PYSDR_AM;
-  uint32_t fword = 0, phase = 0, bfo_fword = 0;
-  float sq_thresh = 0.f;
-  int taps_real = 0;
-  float2 *d_y = nullptr, *d_ypll = nullptr, *d_a = nullptr, *d_y1 = nullptr, *d_w = nullptr;   // d_y / d_y1: THIS call's buffer of the pair
-  float2 *d_y_next = nullptr, *d_y1_next = nullptr;      // the next call's (the same one unless the calls overlap): gets the history prefix
-  float* d_am = nullptr;
-  float2* d_aftaps = nullptr;
-};
-struct CallSnap {
-  int nrx = 0, nwfm = 0;
-  bool use2 = false;             // this call runs in two overlapped halves
-  RxSnap rx[PYSDR_MAX_RX];
-};
+int flush_tail(pysdr_ctx* c);
 
 int apply_pending(pysdr_ctx* c, CallSnap* snap) {
   std::lock_guard<std::mutex> lk(c->mu);
   snap->nrx = c->nrx;
   snap->nwfm = 0;
   for (int r = 0; r < c->nrx; ++r) snap->nwfm += is_wfm(c->rx[r].mode) ? 1 : 0;
-  // Overlapping calls: whatever a setter left to do (taps, resets, buffers) is done with BOTH streams drained -- it is
-  // rare, and everything below may then go on `stream` as in the single-stream form (drained again at the end, so that
-  // the second half on stream2 sees it).
+  // Overlapping calls: a deferred tail belongs to the PREVIOUS call and must see the taps / AGC settings / buffers of that
+  // call, so whatever a setter left to do (taps, resets, buffers) and any change of form first flushes it and drains both
+  // streams -- it is rare, and everything below may then go on `stream` as in the single-stream form (drained again at
+  // the end, so that the loop walks on stream2 see it).
   bool drained = false;
   snap->use2 = c->overlap >= 2;
   for (int r = 0; r < c->nrx && c->overlap == 1; ++r)
     snap->use2 |= (c->rx[r].mode == PYSDR_AM_SYNCH || c->rx[r].mode == PYSDR_WFM2);
-  if (snap->use2 != c->use2) {
-    // the form changes between two calls: both streams drained, the pair's current buffer holds the history either way
+  bool dirty = snap->use2 != c->use2;
+  for (int r = 0; r < c->nrx && (snap->use2 || c->tail.valid); ++r) {
+    const RxHost& x = c->rx[r];
+    dirty |= x.taps_dirty || x.af_dirty || x.agc_dirty || x.reset_pending != 0 || (is_wfm(x.mode) && x.wfm_dirty) ||
+             (x.mode == PYSDR_AM_SYNCH && (x.d_ypll == nullptr || (snap->use2 && x.d_ypll_alt == nullptr))) ||
+             (snap->use2 && (x.d_y_alt == nullptr || (x.d_y1 != nullptr && x.d_y1_alt == nullptr)));
+  }
+  if (dirty) {
+    int rc = flush_tail(c);
+    if (rc) return rc;
     PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->stream2) PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream2));
-    c->s2_pending[0] = c->s2_pending[1] = false;
     if (snap->use2 && !c->stream2) {
       // The second stream exists from the first call that uses it, not from pysdr_set_overlap: the runtime maps streams
       // onto a handful of hardware queues, and an IDLE fifth stream beside a spectrum's two made the PSD's streams share
       // one (measured, same box: C3's PSD call 2.39 -> 2.95 ms, at a low priority 3.6 ms; scripts/diag/ab_r04.sh).
-      // LOW priority: when both halves are ready the dispatcher places the front end's workgroups first.  They are
-      // persistent (one per CU, most of its LDS) over a static share of the tiles: one that starts late because an AF-FIR
-      // workgroup sat on its CU's LDS ends late, and the launch with it (measured at equal priority: C1 front end
-      // 0.299 -> 0.342 ms, 6 RX 0.528 -> 0.702 -- the calls took LONGER overlapped than in a row)
+      // LOW priority: where both have work the dispatcher places the front end's workgroups first (they are persistent
+      // over a static share of the tiles: one that starts late ends late, and the launch with it).
       int lo = 0, hi = 0;
       PYSDR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
       const char* pe = tuning_env("PYSDR_OVERLAP_PRIO");
       const int prio = (pe && *pe) ? atoi(pe) : lo;
       PYSDR_HIP_CHECK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio));
-      for (int i = 0; i < 2; ++i) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_s2[i], hipEventDisableTiming));
+      for (int i = 0; i < 2; ++i) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_pll[i], hipEventDisableTiming));
     }
     c->use2 = snap->use2;
-  }
-  if (snap->use2) {
-    bool dirty = false;
-    for (int r = 0; r < c->nrx; ++r) {
-      const RxHost& x = c->rx[r];
-      dirty |= x.taps_dirty || x.af_dirty || x.agc_dirty || x.reset_pending != 0 || (is_wfm(x.mode) && x.wfm_dirty) ||
-               (x.mode == PYSDR_AM_SYNCH && x.d_ypll == nullptr) || x.d_y_alt == nullptr || (x.d_y1 != nullptr && x.d_y1_alt == nullptr);
-    }
-    if (dirty) {
-      PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream2));
-      PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
-      c->s2_pending[0] = c->s2_pending[1] = false;
-      drained = true;
-    }
-  }
-  if (snap->nwfm != 0 && snap->nwfm != c->nrx) {
-    // the reference's mode is global (P.MODE) and the rate-reduction order differs for
-    // broadcast FM (receiver.py:718-719): one context runs one pipeline
-    set_last_error("pysdr_process_batch: WFM/WFM2 cannot be mixed with narrow-band modes in one context");
-    return PYSDR_ERR_STATE;
+    drained = snap->use2;
   }
   for (int r = 0; r < c->nrx; ++r) {
     RxHost& x = c->rx[r];
@@ -649,6 +663,11 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       PYSDR_HIP_CHECK(hipMalloc(&x.d_ypll, n * sizeof(float2)));
       PYSDR_HIP_CHECK(hipMemsetAsync(x.d_ypll, 0, n * sizeof(float2), c->stream));
     }
+    if (snap->use2 && x.d_ypll != nullptr && x.d_ypll_alt == nullptr) {
+      const size_t ny = (size_t)c->hy + c->mmax;
+      PYSDR_HIP_CHECK(hipMalloc(&x.d_ypll_alt, ny * sizeof(float2)));
+      PYSDR_HIP_CHECK(hipMemsetAsync(x.d_ypll_alt, 0, ny * sizeof(float2), c->stream));
+    }
     if (snap->use2 && x.d_y_alt == nullptr) {
       const size_t ny = (size_t)c->hy + c->mmax;
       PYSDR_HIP_CHECK(hipMalloc(&x.d_y_alt, ny * sizeof(float2)));
@@ -657,21 +676,115 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
     if (snap->use2 && x.d_y1 != nullptr && x.d_y1_alt == nullptr) {
       PYSDR_HIP_CHECK(hipMalloc(&x.d_y1_alt, ((size_t)c->m1max + 2) * sizeof(float2)));
       PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y1_alt, 0, ((size_t)c->m1max + 2) * sizeof(float2), c->stream));
+      PYSDR_HIP_CHECK(hipMalloc(&x.d_w_alt, (size_t)c->m1max * sizeof(float2)));
     }
     RxSnap& q = snap->rx[r];
     q.mode = x.mode; q.fword = x.fword; q.phase = x.phase; q.bfo_fword = x.bfo_fword;
     q.sq_thresh = x.sq_thresh; q.taps_real = x.taps_real;
-    q.d_ypll = x.d_ypll; q.d_a = x.d_a; q.d_am = x.d_am; q.d_aftaps = x.d_aftaps;
-    q.d_w = x.d_w;
+    q.d_a = x.d_a; q.d_am = x.d_am; q.d_aftaps = x.d_aftaps;
     // this call's buffer of each pair and the next call's (the other one when the calls overlap)
     const int p = c->par, pn = snap->use2 ? (p ^ 1) : p;
     q.d_y = p ? x.d_y_alt : x.d_y;
     q.d_y_next = pn ? x.d_y_alt : x.d_y;
+    q.d_ypll = p ? x.d_ypll_alt : x.d_ypll;
+    q.d_ypll_next = pn ? x.d_ypll_alt : x.d_ypll;
     q.d_y1 = p ? x.d_y1_alt : x.d_y1;
     q.d_y1_next = pn ? x.d_y1_alt : x.d_y1;
+    q.d_w = p ? x.d_w_alt : x.d_w;
   }
   if (drained) PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
   return PYSDR_OK;
+}
+
+// Stage2Args of a call from its snapshot (everything but the carrier-loop plan)
+void fill_stage2(pysdr_ctx* c, const CallSnap& snap, bool wfm, int nchunks, size_t chunk_len, const DecimResult& res,
+                 Stage2Args* out) {
+  Stage2Args& s = *out;
+  memset(&s, 0, sizeof(s));
+  const int up = c->cfg.up, down = c->cfg.down, nrx = snap.nrx;
+  s.nrx = nrx; s.n_out = res.n_out; s.ntaps = c->cfg.ntaps_af; s.hy = c->hy;
+  s.t0 = res.t0; s.up = up; s.down = down; s.chunk_len = (uint32_t)chunk_len; s.nchunks = nchunks;
+  s.m0_lo = (uint32_t)(res.m0 & 0xFFFFFFFFull);
+  const double fs_out = std::floor(c->cfg.srate * up / down);
+  s.fm_scale = (float)(fs_out / (2.0 * M_PI * kNfmFullScaleDev));
+  {
+    const double wn = 2.0 * M_PI * kPllBwHz / fs_out;
+    s.pll_kp = (float)(2.0 * kPllZeta * wn);
+    s.pll_ki = (float)(wn * wn);
+  }
+  for (int r = 0; r < nrx; ++r) {
+    const RxSnap& x = snap.rx[r];
+    s.y[r] = x.d_y + c->hy;
+    s.ypll[r] = x.d_ypll ? x.d_ypll + c->hy : nullptr;
+    s.aftaps[r] = x.d_aftaps;
+    s.taps_real[r] = x.taps_real;
+    s.a[r] = x.d_a;
+    s.am[r] = x.d_am;
+    s.det[r] = mode_detector(x.mode);
+    s.out_complex[r] = (x.mode == PYSDR_IQ || wfm) ? 1 : 0;
+    s.fir_complex[r] = s.out_complex[r];
+    s.single_block[r] = wfm ? 1 : 0;
+    s.single_spread = 1;
+    while (s.single_spread * 2 <= std::min(nchunks, 32)) s.single_spread *= 2;
+    s.matrix[r] = (x.mode == PYSDR_WFM2) ? 1 : 0;
+    s.bfo_fword[r] = x.bfo_fword;
+    s.sq_thresh[r] = x.sq_thresh;
+  }
+  s.blkpeak = c->d_blkpeak; s.gain = c->d_gain; s.state = c->d_state;
+  s.blknoise = c->d_blknoise; s.blkcnt = c->d_blkcnt;
+}
+
+// T: the tail of a call on `stream` -- for broadcast FM the audio resamplers first, then detector + AF FIR, the block
+// gains (+ the history rolls into the next call's buffers) and the output stage.  Called at the end of the call itself
+// (single-stream form) or from the NEXT call / a flush (deferred).
+int run_tail(pysdr_ctx* c, TailJob& j) {
+  j.valid = false;
+  const CallSnap& snap = j.snap;
+  const int nrx = snap.nrx;
+  if (j.wait_pll) PYSDR_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_pll[j.par], 0));
+  Stage2Args& s = j.s;
+  int rc;
+  if (j.wfm) {
+    DecimResult res;
+    const uint32_t zero = 0u;
+    for (int r = 0; r < nrx; ++r) {
+      float2* y1 = snap.rx[r].d_y + c->hy;
+      rc = decim_run(c, c->rx[r].wfm_audio, snap.rx[r].d_w, (size_t)j.n1, 1, &y1, &zero, &zero, nullptr, 0,
+                     c->mmax, &res, c->stream);
+      if (rc) return rc;
+    }
+    fill_stage2(c, snap, true, j.nchunks, j.chunk_len, res, &s);
+  }
+  const int n_out = s.n_out;
+  rc = launch_demod_fir(s, c->stream); if (rc) return rc;
+  // the gains, and beside them (same launch) the history roll of the FS_OUT-rate buffers: the AF FIR was their last reader
+  EpilogueArgs e;
+  memset(&e, 0, sizeof(e));
+  e.nrx = nrx; e.n_out = n_out; e.hy = c->hy;
+  for (int r = 0; r < nrx; ++r) {
+    e.ybase[r] = snap.rx[r].d_y;
+    e.ydst[r] = snap.rx[r].d_y_next;
+    e.ypllbase[r] = (s.det[r] == kDetPll) ? snap.rx[r].d_ypll : nullptr;
+    e.yplldst[r] = (s.det[r] == kDetPll) ? snap.rx[r].d_ypll_next : nullptr;
+  }
+  rc = launch_agc_scan(s, e, c->stream); if (rc) return rc;
+  // WFM (mono) emits the real part of the complex pipeline
+  for (int r = 0; r < nrx; ++r) if (snap.rx[r].mode == PYSDR_WFM) s.out_complex[r] = 0;
+  rc = launch_apply(s, c->stream); if (rc) return rc;
+  if (j.ev_end) PYSDR_HIP_CHECK(hipEventRecord(j.ev_end, c->stream));
+  for (int r = 0; r < nrx; ++r) c->last_complex[r] = (snap.rx[r].mode == PYSDR_IQ || snap.rx[r].mode == PYSDR_WFM2) ? 1 : 0;
+  c->last_par = j.par;
+  c->last_nrx = nrx;
+  c->last_nout = n_out; c->last_nchunks = j.nchunks;
+  c->last_chunk_len = j.chunk_len; c->last_s0 = j.s0; c->last_wfm = j.wfm ? 1 : 0;
+  return PYSDR_OK;
+}
+
+// Whatever asks for a call's results (fetch, sync, the state getters, a setter's pending work, a spectrum that orders
+// itself behind the whole demodulation) first queues its deferred tail.
+int flush_tail(pysdr_ctx* c) {
+  if (!c->tail.valid) return PYSDR_OK;
+  return run_tail(c, c->tail);
 }
 
 }  // namespace
@@ -751,6 +864,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
       if (nf >= 5 && tm >= 64) c->am_tmin = (tm + 63) & ~63;
     } }
   { const char* e = tuning_env("PYSDR_MIXDEC_MFMA"); if (e && *e) c->mfma_enable = atoi(e) ? 1 : 0; }
+  { const char* e = tuning_env("PYSDR_OVERLAP_ORDER"); if (e && *e) c->tail_first = atoi(e); }
   { const char* e = tuning_env("PYSDR_OVERLAP"); if (e && *e) c->overlap_env = std::max(0, std::min(2, atoi(e))); }
   { const char* e = tuning_env("PYSDR_RESAMP_PLAIN"); if (e && *e) c->resamp_plain = atoi(e); }
   { const char* e = tuning_env("PYSDR_MIXDEC_GRID"); if (e && atoi(e) > 0) c->grid_override = atoi(e); }
@@ -827,6 +941,8 @@ void pysdr_destroy(pysdr_ctx* c) {
     if (x.d_y) (void)hipFree(x.d_y);
     if (x.d_y_alt) (void)hipFree(x.d_y_alt);
     if (x.d_y1_alt) (void)hipFree(x.d_y1_alt);
+    if (x.d_ypll_alt) (void)hipFree(x.d_ypll_alt);
+    if (x.d_w_alt) (void)hipFree(x.d_w_alt);
     if (x.d_ypll) (void)hipFree(x.d_ypll);
     if (x.d_a) (void)hipFree(x.d_a);
     if (x.d_am) (void)hipFree(x.d_am);
@@ -849,7 +965,7 @@ void pysdr_destroy(pysdr_ctx* c) {
   for (int k = 0; k < pysdr_ctx::kSlots; ++k)
     for (int i = 0; i < 4; ++i) if (c->ev[k][i]) (void)hipEventDestroy(c->ev[k][i]);
   if (c->ev_front) (void)hipEventDestroy(c->ev_front);
-  for (int i = 0; i < 2; ++i) if (c->ev_s2[i]) (void)hipEventDestroy(c->ev_s2[i]);
+  for (int i = 0; i < 2; ++i) if (c->ev_pll[i]) (void)hipEventDestroy(c->ev_pll[i]);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -959,8 +1075,10 @@ int pysdr_squelch_get(pysdr_ctx* c, int irx, float* level, int* open) {
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
-  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->s2()));
-  PYSDR_HIP_CHECK(hipStreamSynchronize(c->s2()));
+  rc = flush_tail(c);                     // (its wait for the loop walks orders `stream` behind stream2 as well)
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (level) *level = d.sq_level;
   if (open) *open = d.sq_open;
   return PYSDR_OK;
@@ -971,8 +1089,10 @@ int pysdr_pll_stats(pysdr_ctx* c, int irx, int* segments, int* patched) {
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
-  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->s2()));
-  PYSDR_HIP_CHECK(hipStreamSynchronize(c->s2()));
+  rc = flush_tail(c);                     // (its wait for the loop walks orders `stream` behind stream2 as well)
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (segments) *segments = d.pll_segments;
   if (patched) *patched = d.pll_patched;
   return PYSDR_OK;
@@ -983,8 +1103,10 @@ int pysdr_pll_join_margin(pysdr_ctx* c, int irx, int* max_words, float* max_dw) 
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
-  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->s2()));
-  PYSDR_HIP_CHECK(hipStreamSynchronize(c->s2()));
+  rc = flush_tail(c);                     // (its wait for the loop walks orders `stream` behind stream2 as well)
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (max_words) *max_words = d.pll_join_words;
   if (max_dw) *max_dw = d.pll_join_dw;
   return PYSDR_OK;
@@ -1001,8 +1123,10 @@ int pysdr_agc_get(pysdr_ctx* c, int irx, pysdr_agc_state* st) {
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
-  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->s2()));
-  PYSDR_HIP_CHECK(hipStreamSynchronize(c->s2()));
+  rc = flush_tail(c);                     // (its wait for the loop walks orders `stream` behind stream2 as well)
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
   st->agc = d.env; st->gain = d.gain; st->maxbuf = d.maxbuf; st->ref = d.ref; st->err = d.err;
   return PYSDR_OK;
 }
@@ -1074,11 +1198,10 @@ int pysdr_sync(pysdr_ctx* c) {
   if (!c) return PYSDR_ERR_ARG;
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
+  rc = flush_tail(c);
+  if (rc) return rc;
   PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
-  if (c->stream2) {
-    PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream2));
-    c->s2_pending[0] = c->s2_pending[1] = false;
-  }
+  if (c->stream2) PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream2));
   return PYSDR_OK;
 }
 
@@ -1090,10 +1213,11 @@ int pysdr_set_overlap(pysdr_ctx* c, int enable) {
     set_last_error("pysdr_set_overlap: the context feeds an ingest ring, which queues its result copies behind each call on one stream");
     return PYSDR_ERR_STATE;
   }
-  // both halves drained: the switch happens between two calls, whatever is queued
+  // a deferred tail queued, both streams drained: the switch happens between two calls, whatever is queued
+  rc = flush_tail(c);
+  if (rc) return rc;
   PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (c->stream2) PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream2));
-  c->s2_pending[0] = c->s2_pending[1] = false;
   if (c->overlap_env >= 0 && c->n_ingest == 0) enable = c->overlap_env;
   c->overlap = enable;
   return PYSDR_OK;
@@ -1163,17 +1287,12 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   if (rc) return rc;
   const int nrx = snap.nrx;
   const bool wfm = snap.nwfm > 0;
-  // the two halves of the call: `stream` takes the front end, S2 everything behind it (the same stream unless the calls overlap)
+  // F on `stream`; P on SP = stream2 when this call's tail is deferred (the loop walks then run beside the previous call's
+  // tail and the next call's front end), else `stream`; T on `stream`, now or a call later (pysdr_ctx, run_tail)
   const bool use2 = snap.use2;
-  hipStream_t S2 = use2 ? c->stream2 : c->stream;
+  hipStream_t SP = use2 ? c->stream2 : c->stream;
   const int par = c->par;
-  if (use2 && c->s2_pending[par]) {
-    // the second half of the call before last is the last reader of this call's buffers
-    PYSDR_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_s2[par], 0));
-    c->s2_pending[par] = false;
-  }
 
-  const int up = c->cfg.up, down = c->cfg.down;
   const unsigned long long s0 = wfm ? c->wfm_front.s_abs : c->main.s_abs;
   c->peak_cur ^= 1;                       // zeroed by the previous call's history roll (both are zero at the start)
   c->d_peak = c->d_peak2[c->peak_cur];
@@ -1187,28 +1306,43 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
 
   hipEvent_t* ev = c->ev[c->ncalls % pysdr_ctx::kSlots];
   if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[0], c->stream));
-  DecimResult res;
-  int n1 = 0;
+  TailJob job;
+  job.snap = snap; job.wfm = wfm; job.par = par; job.nchunks = nchunks; job.chunk_len = chunk_len; job.n = n; job.s0 = s0;
+  job.ev_end = c->profile ? ev[3] : nullptr;
+  bool any_loop = false;                  // this call has segment walks (P)
+  WfmArgs w;
   if (!wfm) {
+    DecimResult res;
     for (int r = 0; r < nrx; ++r) yptr[r] = snap.rx[r].d_y + c->hy;
     rc = decim_run(c, c->main, d_x, n, nrx, yptr, ph, fw, c->d_peak, chunk_len, c->mmax, &res, c->stream);
     if (rc) return rc;
     c->wfm_front.s_abs = c->main.s_abs;       // both pipelines count the same input stream
+    fill_stage2(c, snap, false, nchunks, chunk_len, res, &job.s);
+    Stage2Args& s = job.s;
+    for (int r = 0; r < nrx; ++r) any_loop |= (s.det[r] == kDetPll);
+    any_loop = any_loop && s.n_out > 0;
+    if (any_loop) {
+      const double fs_out = std::floor(c->cfg.srate * c->cfg.up / c->cfg.down);
+      s.pll = plan_pll(s.n_out, fs_out, kPllBwHz, c->am_taus, 0.0, c->am_tmin,
+                       c->pll_kmax > 0 ? std::min(c->pll_kmax, c->am_kmax) : c->am_kmax, c->d_pllseg);
+      if (c->am_coarse_sweeps > 0 && s.pll.K > 1) {
+        const double tau = fs_out / (kPllZetaPlan * 2.0 * M_PI * kPllBwHz);
+        s.pll.Wexact = ((int)std::ceil(c->am_taus_exact * tau) + 63) & ~63;
+        s.pll.coarse_sweeps = c->am_coarse_sweeps;
+      }
+      rc = launch_am_phase(s, c->stream);     // arg y of every sample: parallel, belongs to F
+      if (rc) return rc;
+    }
   } else {
-    // SRATE -> fs1 (video filter, all RX in one launch), discriminator + pilot PLL at fs1,
-    // then each RX's own fs1 -> FS_OUT resampler
+    // SRATE -> fs1 (video filter, all RX in one launch) and the discriminator at fs1 are F; the pilot loop is P; each
+    // RX's own fs1 -> FS_OUT resampler opens T
     for (int r = 0; r < nrx; ++r) yptr[r] = snap.rx[r].d_y1 + 2;
     DecimResult r1;
     rc = decim_run(c, c->wfm_front, d_x, n, nrx, yptr, ph, fw, c->d_peak, chunk_len, c->m1max, &r1, c->stream);
     if (rc) return rc;
     c->main.s_abs = c->wfm_front.s_abs;
-    n1 = r1.n_out;
-    // broadcast FM: the front end is the IF decimator; discriminator, pilot loop and audio resampler belong to the second half
-    if (use2) {
-      PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream));
-      PYSDR_HIP_CHECK(hipStreamWaitEvent(S2, c->ev_front, 0));
-    }
-    WfmArgs w;
+    const int n1 = r1.n_out;
+    job.n1 = n1;
     memset(&w, 0, sizeof(w));
     w.nrx = nrx; w.n1 = n1;
     const double fs1 = c->cfg.srate / c->d1;
@@ -1246,110 +1380,55 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
         w.pll.Wc_mid = ((int)std::ceil(c->wfm_taus_mid * tau) + 63) & ~63;
       }
     }
-    rc = launch_wfm(w, S2);
+    rc = launch_wfm_disc(w, c->stream);
     if (rc) return rc;
-    const uint32_t zero = 0u;
-    for (int r = 0; r < nrx; ++r) {
-      float2* y1 = snap.rx[r].d_y + c->hy;
-      rc = decim_run(c, c->rx[r].wfm_audio, snap.rx[r].d_w, (size_t)n1, 1, &y1, &zero, &zero, nullptr, 0,
-                     c->mmax, &res, S2);
-      if (rc) return rc;
-    }
+    any_loop = wfm_any_stereo(w);
   }
-  const int n_out = res.n_out;
   // "the input of this call has been consumed": a spectrum that orders itself behind the front end waits for it
-  // (pysdr_spectrum_order, direction 2).  An event record costs ~5.5 us of the stream's timeline on this runtime (the
-  // kernel behind it starts that much later: scripts/diag/timeline.sh), so ONE event serves both the profile and the
-  // ordering, and none is recorded when nobody asked for either.
+  // (pysdr_spectrum_order, direction 2), and so do the loop walks of an overlapped call.  An event record costs ~5.5 us
+  // of the stream's timeline on this runtime (the kernel behind it starts that much later: scripts/diag/timeline.sh), so
+  // ONE event serves the profile and both orderings, and none is recorded when nobody asked for any.
+  // (broadcast FM, single-stream form: the profile's mark sits behind the pilot loop as it always has -- "front" there
+  //  is the whole FM front end)
+  const bool loop_on_2 = use2 && any_loop;
   c->front_marker = nullptr;
-  if (wfm && use2) {
-    // (recorded above, behind the IF decimator; the profile's second mark then sits where the pilot chain ends, on S2)
-    c->front_marker = c->ev_front;
-    if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[1], S2));
-  } else {
-    if (c->profile) { PYSDR_HIP_CHECK(hipEventRecord(ev[1], c->stream)); c->front_marker = ev[1]; }
-    else if (c->front_wanted || use2) { PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream)); c->front_marker = c->ev_front; }
-    if (use2) PYSDR_HIP_CHECK(hipStreamWaitEvent(S2, c->front_marker, 0));
-  }
-
-  Stage2Args s;
-  memset(&s, 0, sizeof(s));
-  s.nrx = nrx; s.n_out = n_out; s.ntaps = c->cfg.ntaps_af; s.hy = c->hy;
-  s.t0 = res.t0; s.up = up; s.down = down; s.chunk_len = (uint32_t)chunk_len; s.nchunks = nchunks;
-  s.m0_lo = (uint32_t)(res.m0 & 0xFFFFFFFFull);
-  const double fs_out = std::floor(c->cfg.srate * up / down);
-  s.fm_scale = (float)(fs_out / (2.0 * M_PI * kNfmFullScaleDev));
-  {
-    const double wn = 2.0 * M_PI * kPllBwHz / fs_out;
-    s.pll_kp = (float)(2.0 * kPllZeta * wn);
-    s.pll_ki = (float)(wn * wn);
-  }
-  bool any_pll = false;
-  for (int r = 0; r < nrx; ++r) {
-    const RxSnap& x = snap.rx[r];
-    s.y[r] = x.d_y + c->hy;
-    s.ypll[r] = x.d_ypll ? x.d_ypll + c->hy : nullptr;
-    s.aftaps[r] = x.d_aftaps;
-    s.taps_real[r] = x.taps_real;
-    s.a[r] = x.d_a;
-    s.am[r] = x.d_am;
-    s.det[r] = mode_detector(x.mode);
-    s.out_complex[r] = (x.mode == PYSDR_IQ || wfm) ? 1 : 0;
-    s.fir_complex[r] = s.out_complex[r];
-    s.single_block[r] = wfm ? 1 : 0;
-    s.single_spread = 1;
-    while (s.single_spread * 2 <= std::min(nchunks, 32)) s.single_spread *= 2;
-    s.matrix[r] = (x.mode == PYSDR_WFM2) ? 1 : 0;
-    s.bfo_fword[r] = x.bfo_fword;
-    s.sq_thresh[r] = x.sq_thresh;
-    c->last_complex[r] = (x.mode == PYSDR_IQ || x.mode == PYSDR_WFM2) ? 1 : 0;
-    any_pll |= (s.det[r] == kDetPll);
-  }
-  s.blkpeak = c->d_blkpeak; s.gain = c->d_gain; s.state = c->d_state;
-  s.blknoise = c->d_blknoise; s.blkcnt = c->d_blkcnt;
-  if (any_pll && n_out > 0) {
-    s.pll = plan_pll(n_out, fs_out, kPllBwHz, c->am_taus, 0.0, c->am_tmin,
-                     c->pll_kmax > 0 ? std::min(c->pll_kmax, c->am_kmax) : c->am_kmax, c->d_pllseg);
-    if (c->am_coarse_sweeps > 0 && s.pll.K > 1) {
-      const double tau = fs_out / (kPllZetaPlan * 2.0 * M_PI * kPllBwHz);
-      s.pll.Wexact = ((int)std::ceil(c->am_taus_exact * tau) + 63) & ~63;
-      s.pll.coarse_sweeps = c->am_coarse_sweeps;
-    }
-    rc = launch_pll(s, S2);
+  // WHERE the previous call's tail goes: behind the start of this call's walks (P(k) beside T(k-1) and F(k+1)) or in FRONT
+  // of the mark they wait for (P(k) starts behind T(k-1) and shares the machine with F(k+1) only).  Measured, one box,
+  // GS/s (profiles/r05_overlap_order_ab.txt): broadcast FM single-stream 377, behind 372-382, in front 432-433 -- the AF FIR
+  // and the audio resampler ran 3.5-5x longer beside the pilot loop's waves (58 -> 320 us, 36 -> 125: the two share the vector
+  // pipe, the walks' DPP scans and v_cos hold it), which put the tail on the critical path; AM-Synch single-stream 370,
+  // behind 426, in front 415-416 (its tail is 85 us against walks of 100).  So: in front for broadcast FM, behind otherwise.
+  if (loop_on_2 && (c->tail_first >= 0 ? c->tail_first != 0 : wfm)) { rc = flush_tail(c); if (rc) return rc; }
+  if (wfm && !loop_on_2 && any_loop) { rc = launch_wfm_pll(w, c->stream); if (rc) return rc; }
+  if (c->profile) { PYSDR_HIP_CHECK(hipEventRecord(ev[1], c->stream)); c->front_marker = ev[1]; }
+  else if (c->front_wanted || loop_on_2) { PYSDR_HIP_CHECK(hipEventRecord(c->ev_front, c->stream)); c->front_marker = c->ev_front; }
+  // P
+  if (loop_on_2) {
+    PYSDR_HIP_CHECK(hipStreamWaitEvent(SP, c->front_marker, 0));
+    rc = wfm ? launch_wfm_pll(w, SP) : launch_pll(job.s, SP);
+    if (rc) return rc;
+    PYSDR_HIP_CHECK(hipEventRecord(c->ev_pll[par], SP));
+    job.wait_pll = true;
+  } else if (!wfm && any_loop) {
+    rc = launch_pll(job.s, c->stream);
     if (rc) return rc;
   }
-  rc = launch_demod_fir(s, S2); if (rc) return rc;
-  // the gains, and beside them (same launch) the history roll of the FS_OUT-rate buffers: the AF FIR was their last reader
-  EpilogueArgs e;
-  memset(&e, 0, sizeof(e));
-  e.nrx = nrx; e.n_out = n_out; e.hy = c->hy;
-  for (int r = 0; r < nrx; ++r) {
-    e.ybase[r] = snap.rx[r].d_y;
-    e.ydst[r] = snap.rx[r].d_y_next;
-    e.ypllbase[r] = (s.det[r] == kDetPll) ? snap.rx[r].d_ypll : nullptr;
-  }
-  rc = launch_agc_scan(s, e, S2); if (rc) return rc;
-  // WFM (mono) emits the real part of the complex pipeline
-  for (int r = 0; r < nrx; ++r) if (snap.rx[r].mode == PYSDR_WFM) s.out_complex[r] = 0;
-  rc = launch_apply(s, S2); if (rc) return rc;
-  if (c->profile) PYSDR_HIP_CHECK(hipEventRecord(ev[3], S2));
   c->ncalls++;
-  c->last_par = par;
-  if (use2) {
-    PYSDR_HIP_CHECK(hipEventRecord(c->ev_s2[par], S2));
-    c->s2_pending[par] = true;
-    c->par = par ^ 1;
-  }
-
   {
     // the NCO phase belongs to the process thread; the lock only orders it against pysdr_rx_add
     std::lock_guard<std::mutex> lk(c->mu);
     for (int r = 0; r < nrx; ++r) c->rx[r].phase = snap.rx[r].phase + snap.rx[r].fword * (uint32_t)n;
   }
-  c->last_nrx = nrx;
-  c->last_nout = n_out; c->last_nchunks = nchunks;
-  c->last_chunk_len = chunk_len; c->last_s0 = s0; c->last_wfm = wfm ? 1 : 0;
-  return PYSDR_OK;
+  // T: the previous call's if it was deferred, then this call's -- now, or left for the next call / a flush
+  rc = flush_tail(c);
+  if (rc) return rc;
+  if (use2) {
+    c->tail = job;
+    c->tail.valid = true;
+    c->par = par ^ 1;
+    return PYSDR_OK;
+  }
+  return run_tail(c, job);
 }
 
 // outputs of the last call per chunk: those whose newest input sample falls into chunk k (a
@@ -1374,12 +1453,13 @@ int pysdr_fetch(pysdr_ctx* c, int irx, float* am, float* iq, int cap, int* n_out
   if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
+  rc = flush_tail(c);                     // a deferred tail (pysdr_set_overlap) is queued now: its results are what is asked for
+  if (rc) return rc;
   const int n = c->last_nout;
   if ((am || iq) && cap < n) { set_last_error("pysdr_fetch: cap %d < n_out %d", cap, n); return PYSDR_ERR_ARG; }
   const int cx = c->last_complex[irx];
   // The epilogue rolled the last hy outputs into the prefix but left [hy, hy+n) intact.
-  // (on the stream of the call's second half: it is ordered behind the front end, whose raw peaks and IQ these are)
-  hipStream_t S2 = c->s2();
+  hipStream_t S2 = c->stream;
   const float2* yb = c->last_par ? c->rx[irx].d_y_alt : c->rx[irx].d_y;
   if (am && n > 0)
     PYSDR_HIP_CHECK(hipMemcpyAsync(am, c->rx[irx].d_am, (size_t)n * (cx ? 2 : 1) * sizeof(float), hipMemcpyDeviceToHost, S2));
@@ -1703,7 +1783,8 @@ int pysdr_spectrum_order(pysdr_spectrum* sp, pysdr_ctx* c, int direction) {
     return PYSDR_OK;
   }
   if (!sp->ev_order) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&sp->ev_order, hipEventDisableTiming));
-  hipStream_t first = direction == 0 ? c->s2() : sp->stream;     // (the second half of a call ends last)
+  if (direction == 0) { rc = flush_tail(c); if (rc) return rc; }   // "behind the whole demodulation" includes a deferred tail
+  hipStream_t first = direction == 0 ? c->stream : sp->stream;
   hipStream_t then = direction == 0 ? sp->stream : c->stream;
   PYSDR_HIP_CHECK(hipEventRecord(sp->ev_order, first));
   PYSDR_HIP_CHECK(hipStreamWaitEvent(then, sp->ev_order, 0));

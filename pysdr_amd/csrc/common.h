@@ -251,7 +251,8 @@ struct Stage2Args {
   RxDevState* state;                  // [nrx]
   PllPlan pll;                        // AM-Synch carrier PLL segmentation of this call
 };
-int launch_pll(const Stage2Args& a, hipStream_t st);
+int launch_am_phase(const Stage2Args& a, hipStream_t st);   // arg y -> phase words (parallel; in front of the walks)
+int launch_pll(const Stage2Args& a, hipStream_t st);        // the carrier loop's segment walks + patch-up pass
 int launch_demod_fir(const Stage2Args& a, hipStream_t st);
 int launch_apply(const Stage2Args& a, hipStream_t st);
 
@@ -261,6 +262,7 @@ struct EpilogueArgs {
   float2* ydst[PYSDR_MAX_RX];         // where the NEXT call's prefix lives: ybase, or the other buffer of the pair when the
                                       // front end of the next call already writes beside this call's stage 2 (pysdr_set_overlap)
   float2* ypllbase[PYSDR_MAX_RX];     // may be null
+  float2* yplldst[PYSDR_MAX_RX];      // the next call's PLL buffer (= ypllbase unless the calls overlap)
 };
 // block gains (one workgroup per RX) + the history roll of the FS_OUT-rate buffers (two workgroups per RX), one launch
 int launch_agc_scan(const Stage2Args& a, const EpilogueArgs& e, hipStream_t st);
@@ -284,7 +286,9 @@ struct WfmArgs {
   PllPlan pll;                        // pilot PLL segmentation of this call
   int pll_pass;                       // 0: first pass over the segments, 1: the redo pass (only if state.wfm_redo)
 };
-int launch_wfm(const WfmArgs& a, hipStream_t st);
+int launch_wfm_disc(const WfmArgs& a, hipStream_t st);      // polar discriminator + the IF buffer's 1-sample history
+bool wfm_any_stereo(const WfmArgs& a);
+int launch_wfm_pll(const WfmArgs& a, hipStream_t st);       // the pilot loop's segment walks, check and patch-up passes
 
 // ---- misc kernels (misc.hip) ---------------------------------------------------------
 int launch_quad_mixer(const float2* x, float2* y, size_t n, uint32_t phase0, uint32_t fword,

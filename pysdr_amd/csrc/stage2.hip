@@ -109,12 +109,24 @@ __device__ __forceinline__ uint32_t phase_word(float x, float y) {
   return (uint32_t)(y < 0.f ? -a : a);
 }
 
-// grid (ceil(n / 256), nrx): the phase word of every new sample, into the .y of the PLL buffer (its .x gets Re v)
+// grid (ceil(n / 2048), nrx): the phase word of every new sample, into the .y of the PLL buffer (its .x gets Re v).
+// Eight samples per thread, 256 apart, all eight loads in flight before the first is used (one sample per thread: 16 k
+// workgroups of one load each, 17 us for 4.2 M samples = 3 TB/s of 12 bytes per sample).
+constexpr int kPhasePer = 8;
 __global__ __launch_bounds__(256) void am_phase_kernel(const Stage2Args a) {
-  const int r = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-  if (a.det[r] != kDetPll || i >= a.n_out) return;
-  const float2 v = a.y[r][i];
-  reinterpret_cast<uint32_t*>(a.ypll[r] + i)[1] = phase_word(v.x, v.y);
+  const int r = blockIdx.y, i0 = blockIdx.x * (256 * kPhasePer) + threadIdx.x;
+  if (a.det[r] != kDetPll) return;
+  float2 v[kPhasePer];
+#pragma unroll
+  for (int j = 0; j < kPhasePer; ++j) {
+    const int i = i0 + 256 * j;
+    v[j] = i < a.n_out ? a.y[r][i] : make_float2(0.f, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < kPhasePer; ++j) {
+    const int i = i0 + 256 * j;
+    if (i < a.n_out) reinterpret_cast<uint32_t*>(a.ypll[r] + i)[1] = phase_word(v[j].x, v[j].y);
+  }
 }
 
 // The loop over [i_begin, i_end) from the state (ph0, w0) in front of sample i_begin; 64 samples per block.
@@ -643,7 +655,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
   if ((int)blockIdx.x >= a.nrx) {
     const int job = blockIdx.x - a.nrx;
     const float2* base = (job < eh.nrx) ? eh.ybase[job] : eh.ypllbase[job - eh.nrx];
-    float2* dst = (job < eh.nrx) ? eh.ydst[job] : eh.ypllbase[job - eh.nrx];
+    float2* dst = (job < eh.nrx) ? eh.ydst[job] : eh.yplldst[job - eh.nrx];
     if (base == nullptr) return;
     float2* sh = reinterpret_cast<float2*>(agc_lds);
     // element j of the new prefix = old element n_out + j  (prefix occupies [0,hy))
@@ -907,6 +919,9 @@ __global__ __launch_bounds__(256) void wfm_disc_kernel(const WfmArgs a) {
   if (i >= a.n1) return;
   // (nontemporal loads here measured 36.1-36.6 us against 34.6-35.8: plain)
   const float2 yb = a.y1[r][i], ya = a.y1[r][i - 1];
+  // the 1-sample IF history of the NEXT call (this kernel is the buffer's only reader; until round 5 the pilot loop's
+  // patch-up kernel rolled it, which tied the next call's discriminator to this call's pilot loop)
+  if (i == a.n1 - 1) a.y1dst[r][1] = yb;
   const float re = yb.x * ya.x + yb.y * ya.y;
   const float im = yb.y * ya.x - yb.x * ya.y;
   a.w[r][i] = make_float2(atan2f(im, re) * a.scale, 0.f);
@@ -1124,8 +1139,6 @@ __global__ __launch_bounds__(64) void wfm_pll_check_kernel(const WfmArgs a) {
 
 __global__ __launch_bounds__(64) void wfm_pll_patch_kernel(const WfmArgs a) {
   const int r = blockIdx.x, lane = threadIdx.x;
-  // roll the 1-sample IF history for the next call (the discriminator kernel is done: same stream)
-  if (lane == 0 && a.n1 > 0) a.y1dst[r][1] = a.y1[r][a.n1 - 1];
   if (!a.stereo[r] || a.n1 <= 0) return;
   const PllPlan& pl = a.pll;
   const int K = pl.K, n = a.n1;
@@ -1199,9 +1212,13 @@ __global__ __launch_bounds__(64) void wfm_pll_patch_kernel(const WfmArgs a) {
 
 }  // namespace
 
-int launch_pll(const Stage2Args& a, hipStream_t st) {
-  hipLaunchKernelGGL(am_phase_kernel, dim3((a.n_out + 255) / 256, a.nrx), dim3(256), 0, st, a);
+int launch_am_phase(const Stage2Args& a, hipStream_t st) {
+  hipLaunchKernelGGL(am_phase_kernel, dim3((a.n_out + 256 * kPhasePer - 1) / (256 * kPhasePer), a.nrx), dim3(256), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
+  return PYSDR_OK;
+}
+
+int launch_pll(const Stage2Args& a, hipStream_t st) {
   hipLaunchKernelGGL(am_pll_seg_kernel, dim3(a.pll.K, a.nrx), dim3(64), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   if (a.pll.K > 1) {                          // (a one-segment call writes its end state itself)
@@ -1289,11 +1306,21 @@ int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, 
   return PYSDR_OK;
 }
 
-int launch_wfm(const WfmArgs& a, hipStream_t st) {
+int launch_wfm_disc(const WfmArgs& a, hipStream_t st) {
   if (a.n1 > 0) {
     hipLaunchKernelGGL(wfm_disc_kernel, dim3((a.n1 + 255) / 256, a.nrx), dim3(256), 0, st, a);
     PYSDR_HIP_CHECK(hipGetLastError());
   }
+  return PYSDR_OK;
+}
+
+bool wfm_any_stereo(const WfmArgs& a) {
+  bool any_stereo = false;
+  for (int r = 0; r < a.nrx; ++r) any_stereo |= (a.stereo[r] != 0);
+  return any_stereo && a.n1 > 0;
+}
+
+int launch_wfm_pll(const WfmArgs& a, hipStream_t st) {
   bool any_stereo = false;
   for (int r = 0; r < a.nrx; ++r) any_stereo |= (a.stereo[r] != 0);
   if (any_stereo && a.n1 > 0) {
@@ -1308,8 +1335,10 @@ int launch_wfm(const WfmArgs& a, hipStream_t st) {
       PYSDR_HIP_CHECK(hipGetLastError());
     }
   }
-  hipLaunchKernelGGL(wfm_pll_patch_kernel, dim3(a.nrx), dim3(64), 0, st, a);
-  PYSDR_HIP_CHECK(hipGetLastError());
+  if (any_stereo && a.n1 > 0) {
+    hipLaunchKernelGGL(wfm_pll_patch_kernel, dim3(a.nrx), dim3(64), 0, st, a);
+    PYSDR_HIP_CHECK(hipGetLastError());
+  }
   return PYSDR_OK;
 }
 

@@ -254,6 +254,16 @@ static void check_plan(const PllPlan& p, int n, int nrx) {
   write_all(p.seg, (size_t)nrx * p.K * 4);
 }
 
+int launch_am_phase(const Stage2Args& a, hipStream_t) {
+  for (int r = 0; r < a.nrx; ++r)
+    if (a.det[r] == kDetPll) {
+      SAN_CHECK(a.ypll[r] != nullptr, "AM-Synch rx %d has no PLL buffer", r);
+      read_all(a.y[r], (size_t)a.n_out);
+      write_all(a.ypll[r], (size_t)a.n_out);
+    }
+  return PYSDR_OK;
+}
+
 int launch_pll(const Stage2Args& a, hipStream_t) {
   check_plan(a.pll, a.n_out, a.nrx);
   for (int r = 0; r < a.nrx; ++r)
@@ -313,7 +323,8 @@ static int stub_epilogue(const EpilogueArgs& a) {
   SAN_CHECK(a.hy <= 4096, "hy %d", a.hy);
   for (int r = 0; r < a.nrx; ++r) {
     SAN_CHECK(a.ydst[r] != nullptr, "rx %d: no destination for the next call's prefix", r);
-    const std::pair<float2*, float2*> jobs[2] = {{a.ybase[r], a.ydst[r]}, {a.ypllbase[r], a.ypllbase[r]}};
+    SAN_CHECK((a.ypllbase[r] == nullptr) == (a.yplldst[r] == nullptr), "rx %d: PLL buffer and its prefix destination", r);
+    const std::pair<float2*, float2*> jobs[2] = {{a.ybase[r], a.ydst[r]}, {a.ypllbase[r], a.yplldst[r]}};
     for (const auto& j : jobs)
       if (j.first) {
         read_all(j.first, (size_t)a.hy + a.n_out);
@@ -323,8 +334,7 @@ static int stub_epilogue(const EpilogueArgs& a) {
   return PYSDR_OK;
 }
 
-int launch_wfm(const WfmArgs& a, hipStream_t) {
-  check_plan(a.pll, a.n1, a.nrx);
+int launch_wfm_disc(const WfmArgs& a, hipStream_t) {
   for (int r = 0; r < a.nrx; ++r) {
     SAN_CHECK(a.y1[r] == a.y1base[r] + 2, "IF buffer layout");
     read_all(a.y1[r] - 1, (size_t)a.n1 + 1);
@@ -332,6 +342,19 @@ int launch_wfm(const WfmArgs& a, hipStream_t) {
     SAN_CHECK(a.y1dst[r] != nullptr, "IF prefix destination");
     if (a.n1 > 0) a.y1dst[r][1] = a.y1[r][a.n1 - 1];
   }
+  return PYSDR_OK;
+}
+
+bool wfm_any_stereo(const WfmArgs& a) {
+  bool any = false;
+  for (int r = 0; r < a.nrx; ++r) any |= (a.stereo[r] != 0);
+  return any && a.n1 > 0;
+}
+
+int launch_wfm_pll(const WfmArgs& a, hipStream_t) {
+  check_plan(a.pll, a.n1, a.nrx);
+  for (int r = 0; r < a.nrx; ++r)
+    if (a.stereo[r]) { read_all(a.w[r], (size_t)a.n1); write_all(a.w[r], (size_t)a.n1); }
   read_all(a.state, (size_t)a.nrx);
   return PYSDR_OK;
 }
