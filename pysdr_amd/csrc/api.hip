@@ -564,6 +564,12 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
   snap->nrx = c->nrx;
   snap->nwfm = 0;
   for (int r = 0; r < c->nrx; ++r) snap->nwfm += is_wfm(c->rx[r].mode) ? 1 : 0;
+  if (snap->nwfm != 0 && snap->nwfm != c->nrx) {
+    // the reference's mode is global (P.MODE) and the rate-reduction order differs for
+    // broadcast FM (receiver.py:718-719): one context runs one pipeline
+    set_last_error("pysdr_process_batch: WFM/WFM2 cannot be mixed with narrow-band modes in one context");
+    return PYSDR_ERR_STATE;
+  }
   // Overlapping calls: a deferred tail belongs to the PREVIOUS call and must see the taps / AGC settings / buffers of that
   // call, so whatever a setter left to do (taps, resets, buffers) and any change of form first flushes it and drains both
   // streams -- it is rare, and everything below may then go on `stream` as in the single-stream form (drained again at
@@ -572,12 +578,15 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
   snap->use2 = c->overlap >= 2;
   for (int r = 0; r < c->nrx && c->overlap == 1; ++r)
     snap->use2 |= (c->rx[r].mode == PYSDR_AM_SYNCH || c->rx[r].mode == PYSDR_WFM2);
+  // the second buffer of every pair exists while the calls overlap AND afterwards for as long as the current buffer is the
+  // second one (par only moves in overlapped calls; a single-stream call stays on whichever buffer is current)
+  const bool need_alt = snap->use2 || c->par != 0;
   bool dirty = snap->use2 != c->use2;
-  for (int r = 0; r < c->nrx && (snap->use2 || c->tail.valid); ++r) {
+  for (int r = 0; r < c->nrx && (need_alt || c->tail.valid); ++r) {
     const RxHost& x = c->rx[r];
     dirty |= x.taps_dirty || x.af_dirty || x.agc_dirty || x.reset_pending != 0 || (is_wfm(x.mode) && x.wfm_dirty) ||
-             (x.mode == PYSDR_AM_SYNCH && (x.d_ypll == nullptr || (snap->use2 && x.d_ypll_alt == nullptr))) ||
-             (snap->use2 && (x.d_y_alt == nullptr || (x.d_y1 != nullptr && x.d_y1_alt == nullptr)));
+             (x.mode == PYSDR_AM_SYNCH && (x.d_ypll == nullptr || (need_alt && x.d_ypll_alt == nullptr))) ||
+             (need_alt && (x.d_y_alt == nullptr || (x.d_y1 != nullptr && x.d_y1_alt == nullptr)));
   }
   if (dirty) {
     int rc = flush_tail(c);
@@ -598,7 +607,7 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       for (int i = 0; i < 2; ++i) PYSDR_HIP_CHECK(hipEventCreateWithFlags(&c->ev_pll[i], hipEventDisableTiming));
     }
     c->use2 = snap->use2;
-    drained = snap->use2;
+    drained = true;
   }
   for (int r = 0; r < c->nrx; ++r) {
     RxHost& x = c->rx[r];
@@ -618,7 +627,7 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       if (!x.d_y1) {
         PYSDR_HIP_CHECK(hipMalloc(&x.d_y1, ((size_t)c->m1max + 2) * sizeof(float2)));
         PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y1, 0, ((size_t)c->m1max + 2) * sizeof(float2), c->stream));
-        drained = drained || snap->use2;      // (the pair's second buffer follows below)
+        drained = drained || need_alt;        // (the pair's second buffer follows below)
         PYSDR_HIP_CHECK(hipMalloc(&x.d_w, (size_t)c->m1max * sizeof(float2)));
         rc = decim_init(x.wfm_audio, c->up2, c->down2, (int)x.wfm_resamp.size(), 1, c->stream);
         if (rc) return rc;
@@ -663,19 +672,24 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       PYSDR_HIP_CHECK(hipMalloc(&x.d_ypll, n * sizeof(float2)));
       PYSDR_HIP_CHECK(hipMemsetAsync(x.d_ypll, 0, n * sizeof(float2), c->stream));
     }
-    if (snap->use2 && x.d_ypll != nullptr && x.d_ypll_alt == nullptr) {
+    // (a second buffer that comes into being while it is the CURRENT one -- a mode first used after overlapped calls left
+    //  par at 1 -- inherits the history prefix of the first, which is where that mode's last use left it)
+    if (need_alt && x.d_ypll != nullptr && x.d_ypll_alt == nullptr) {
       const size_t ny = (size_t)c->hy + c->mmax;
       PYSDR_HIP_CHECK(hipMalloc(&x.d_ypll_alt, ny * sizeof(float2)));
       PYSDR_HIP_CHECK(hipMemsetAsync(x.d_ypll_alt, 0, ny * sizeof(float2), c->stream));
+      if (c->par) PYSDR_HIP_CHECK(hipMemcpyAsync(x.d_ypll_alt, x.d_ypll, (size_t)c->hy * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
     }
-    if (snap->use2 && x.d_y_alt == nullptr) {
+    if (need_alt && x.d_y_alt == nullptr) {
       const size_t ny = (size_t)c->hy + c->mmax;
       PYSDR_HIP_CHECK(hipMalloc(&x.d_y_alt, ny * sizeof(float2)));
       PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y_alt, 0, ny * sizeof(float2), c->stream));
+      if (c->par) PYSDR_HIP_CHECK(hipMemcpyAsync(x.d_y_alt, x.d_y, (size_t)c->hy * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
     }
-    if (snap->use2 && x.d_y1 != nullptr && x.d_y1_alt == nullptr) {
+    if (need_alt && x.d_y1 != nullptr && x.d_y1_alt == nullptr) {
       PYSDR_HIP_CHECK(hipMalloc(&x.d_y1_alt, ((size_t)c->m1max + 2) * sizeof(float2)));
       PYSDR_HIP_CHECK(hipMemsetAsync(x.d_y1_alt, 0, ((size_t)c->m1max + 2) * sizeof(float2), c->stream));
+      if (c->par) PYSDR_HIP_CHECK(hipMemcpyAsync(x.d_y1_alt, x.d_y1, 2 * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
       PYSDR_HIP_CHECK(hipMalloc(&x.d_w_alt, (size_t)c->m1max * sizeof(float2)));
     }
     RxSnap& q = snap->rx[r];
@@ -1477,6 +1491,8 @@ int pysdr_fetch(pysdr_ctx* c, int irx, float* am, float* iq, int cap, int* n_out
 int pysdr_process(pysdr_ctx* c, const float* iq, size_t n, pysdr_out* outs) {
   if (!c || !iq || !outs || n < 1) return PYSDR_ERR_ARG;
   int rc = pysdr_process_batch(c, iq, 1, n, 0);
+  if (rc) return rc;
+  rc = flush_tail(c);                     // (an overlapped context deferred the call's tail: its results are wanted now)
   if (rc) return rc;
   for (int r = 0; r < c->last_nrx; ++r) {
     int nout = 0, cx = 0;

@@ -173,6 +173,28 @@ static void single_rx_long_prototype(const Rate& r) {
   const char* off = getenv("PYSDR_MIXDEC_MFMA");
   const bool expect = !(tun && atoi(tun) > 0 && off && atoi(off) == 0);
   if ((pysdr::g_mfma_launches > before) != expect) { std::fprintf(stderr, "matrix-core path: launches %d, expected %d\n", pysdr::g_mfma_launches - before, (int)expect); std::exit(1); }
+  // Mode changes across the forms of a call: AM-Synch batches (overlapped when the pass allows it: the pairs' current buffer
+  // alternates and is left on the SECOND one by an odd number of calls), then modes whose buffers have not existed yet
+  // (their second buffer must come into being as the current one), and back.
+  std::vector<float> x(2 * (size_t)max_chunks * r.in_chunk, 0.2f);
+  for (int round = 0; round < 2; ++round) {
+    OK(pysdr_set_mode(c, 0, PYSDR_AM_SYNCH, af.data(), ntaps_af, 0.0));
+    for (int k = 0; k < 3; ++k) OK(pysdr_process_batch(c, x.data(), max_chunks, r.in_chunk, 0));
+    OK(pysdr_set_mode(c, 0, PYSDR_NFM, af.data(), ntaps_af, 0.0));
+    OK(pysdr_process_batch(c, x.data(), 2, r.in_chunk, 0));
+    if (r.fs == 2.048e6) {                                  // a rate pysdr_wfm_params accepts
+      int d1 = 0, up2 = 0, down2 = 0;
+      if (pysdr_wfm_params(r.fs, 48000.0, &d1, &up2, &down2) == 0) {
+        const auto video = taps(ntaps_dec), res = taps(64 * up2);
+        OK(pysdr_set_wfm_taps(c, 0, video.data(), ntaps_dec, res.data(), 64 * up2));
+        OK(pysdr_set_mode(c, 0, PYSDR_WFM2, af.data(), ntaps_af, 0.0));
+        for (int k = 0; k < 2 + round; ++k) OK(pysdr_process_batch(c, x.data(), max_chunks, r.in_chunk, 0));
+        OK(pysdr_set_mode(c, 0, PYSDR_WFM, af.data(), ntaps_af, 0.0));
+        OK(pysdr_process_batch(c, x.data(), 1, r.in_chunk, 0));
+      }
+    }
+    run_calls(c, r, 1, max_chunks, {L, 5});
+  }
   pysdr_destroy(c);
 }
 
@@ -194,6 +216,30 @@ static void broadcast_fm() {
   run_calls(c, r, 1, max_chunks, {(size_t)r.in_chunk});
   int seg = 0, pat = 0;
   OK(pysdr_pll_stats(c, 0, &seg, &pat));
+  pysdr_destroy(c);
+}
+
+// A narrow-band and a broadcast-FM sub-receiver in one context: the call is refused (one context runs one pipeline,
+// receiver.py:718-719) and the context is torn down with whatever the refused call left behind.
+static void mixed_modes_are_refused() {
+  const Rate r = kRates[1];
+  const int ntaps = 255;
+  pysdr_ctx* c = make_ctx(r, 1, ntaps, ntaps);
+  const auto h = taps(ntaps), af = taps(2 * ntaps);
+  int irx = -1;
+  OK(pysdr_rx_add(c, PYSDR_AM, 100e3, h.data(), af.data(), 0.0, &irx));
+  OK(pysdr_rx_add(c, PYSDR_AM, 200e3, h.data(), af.data(), 0.0, &irx));
+  int d1 = 0, up2 = 0, down2 = 0;
+  OK(pysdr_wfm_params(r.fs, 48000.0, &d1, &up2, &down2));
+  const auto res = taps(64 * up2);
+  OK(pysdr_set_wfm_taps(c, 1, h.data(), ntaps, res.data(), 64 * up2));
+  OK(pysdr_set_mode(c, 1, PYSDR_WFM, af.data(), ntaps, 0.0));
+  std::vector<float> x(2 * (size_t)r.in_chunk, 0.f);
+  std::vector<float> am(4 * 2048), iq(4 * 2048);
+  pysdr_out outs[2];
+  for (int i = 0; i < 2; ++i) { outs[i].am = am.data() + 4096 * i; outs[i].iq = iq.data() + 4096 * i; outs[i].cap = 2048; }
+  FAILS(pysdr_process(c, x.data(), r.in_chunk, outs));
+  FAILS(pysdr_process(c, x.data(), r.in_chunk, outs));
   pysdr_destroy(c);
 }
 
@@ -306,6 +352,7 @@ int main(int argc, char** argv) {
     const bool expect = !(tun && atoi(tun) > 0 && off && atoi(off) == 0);
     if ((pysdr::g_mfma_launches > before) != expect) { std::fprintf(stderr, "broadcast FM: matrix-core launches %d\n", pysdr::g_mfma_launches - before); return 1; }
   }
+  mixed_modes_are_refused();
   spectrum();
   }
   std::puts("HOST_SAN_OK");
