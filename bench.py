@@ -888,10 +888,12 @@ def main():
 
     mfma_on = bool(tune[7]) and nrx == 1 and ((not is_wfm and (P.UP, P.DOWN, cfg['ntaps_dec']) == (3, 128, 1001)) or
                                               (is_wfm and rxs[0].demod.wfm_d1 == 40 and cfg['ntaps_dec'] == 255))
+    overlapped = bool(lib.pysdr_last_call_overlapped(ctx.h))
     front_name = ((("mixdec_mfma_kernel (f32 MFMA, shifted-tap columns; " if mfma_on else f"mixdec_kernel<{nrx}> (") +
-                   "fused NCO mix + polyphase decimate, all RX)") if not is_wfm else
+                   "fused NCO mix + polyphase decimate, all RX)" + (" + am_phase_kernel" if synch else "")) if not is_wfm else
                   (("mixdec_mfma_kernel<1/40>" if mfma_on else "mixdec_kernel<1,16>") +
-                   " + wfm_disc/pll + resamp_wave_kernel (FM front end: IF decimate, discriminator, pilot PLL, audio resample)"))
+                   (" + wfm_disc_kernel (IF decimate, discriminator; the pilot loop runs on the second stream)" if overlapped else
+                    " + wfm_disc / wfm_pll kernels (FM front end: IF decimate, discriminator, pilot PLL)")))
     r_front = roof(front_name, k1_bytes, k1_ms if k1 else None,
                    measured_traffic(args, nrx, B, "mixdec", ["mixdec_mfma.hip", "mixdec_mfma_geom.h"] if (mfma_on and not is_wfm)
                                     else (["mixdec_mfma.hip", "mixdec_mfma_geom.h", "resamp_small.hip"] if mfma_on else ["mixdec.hip"])))

@@ -145,14 +145,17 @@ int pysdr_process(pysdr_ctx* ctx, const float* iq_interleaved, size_t n, pysdr_o
  * (receiver.py:541-559) and the throughput benchmark. */
 int pysdr_process_batch(pysdr_ctx* ctx, const void* iq, int nchunks, size_t chunk_len, int on_device);
 /* Batch pipelining (a build feature, no reference call site; the analogue in the reference is MP_SCHEME 2/3 running the
- * demodulators beside the chunk acquisition, receiver.py:726-739): the audio-rate half of a call (PLL walks, detector +
- * AF filter, AGC; for broadcast FM everything behind the IF decimator) is queued on a second HIP stream and runs BESIDE
- * the mix + decimate of the next call; results, state and every other entry point are unchanged (pysdr_fetch /
- * pysdr_sync wait for both halves).  enable = 0 off (default), 1 = in the calls where it pays -- those with a serial
- * loop in them (AM-Synch carrier PLL, WFM2 pilot PLL: a long latency-bound second half that needs no LDS; elsewhere the AF
- * FIR cannot start while the front end's persistent workgroups hold the LDS, and the halves take turns anyway), 2 = in
- * every call (A/B).  A context that feeds an ingest ring runs single-stream: pysdr_ingest_create* switches this off, and
- * switching it on then fails with PYSDR_ERR_STATE.  pysdr_last_call_overlapped: the form the last call really took. */
+ * demodulators beside the chunk acquisition, receiver.py:726-739).  A call is three groups of launches: F the front end
+ * (mix + decimate, and the parallel kernel in front of a serial loop), P the segment walks of a serial loop (AM-Synch
+ * carrier PLL, WFM2 pilot PLL: thousands of single-wave chains, latency bound, no LDS), T the tail (detector + AF
+ * filter, AGC, output; for broadcast FM the audio resampler first).  Overlapped, P(k) is queued on a second HIP stream and
+ * T(k) is DEFERRED: it is queued behind F(k+1) by the next pysdr_process_batch, or at once by whatever asks for the
+ * call's results (pysdr_fetch, pysdr_sync, the state getters, a setter with pending work) -- so the walks of call k run
+ * beside the tail of call k-1 and the front end of call k+1.  Results, state and every other entry point are unchanged, bit
+ * for bit (tests/test_gpu_overlap.py).  enable = 0 off (default), 1 = the calls with a serial loop in them, 2 = every
+ * call (tests: without a loop nothing runs on the second stream, the buffers and the deferral are exercised all the
+ * same).  A context that feeds an ingest ring runs single-stream: pysdr_ingest_create* switches this off, and switching it
+ * on then fails with PYSDR_ERR_STATE.  pysdr_last_call_overlapped: the form the last call really took. */
 /* 0 for a library built from the sources as they are; otherwise a 31-bit hash of the extra compiler flags (A/B switches
  * from PYSDR_*_FLAGS under PYSDR_TUNING=1, or the diagnostic build's) it was built with -- echoed by bench.py. */
 int pysdr_build_flags_hash(void);

@@ -9,7 +9,7 @@ OUT=${1:-gpurun_out/prof}
 QUICK=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$OUT" && mkdir -p "$OUT"
-TAG=${PROFILE_TAG:-r04}
+TAG=${PROFILE_TAG:-r05}
 declare -a CFG_NAMES=() CFG_ARGS=()
 run_cfg() {  # name, pmc(0/1), bench args...
   local name=$1 pmc=$2; shift 2
@@ -38,7 +38,8 @@ run_cfg c2 1 --workload c2
 run_cfg c1 1 --workload c1
 run_cfg c4 1 --workload c4
 run_cfg c4mono 0 --workload c4mono --no-cpu-baseline
-run_cfg rx6 0 --nrx 6 --no-psd --no-cpu-baseline
+run_cfg rx6 0 --workload rx6 --no-cpu-baseline
+run_cfg c1synch 0 --workload c1synch --no-cpu-baseline
 # The plain bench lines (events only, no profiler attached) come LAST: the counters above are first condensed into
 # profiles/<tag>_pmc_traffic.json (stamped with the hashes of the kernel sources), so that the lines carry `traffic`.
 python3 scripts/summarize_profiles.py "$OUT" profiles "$TAG" > "$OUT/summarize.log" 2>&1
