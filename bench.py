@@ -469,13 +469,21 @@ def verify_rank(cfg, ctx, rxs, rx_idx, xu, nloop, seam, nsamp, L, B, steps_done,
         x = stream_slice(xu, nloop, seam, nsamp, s_start, (prime + nchk) * L)
         want_am = [[] for _ in orx]
         want_iq = [[] for _ in orx]
-        for k in range(prime + nchk):
-            xc = x[k * L:(k + 1) * L]
-            for i, o in enumerate(orx):
-                a = o.demod_data(xc)
+
+        def one_rx(i):                  # the sub-receivers are independent: one thread each (NumPy / SciPy release the GIL in the
+            o = orx[i]                  # resampler and the FIRs, where the time goes); 6 RX x 194 chunks took 19 s in a row
+            for k in range(prime + nchk):
+                a = o.demod_data(x[k * L:(k + 1) * L])
                 if k >= prime:
                     want_am[i].append(np.array(a))
                     want_iq[i].append(np.array(o.iq))
+
+        if len(orx) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=len(orx)) as ex:
+                list(ex.map(one_rx, range(len(orx))))
+        else:
+            one_rx(0)
         for i, o in enumerate(orx):
             am, iq, cn, _pk = ctx.fetch(i, B)
             n = int(cn[:nchk].sum())

@@ -221,6 +221,86 @@ def test_am_synch_unlocked_loop_degenerates_to_the_serial_walk():
     assert abs(agc[0] - agc_s[0]) <= 1e-5 * agc_s[0]
 
 
+def _carrier_stream(n, fs, f_off, snr_noise, jumps=(), seed=21, depth=0.5):
+    """An AM station f_off Hz off tune at the decimator's INPUT rate is what the tests above use; here the signal is
+    made at 2.048 MS/s the same way but with phase jumps of the carrier at given sample indices."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n, dtype=np.float64) / fs
+    ph = 2 * np.pi * (100e3 + f_off) * t
+    for at, rad in jumps:
+        ph[at:] += rad
+    x = 0.3 * (1 + depth * np.sin(2 * np.pi * 1000.0 * t)) * np.exp(1j * ph)
+    x += snr_noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2)
+    return x.astype(np.complex64)
+
+
+@pytest.mark.parametrize("f_off,noise,jumps", [(-7.0, 2e-3, ((700001, 2.0), (1500003, -2.6))),     # the carrier jumps twice inside the call
+                                               (40.0, 3e-2, ()),                                   # the edge of the loop's range, -20 dBc of noise
+                                               (-120.0, 2e-3, ())])                                # beyond it: cycle slips
+def test_am_synch_hard_carriers_equal_the_serial_oracle(f_off, noise, jumps):
+    """The carrier loop as segments + sweeps against the serial float32 CarrierPLL of the oracle where a warm-up has
+    something to get wrong: phase jumps of 2 and 2.6 rad in the middle of a call (a warm-up that converged before a
+    jump goes through it like the serial walk; one that starts inside the pull-in has to find the same trajectory),
+    a noisy carrier 40 Hz off tune (the loop's noise bandwidth is 50 Hz), and one 120 Hz off (the loop slips cycles;
+    whatever the joins do, the patch-up pass makes the result the serial walk's).  60 chunks = 120 segments, two calls."""
+    cfg = dict(so.CONFIGS['C1'])
+    cfg['ntaps_dec'] = 255
+    cfg['rx'] = [dict(frq=100e3, mode='AM-Synch', video_bw=10e3, af_bw=5e3)]
+    B = 60
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    x = _carrier_stream(2 * B * L, cfg['fs'], f_off, noise, jumps)
+    P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[7e6], mode='AM-Synch', nfilt=255, max_batch_chunks=B)
+    P.VIDEO_BW = 10e3
+    g = sig_proc.Receiver(P, 100e3, 0, '1')
+    g.mode, g.af_bw = 'AM-Synch', 5e3
+    ctx = P._pysdr_stream
+    got, stats = [], []
+    for h in range(2):
+        ctx.process_batch(x[h * B * L:(h + 1) * B * L], B, L, on_device=False)
+        got.append(ctx.fetch(0, B)[0].copy())
+        stats.append(pll_stats(ctx))
+    o = so.make_receivers(cfg, np.float32)[0]
+    want = np.concatenate([o.demod_data(x[k * L:(k + 1) * L]) for k in range(2 * B)])
+    am = np.concatenate(got)
+    assert am.shape == want.shape
+    assert all(s[0] >= 100 for s in stats), stats
+    if abs(f_off) <= 40.0:
+        assert all(s[1] <= 4 for s in stats), stats       # a locked loop needs (next to) no patching, jumps included
+    assert relerr(am[1024:], want[1024:]) <= TOL, (stats, relerr(am[1024:], want[1024:]))
+
+
+def test_two_am_synch_receivers_beside_other_modes_in_one_overlapped_context():
+    """Four sub-receivers on one stream, two of them AM-Synch (two carrier loops walk side by side: grid (K, nrx)),
+    in a batch context (the facade's default: calls overlapped, tails deferred): every sub-receiver's audio against
+    the oracle chunk by chunk, three calls, results fetched only after the last two."""
+    cfg = dict(so.CONFIGS['C3'])
+    cfg['rx'] = [dict(frq=-1.2e6 + 4.0, mode='AM-Synch', video_bw=10e3, af_bw=5e3),
+                 dict(frq=455e3, mode='NFM', video_bw=20e3, af_bw=4e3),
+                 dict(frq=-1.2e6 - 9.0, mode='AM-Synch', video_bw=10e3, af_bw=3e3),
+                 dict(frq=200e3, mode='USB', video_bw=10e3, af_bw=3e3)]
+    from tests.test_gpu_parity import make_gpu_receivers
+    B, K = 12, 3
+    L = so.chunk_sizes(cfg['fs'], 48e3)[3]
+    x = so.synth_iq(cfg, K * B * L, 23)
+    P, g = make_gpu_receivers(cfg, max_batch_chunks=B)
+    ctx = P._pysdr_stream
+    assert _lib.lib().pysdr_get_overlap(ctx.h) == 1
+    outs = []
+    for k in range(K):
+        ctx.process_batch(x[k * B * L:(k + 1) * B * L], B, L, on_device=False)
+        assert _lib.lib().pysdr_last_call_overlapped(ctx.h) == 1
+        if k >= 1:
+            outs.append([ctx.fetch(i, B)[0].copy() for i in range(4)])
+    orx = so.make_receivers(cfg, np.float32)
+    want = [np.concatenate([o.demod_data(x[j * L:(j + 1) * L]) for j in range(K * B)]) for o in orx]
+    for i in range(4):
+        n1 = len(outs[0][i])
+        w = want[i][len(want[i]) - 2 * n1:] if len(outs[1][i]) == n1 else None
+        got = np.concatenate([outs[0][i], outs[1][i]])
+        w = want[i][len(want[i]) - len(got):]
+        assert relerr(got, w) <= TOL, (i, cfg['rx'][i]['mode'], relerr(got, w))
+
+
 def test_full_size_c4_time_parallel_equals_the_serial_walk():
     """BASELINE config #4 at the size and in the way bench.py times it: 2048 chunks x 213333 samples
     (3.5 GB) resident in HBM, three consecutive calls of ONE continuous broadcast-FM stream (call k
