@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpysdr_hip.so")
 LIB_DIAG = os.path.join(HERE, "libpysdr_hip_diag.so")   # loaded only when PYSDR_USE_DIAG_LIB=1
-SOURCES = ["api.hip", "mixdec.hip", "mixdec_mfma.hip", "resamp_small.hip", "stage2.hip", "misc.hip", "psdfft.hip", "waterfall.hip"]
+SOURCES = ["api.hip", "mixdec.hip", "mixdec_mfma.hip", "resamp_small.hip", "stage2.hip", "pllseed.hip", "misc.hip", "psdfft.hip", "waterfall.hip"]
 # Flags every build uses (measured choices, part of the shipped configuration):
 #   stage2.hip   -fno-slp-vectorize: packed-f32 pairs built by the SLP vectoriser run at half rate on gfx950 and are fed
 #                by v_mov shuffles; the AF FIR is written for plain FMAs with its own v_pk_fma_f32
@@ -32,7 +32,7 @@ BASE_FLAGS = {"stage2.hip": ["-fno-slp-vectorize"],
 # the work-skipping ablation switches compile only with -DPYSDR_ABLATE, which only --diag defines (common.h).
 FLAG_VARS = {"mixdec.hip": "PYSDR_MIXDEC_FLAGS", "mixdec_mfma.hip": "PYSDR_MFMA_FLAGS", "resamp_small.hip": "PYSDR_RESAMP_FLAGS",
              "api.hip": "PYSDR_API_FLAGS",        # a shape's S / NB enter the host's plan: pass the same -D to both
-             "stage2.hip": "PYSDR_STAGE2_FLAGS", "psdfft.hip": "PYSDR_PSD_FLAGS"}
+             "stage2.hip": "PYSDR_STAGE2_FLAGS", "pllseed.hip": "PYSDR_SEED_FLAGS", "psdfft.hip": "PYSDR_PSD_FLAGS"}
 
 
 def extra_flags(diag=False):
@@ -63,7 +63,7 @@ def flags_for(src, extra):
 
 
 # (tests/test_isa_checks.py compiles with these: the flags of the shipped build)
-EXTRA_FLAGS = {src: flags_for(src, {}) for src in ("api.hip", "mixdec.hip", "mixdec_mfma.hip", "resamp_small.hip", "stage2.hip", "misc.hip", "psdfft.hip", "waterfall.hip")}
+EXTRA_FLAGS = {src: flags_for(src, {}) for src in SOURCES}
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 

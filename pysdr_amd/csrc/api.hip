@@ -117,6 +117,8 @@ struct RxHost {
   float2* d_y1_alt = nullptr;      // its pair (pysdr_set_overlap)
   float2* d_w = nullptr;           // [m1max] composite * (1 + 2j sin 2theta)
   float2* d_w_alt = nullptr;       // its pair (pysdr_set_overlap)
+  double* d_seed = nullptr;        // WFM2: scan buffers of the pilot loop's Newton-in-time seeds (pllseed.hip), allocated on first stereo use
+  float* d_mnt[2] = {nullptr, nullptr};   // ... and mpx * norm in the seed kernels' order, written by the discriminator: a pair like d_w
 };
 
 // What one pysdr_process_batch call uses of the receivers' host-side state.  Taken under
@@ -130,6 +132,8 @@ struct RxSnap {
   int taps_real = 0;
   float2 *d_y = nullptr, *d_ypll = nullptr, *d_a = nullptr, *d_y1 = nullptr, *d_w = nullptr;   // d_y / d_ypll / d_y1 / d_w: THIS call's buffer of each pair
   float2 *d_y_next = nullptr, *d_ypll_next = nullptr, *d_y1_next = nullptr;   // the next call's (the same one unless the calls overlap): gets the history prefix
+  double* d_seed = nullptr;
+  float* d_mnt = nullptr;
   float* d_am = nullptr;
   float2* d_aftaps = nullptr;
 };
@@ -249,6 +253,10 @@ struct pysdr_ctx {
   double wfm_taus_hi = 0.0, wfm_taus_mid = 0.0;   // staged coarse warm-up (PllPlan::Wc_hi / Wc_mid) in time constants; 0, 0: one stage
   int wfm_tail_cap = 0;                // sweeps per block of the exact tail of a warm-up (0: wfm_exact_cap)
   int wfm_exact_cap = 5;               // sweeps per block of the pilot loop's exact walks (0: to the bit-stable fixed point)
+  // Round 5: the segments of the pilot loop start from Newton-in-time seeds (pllseed.hip; two linearised passes over the call by
+  // parallel scans of affine maps: within ~30 words of 2^32 of the exact walk) instead of a 13-tau warm-up, whenever the previous
+  // call left a mean phase increment; PYSDR_WFM_SEED="0" switches it off, "1,n" walks n samples from the seed first (A/B)
+  int wfm_seeded = 1, wfm_wseed = 0;
   int profile = 0;
   static constexpr int kSlots = 64;       // ring of per-call event sets (profiling)
   hipEvent_t ev[kSlots][4] = {};
@@ -586,6 +594,7 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
     const RxHost& x = c->rx[r];
     dirty |= x.taps_dirty || x.af_dirty || x.agc_dirty || x.reset_pending != 0 || (is_wfm(x.mode) && x.wfm_dirty) ||
              (x.mode == PYSDR_AM_SYNCH && (x.d_ypll == nullptr || (need_alt && x.d_ypll_alt == nullptr))) ||
+             (x.mode == PYSDR_WFM2 && x.d_seed == nullptr && c->wfm_seeded) ||
              (need_alt && (x.d_y_alt == nullptr || (x.d_y1 != nullptr && x.d_y1_alt == nullptr)));
   }
   if (dirty) {
@@ -667,6 +676,13 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
       x.agc_dirty = false;
     }
+    if (x.mode == PYSDR_WFM2 && x.d_seed == nullptr && c->wfm_seeded && c->m1max > 0) {
+      PYSDR_HIP_CHECK(hipMalloc(&x.d_seed, pll_seed_doubles(c->m1max) * sizeof(double)));
+      for (int i = 0; i < 2; ++i) {
+        PYSDR_HIP_CHECK(hipMalloc(&x.d_mnt[i], pll_seed_mnt_floats(c->m1max) * sizeof(float)));
+        PYSDR_HIP_CHECK(hipMemsetAsync(x.d_mnt[i], 0, pll_seed_mnt_floats(c->m1max) * sizeof(float), c->stream));
+      }
+    }
     if (x.mode == PYSDR_AM_SYNCH && x.d_ypll == nullptr) {
       const size_t n = (size_t)c->hy + c->mmax;
       PYSDR_HIP_CHECK(hipMalloc(&x.d_ypll, n * sizeof(float2)));
@@ -696,6 +712,8 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
     q.mode = x.mode; q.fword = x.fword; q.phase = x.phase; q.bfo_fword = x.bfo_fword;
     q.sq_thresh = x.sq_thresh; q.taps_real = x.taps_real;
     q.d_a = x.d_a; q.d_am = x.d_am; q.d_aftaps = x.d_aftaps;
+    q.d_seed = x.d_seed;
+    q.d_mnt = x.d_mnt[c->par];
     // this call's buffer of each pair and the next call's (the other one when the calls overlap)
     const int p = c->par, pn = snap->use2 ? (p ^ 1) : p;
     q.d_y = p ? x.d_y_alt : x.d_y;
@@ -878,6 +896,8 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
       if (nf >= 5 && tm >= 64) c->am_tmin = (tm + 63) & ~63;
     } }
   { const char* e = tuning_env("PYSDR_MIXDEC_MFMA"); if (e && *e) c->mfma_enable = atoi(e) ? 1 : 0; }
+  { const char* e = tuning_env("PYSDR_WFM_SEED");
+    if (e && *e) { int on = 1, ws = 0; const int nf = sscanf(e, "%d,%d", &on, &ws); if (nf >= 1) c->wfm_seeded = on ? 1 : 0; if (nf >= 2 && ws >= 0) c->wfm_wseed = ws; } }
   { const char* e = tuning_env("PYSDR_OVERLAP_ORDER"); if (e && *e) c->tail_first = atoi(e); }
   { const char* e = tuning_env("PYSDR_OVERLAP"); if (e && *e) c->overlap_env = std::max(0, std::min(2, atoi(e))); }
   { const char* e = tuning_env("PYSDR_RESAMP_PLAIN"); if (e && *e) c->resamp_plain = atoi(e); }
@@ -957,6 +977,8 @@ void pysdr_destroy(pysdr_ctx* c) {
     if (x.d_y1_alt) (void)hipFree(x.d_y1_alt);
     if (x.d_ypll_alt) (void)hipFree(x.d_ypll_alt);
     if (x.d_w_alt) (void)hipFree(x.d_w_alt);
+    if (x.d_seed) (void)hipFree(x.d_seed);
+    for (int i = 0; i < 2; ++i) if (x.d_mnt[i]) (void)hipFree(x.d_mnt[i]);
     if (x.d_ypll) (void)hipFree(x.d_ypll);
     if (x.d_a) (void)hipFree(x.d_a);
     if (x.d_am) (void)hipFree(x.d_am);
@@ -1375,6 +1397,8 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
       w.y1dst[r] = snap.rx[r].d_y1_next;
       w.w[r] = snap.rx[r].d_w;
       w.stereo[r] = (snap.rx[r].mode == PYSDR_WFM2) ? 1 : 0;
+      w.seed[r] = snap.rx[r].d_seed;
+      w.mnT[r] = (snap.rx[r].mode == PYSDR_WFM2) ? snap.rx[r].d_mnt : nullptr;
     }
     w.state = c->d_state;
     // measured (scripts/experiments/pll_warmup.py), words of 2^32 left of a wrong start state: from
@@ -1385,6 +1409,8 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
                      c->pll_kmax > 0 ? std::min(c->pll_kmax, c->wfm_kmax) : c->wfm_kmax, c->d_pllseg);
     w.pll.exact_cap = c->wfm_exact_cap;
     w.pll.tail_cap = c->wfm_tail_cap;
+    w.pll.seeded = (c->wfm_seeded && w.pll.K > 1) ? 1 : 0;
+    w.pll.Wseed = (std::max(0, c->wfm_wseed) + 63) & ~63;
     if (c->wfm_coarse_sweeps > 0 && w.pll.K > 1) {
       const double tau = fs1 / (kPllZetaPlan * 2.0 * M_PI * kWfmPllBwHz);
       w.pll.Wexact = ((int)std::ceil(c->wfm_taus_exact * tau) + 63) & ~63;

@@ -217,6 +217,9 @@ struct PllPlan {
   int coarse_sweeps;
   int Wc_hi, Wc_mid;        // staged coarse part (0, 0: all of it at coarse_sweeps): the Wc_hi samples in front of the exact tail get
                             // coarse_sweeps, the Wc_mid samples in front of those coarse_sweeps - 1, whatever lies before coarse_sweeps - 2 (>= 1)
+  int seeded;               // pilot loop: segments start from the Newton-in-time seeds (pllseed.hip) instead of a warm-up, whenever the
+                            // previous call left a mean phase increment (state.wfm_slope_ok); the check pass still judges every join
+  int Wseed;                // ... after walking this many samples in front of the segment from the seed (0; a multiple of 64)
   int tail_cap;             // sweeps per block of the exact TAIL of a warm-up (0: exact_cap)
   int exact_cap;            // sweeps per block of the "exact" walks (pilot loop; 0: until a sweep reproduces its input bit for bit)
   uint32_t* seg;            // [nrx][K][4]: S.phase, S.w, E.phase, E.w (float fields as bits)
@@ -282,13 +285,25 @@ struct WfmArgs {
   float2* y1dst[PYSDR_MAX_RX];        // buffer start of the NEXT call's IF buffer (= y1base unless the calls overlap): gets the prefix
   float2* w[PYSDR_MAX_RX];            // out: mpx*(1 + 2j*sin(2*theta)) (WFM: imag 0)
   int stereo[PYSDR_MAX_RX];
+  double* seed[PYSDR_MAX_RX];         // scan buffers of the Newton-in-time seeds (pll_seed_doubles(m1max) doubles; may be null)
+  float* mnT[PYSDR_MAX_RX];           // mpx * norm in the seed kernels' order (pll_seed_index: sample j of lane l of wave v at
+                                      // (v * 32 + j) * 64 + l), written by the discriminator kernel; null: no seeds
   RxDevState* state;
   PllPlan pll;                        // pilot PLL segmentation of this call
   int pll_pass;                       // 0: first pass over the segments, 1: the redo pass (only if state.wfm_redo)
 };
 int launch_wfm_disc(const WfmArgs& a, hipStream_t st);      // polar discriminator + the IF buffer's 1-sample history
 bool wfm_any_stereo(const WfmArgs& a);
-int launch_wfm_pll(const WfmArgs& a, hipStream_t st);       // the pilot loop's segment walks, check and patch-up passes
+int launch_wfm_pll(const WfmArgs& a, hipStream_t st);       // the pilot loop's (seeds,) segment walks, check and patch-up passes
+size_t pll_seed_doubles(int n1max);                         // pllseed.hip: doubles of scan buffer per RX
+inline size_t pll_seed_mnt_floats(int n1max) { return (((size_t)n1max + 2047) / 2048) * 2048; }
+// where sample i of a call sits in mnT: a lane of the seed kernels owns 32 consecutive samples, a wave 64 lanes; the lanes'
+// j-th samples lie side by side, so that the kernels read them coalesced WITHOUT staging through LDS (which cannot be had
+// beside the persistent front end of the next call: even 8 KB per workgroup waited for it to end)
+constexpr size_t pll_seed_index(int i) {     // (constexpr: usable from host and device code alike)
+  return ((size_t)(i >> 11) * 32 + (size_t)(i & 31)) * 64 + (size_t)((i >> 5) & 63);
+}
+int launch_wfm_seed(const WfmArgs& a, hipStream_t st);      // segment start states by two Newton passes over the whole call
 
 // ---- misc kernels (misc.hip) ---------------------------------------------------------
 int launch_quad_mixer(const float2* x, float2* y, size_t n, uint32_t phase0, uint32_t fword,

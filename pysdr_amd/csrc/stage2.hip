@@ -924,7 +924,9 @@ __global__ __launch_bounds__(256) void wfm_disc_kernel(const WfmArgs a) {
   if (i == a.n1 - 1) a.y1dst[r][1] = yb;
   const float re = yb.x * ya.x + yb.y * ya.y;
   const float im = yb.y * ya.x - yb.x * ya.y;
-  a.w[r][i] = make_float2(atan2f(im, re) * a.scale, 0.f);
+  const float mpx = atan2f(im, re) * a.scale;
+  a.w[r][i] = make_float2(mpx, 0.f);
+  if (a.mnT[r] != nullptr) a.mnT[r][pll_seed_index(i)] = __fmul_rn(mpx, a.norm);     // the seed kernels' copy (pllseed.hip)
 }
 
 // 19 kHz pilot PLL of the stereo decoder: a recursion through cos of its own phase
@@ -1042,8 +1044,15 @@ __global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
   float w = st->wfm_w;
   const bool fast = pl.Wfast > 0 && st->wfm_slope_ok;
   const int xcap = pl.exact_cap > 0 ? pl.exact_cap : 66;
-  int wb = s0 - (fast ? pl.Wfast : pl.W);
-  if (k > 0 && wb > 0) {
+  const bool seeded = pl.seeded && a.pll_pass == 0 && st->wfm_slope_ok && a.seed[r] != nullptr && k > 0 && s0 - pl.Wseed > 0;
+  int wb = seeded ? s0 - pl.Wseed : s0 - (fast ? pl.Wfast : pl.W);
+  if (seeded) {
+    // the loop's state in front of sample wb from two Newton passes over the whole call (pllseed.hip): within ~30 words of
+    // 2^32 of where the exact walk would be, so there is (next to) nothing to forget
+    const uint32_t* sd = pl.seg + ((size_t)r * pl.K + k) * 4;
+    ph = sd[0];
+    w = __uint_as_float(sd[1]);
+  } else if (k > 0 && wb > 0) {
     if (fast) {
       // guess: the call's initial phase carried forward at the MEAN increment of the previous call
       // (a locked loop follows the station's crystal: a straight line plus a bounded wobble, off by
@@ -1059,7 +1068,9 @@ __global__ __launch_bounds__(64) void wfm_pll_seg_kernel(const WfmArgs a) {
   } else {
     wb = 0;
   }
-  if (wb < s0) {
+  if (seeded) {
+    if (wb < s0) wfm_pll_walk<false>(a, a.w[r], wb, s0, ph, w, lane, xcap);
+  } else if (wb < s0) {
     // coarse sweeps first, the last Wexact samples exactly (both bounds on multiples of 64)
     const int sx = (pl.coarse_sweeps > 0 && s0 - pl.Wexact > wb) ? s0 - pl.Wexact : wb;
     if (wb < sx) {
@@ -1097,7 +1108,7 @@ __global__ __launch_bounds__(64) void wfm_pll_check_kernel(const WfmArgs a) {
   int redo = 0;
   int jw = 0;
   float jd = 0.f;
-  if (pl.Wfast > 0 && st->wfm_slope_ok && pl.K > 1) {
+  if ((pl.Wfast > 0 || pl.seeded) && st->wfm_slope_ok && pl.K > 1) {
     const uint32_t* sg = pl.seg + (size_t)r * pl.K * 4;
     int miss = 0;
     // eight joins per lane in flight (one load round trip per 512 joins instead of per 64: this wave is alone on the stream)
@@ -1324,9 +1335,13 @@ int launch_wfm_pll(const WfmArgs& a, hipStream_t st) {
   bool any_stereo = false;
   for (int r = 0; r < a.nrx; ++r) any_stereo |= (a.stereo[r] != 0);
   if (any_stereo && a.n1 > 0) {
+    if (a.pll.seeded && a.pll.K > 1) {
+      const int rc = launch_wfm_seed(a, st);
+      if (rc) return rc;
+    }
     hipLaunchKernelGGL(wfm_pll_seg_kernel, dim3(a.pll.K, a.nrx), dim3(64), 0, st, a);
     PYSDR_HIP_CHECK(hipGetLastError());
-    if (a.pll.Wfast > 0 && a.pll.K > 1) {
+    if ((a.pll.Wfast > 0 || a.pll.seeded) && a.pll.K > 1) {
       hipLaunchKernelGGL(wfm_pll_check_kernel, dim3(a.nrx), dim3(64), 0, st, a);
       PYSDR_HIP_CHECK(hipGetLastError());
       WfmArgs b = a;

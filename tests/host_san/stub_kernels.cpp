@@ -339,9 +339,27 @@ int launch_wfm_disc(const WfmArgs& a, hipStream_t) {
     SAN_CHECK(a.y1[r] == a.y1base[r] + 2, "IF buffer layout");
     read_all(a.y1[r] - 1, (size_t)a.n1 + 1);
     write_all(a.w[r], (size_t)a.n1);
+    if (a.mnT[r] != nullptr)                                 // the seed kernels' copy: every sample of the call lands inside the padded buffer
+      for (int i = 0; i < a.n1; i += (a.n1 > 4096 ? 997 : 1)) { SAN_CHECK(pll_seed_index(i) < pll_seed_mnt_floats(a.n1), "mnT index of sample %d", i); a.mnT[r][pll_seed_index(i)] = 0.f; }
     SAN_CHECK(a.y1dst[r] != nullptr, "IF prefix destination");
     if (a.n1 > 0) a.y1dst[r][1] = a.y1[r][a.n1 - 1];
   }
+  return PYSDR_OK;
+}
+
+size_t pll_seed_doubles(int n1max) {
+  const size_t nlanes = ((size_t)n1max + 31) / 32, nwaves = (nlanes + 63) / 64;
+  return nlanes * 6 + nwaves * 6 + nwaves * 2 + nlanes * 2;
+}
+
+int launch_wfm_seed(const WfmArgs& a, hipStream_t) {
+  // pllseed.hip: a lane per 32 samples, a wave per 2048; the scan buffers of a stereo RX hold both levels and pass 1's states
+  for (int r = 0; r < a.nrx; ++r)
+    if (a.stereo[r] && a.seed[r] != nullptr && a.mnT[r] != nullptr) {
+      read_all(a.mnT[r], pll_seed_mnt_floats(a.n1));
+      write_all(a.seed[r], pll_seed_doubles(a.n1));
+      SAN_CHECK(a.pll.T % 32 == 0 && a.pll.Wseed % 64 == 0 && a.pll.Wseed >= 0, "seed plan T %d Wseed %d", a.pll.T, a.pll.Wseed);
+    }
   return PYSDR_OK;
 }
 
@@ -351,8 +369,9 @@ bool wfm_any_stereo(const WfmArgs& a) {
   return any && a.n1 > 0;
 }
 
-int launch_wfm_pll(const WfmArgs& a, hipStream_t) {
+int launch_wfm_pll(const WfmArgs& a, hipStream_t st) {
   check_plan(a.pll, a.n1, a.nrx);
+  if (a.pll.seeded && a.pll.K > 1) { const int rc = launch_wfm_seed(a, st); if (rc) return rc; }
   for (int r = 0; r < a.nrx; ++r)
     if (a.stereo[r]) { read_all(a.w[r], (size_t)a.n1); write_all(a.w[r], (size_t)a.n1); }
   read_all(a.state, (size_t)a.nrx);

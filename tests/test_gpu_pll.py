@@ -301,6 +301,39 @@ def test_two_am_synch_receivers_beside_other_modes_in_one_overlapped_context():
         assert relerr(got, w) <= TOL, (i, cfg['rx'][i]['mode'], relerr(got, w))
 
 
+def test_wfm2_newton_seeds_equal_the_warm_ups_and_the_serial_oracle(monkeypatch):
+    """Round 5: from the second call of a continuous stream on, the pilot loop's segments start from Newton-in-time seeds
+    (pllseed.hip: two linearised passes over the whole call by parallel scans of affine maps) instead of walking 13 time
+    constants of warm-up.  The seeds are a starting point, not an answer -- the segments walk their samples exactly and the
+    check kernel judges every join -- so the audio must equal (i) the same build with the seeds switched off
+    (PYSDR_WFM_SEED=0: the warm-ups of round 4) within the parity bar and (ii) the serial oracle; the seeded joins are held
+    to a quarter of the tolerance the check kernel applies (measured 42-56 words of 512)."""
+    L, B = 213333, 24
+    x = wo.synth_wfm(10e6, 3 * B * L, 9)
+
+    def run():
+        P, g, ctx = wfm_gpu(B)
+        out, marg = [], []
+        for k in range(3):
+            ctx.process_batch(x[k * B * L:(k + 1) * B * L], B, L, on_device=False)
+            out.append(ctx.fetch(0, B)[0].copy())
+            jw, jd = C.c_int(0), C.c_float(0)
+            _lib.check(_lib.lib().pysdr_pll_join_margin(ctx.h, 0, C.byref(jw), C.byref(jd)), "pll_join_margin")
+            marg.append((jw.value, jd.value, pll_stats(ctx)))
+        ctx.close()
+        return np.concatenate(out), marg
+    seeded, m1 = run()
+    monkeypatch.setenv("PYSDR_TUNING", "1")
+    monkeypatch.setenv("PYSDR_WFM_SEED", "0")
+    warm, m0 = run()
+    assert all(s[2][0] > 32 and s[2][1] <= 2 for s in m1 + m0), (m1, m0)
+    # calls 2 and 3 are the seeded ones (the first has no mean increment to linearise around)
+    assert all(jw <= 128 and jd <= 2.5e-10 for jw, jd, _ in m1[1:]), m1
+    assert relerr(seeded, warm) <= TOL
+    want = wfm_oracle_run(x, 3 * B, L)
+    assert relerr(seeded, want) <= TOL
+
+
 def test_full_size_c4_time_parallel_equals_the_serial_walk():
     """BASELINE config #4 at the size and in the way bench.py times it: 2048 chunks x 213333 samples
     (3.5 GB) resident in HBM, three consecutive calls of ONE continuous broadcast-FM stream (call k
