@@ -287,7 +287,7 @@ struct WfmArgs {
   int stereo[PYSDR_MAX_RX];
   double* seed[PYSDR_MAX_RX];         // scan buffers of the Newton-in-time seeds (pll_seed_doubles(m1max) doubles; may be null)
   float* mnT[PYSDR_MAX_RX];           // mpx * norm in the seed kernels' order (pll_seed_index: sample j of lane l of wave v at
-                                      // (v * 32 + j) * 64 + l), written by the discriminator kernel; null: no seeds
+                                      // (v * kSeedRun + j) * 64 + l), written by the discriminator kernel; null: no seeds
   RxDevState* state;
   PllPlan pll;                        // pilot PLL segmentation of this call
   int pll_pass;                       // 0: first pass over the segments, 1: the redo pass (only if state.wfm_redo)
@@ -296,12 +296,14 @@ int launch_wfm_disc(const WfmArgs& a, hipStream_t st);      // polar discriminat
 bool wfm_any_stereo(const WfmArgs& a);
 int launch_wfm_pll(const WfmArgs& a, hipStream_t st);       // the pilot loop's (seeds,) segment walks, check and patch-up passes
 size_t pll_seed_doubles(int n1max);                         // pllseed.hip: doubles of scan buffer per RX
-inline size_t pll_seed_mnt_floats(int n1max) { return (((size_t)n1max + 2047) / 2048) * 2048; }
-// where sample i of a call sits in mnT: a lane of the seed kernels owns 32 consecutive samples, a wave 64 lanes; the lanes'
-// j-th samples lie side by side, so that the kernels read them coalesced WITHOUT staging through LDS (which cannot be had
-// beside the persistent front end of the next call: even 8 KB per workgroup waited for it to end)
+// A lane of the seed kernels owns kSeedRun = 64 consecutive samples (every segment length is a multiple of 64: a segment
+// starts a lane), a wave 64 lanes = a tile of 4096 samples.  Where sample i of a call sits in mnT: the lanes' j-th samples lie
+// side by side, so that the kernels read them coalesced WITHOUT staging through LDS (which cannot be had beside the
+// persistent front end of the next call: even 8 KB per workgroup waited for it to end).
+constexpr int kSeedRun = 64, kSeedTile = 64 * kSeedRun;
+inline size_t pll_seed_mnt_floats(int n1max) { return (((size_t)n1max + kSeedTile - 1) / kSeedTile) * kSeedTile; }
 constexpr size_t pll_seed_index(int i) {     // (constexpr: usable from host and device code alike)
-  return ((size_t)(i >> 11) * 32 + (size_t)(i & 31)) * 64 + (size_t)((i >> 5) & 63);
+  return ((size_t)(i / kSeedTile) * kSeedRun + (size_t)(i % kSeedRun)) * 64 + (size_t)((i / kSeedRun) % 64);
 }
 int launch_wfm_seed(const WfmArgs& a, hipStream_t st);      // segment start states by two Newton passes over the whole call
 

@@ -21,7 +21,7 @@
 // kernel still holds every join against the tolerance, and a call whose seeds miss (no lock, a discontinuous stream) is
 // redone with the long warm-ups exactly as before -- what changes is that a locked loop no longer pays for them.
 //
-// Scan layout: a lane owns R = 32 consecutive samples and composes their maps in registers (fp64: the products of
+// Scan layout: a lane owns R = 64 consecutive samples and composes their maps in registers (fp64: the products of
 // thousands of near-identity maps must not lose the 1e-9 the integrator is held to); 64 lanes scan their maps by
 // shuffles; a one-workgroup kernel scans the per-wave maps of the call; the next pass (or the finish kernel) applies
 // prefix-of-waves and prefix-in-wave to get the state at its own first sample.  cos / sin are the same v_cos / v_sin of
@@ -42,7 +42,7 @@ typedef float sreal;                       // A/B: the maps in float32 (buffers 
 #else
 typedef double sreal;
 #endif
-constexpr int kSeedR = 32;                 // samples per lane (segments are multiples of 64 samples: a segment starts a lane)
+constexpr int kSeedR = kSeedRun;           // samples per lane (common.h: segments are multiples of 64 samples, so a segment starts a lane)
 constexpr double kWord2Rad = 6.283185307179586476925 / 4294967296.0;
 
 struct Aff {                                // x -> M x + v on (eps, W)
@@ -107,9 +107,9 @@ __device__ __forceinline__ void smap_apply(const SMap& f, double& e, double& w) 
   e = e2; w = w2;
 }
 
-// Seed buffer of one RX (doubles): [lmap: nlanes x 6][wmap: nwaves x 6][wstate: nwaves x 2][s1: nlanes x 2]
+// Seed buffer of one RX (doubles): [lmap: nlanes x 6][wmap: nwaves x 6][wstate: nwaves x 2][s1: nlanes x 2][tot: 16 x 6]
 struct SeedView {
-  double *lmap, *wmap, *wstate, *s1;
+  double *lmap, *wmap, *wstate, *s1, *tot;
   int nlanes, nwaves;
 };
 __device__ __forceinline__ SeedView seed_view(double* base, int n1) {
@@ -120,6 +120,7 @@ __device__ __forceinline__ SeedView seed_view(double* base, int n1) {
   v.wmap = v.lmap + (size_t)v.nlanes * 6;
   v.wstate = v.wmap + (size_t)v.nwaves * 6;
   v.s1 = v.wstate + (size_t)v.nwaves * 2;
+  v.tot = v.s1 + (size_t)v.nlanes * 2;                       // [16 x 6] totals of the scan kernel's waves
   return v;
 }
 
@@ -197,18 +198,21 @@ __global__ __launch_bounds__(256) void seed_reduce_kernel(const WfmArgs a) {
   if (lane == 63) aff_store(sv.wmap + (size_t)wave * 6, inc_map);
 }
 
-// grid (nrx), ONE wave, no LDS (beside the next call's front end not even 192 bytes of it can be had): the state in front of
-// every wave of the reduce kernels = (maps of the waves before it)(state of the call's first sample).  Lane t owns a
-// contiguous run of waves; the 64 run maps are scanned by shuffles.
-__global__ __launch_bounds__(64) void seed_scan_kernel(const WfmArgs a) {
-  const int r = blockIdx.x, lane = threadIdx.x;
+// grid (nrx), 256 threads = one wave per SIMD, no LDS: the state in front of every wave of the reduce kernels = (maps of the
+// waves before it)(state of the call's first sample).  (What could run beside the next call's front end decided the shape:
+// not even 192 bytes of LDS can be had there; one wave over all the maps took 44 us alone and 300 beside it; sixteen waves
+// need four wave slots AND 4 x 44 registers per SIMD, which the front end's four waves of 101 do not leave -- that
+// workgroup waited for the front end to end.)  Thread t owns a contiguous run of wave maps; each wave scans its
+// 64 runs by shuffles and leaves its total in global scratch; behind ONE barrier every wave composes the totals in front of it.
+__global__ __launch_bounds__(256) void seed_scan_kernel(const WfmArgs a) {
+  const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   if (!a.stereo[r] || a.seed[r] == nullptr) return;
   const RxDevState* st = a.state + r;
   if (!st->wfm_slope_ok) return;
   __builtin_amdgcn_s_setprio(SEEDX_PRIO);
   const SeedView sv = seed_view(a.seed[r], a.n1);
-  const int per = (sv.nwaves + 63) / 64;
-  const int w_lo = lane * per, w_hi = (w_lo + per < sv.nwaves) ? w_lo + per : sv.nwaves;
+  const int per = (sv.nwaves + 255) / 256;
+  const int w_lo = t * per, w_hi = (w_lo + per < sv.nwaves) ? w_lo + per : sv.nwaves;
   Aff run = aff_identity();
   for (int w = w_lo; w < w_hi; ++w) run = aff_then(run, aff_load(sv.wmap + (size_t)w * 6));
   Aff inc_map = run;
@@ -219,9 +223,13 @@ __global__ __launch_bounds__(64) void seed_scan_kernel(const WfmArgs a) {
   }
   Aff exc = aff_shfl_up(inc_map, 1);
   if (lane == 0) exc = aff_identity();
-  // exclusive prefix of this lane's run applied to the call's initial state: eps = 0 (the guess starts ON the true phase),
-  // W = the integrator in words per sample
+  if (lane == 63) aff_store(sv.tot + wv * 6, inc_map);
+  __threadfence_block();
+  __syncthreads();
+  // the call's initial state: eps = 0 (the guess starts ON the true phase), W = the integrator in words per sample;
+  // then the totals of the waves in front, then the runs in front inside the wave
   double e = 0.0, w = (double)st->wfm_w * (double)a.rad2word;
+  for (int k = 0; k < wv; ++k) aff_apply(aff_load(sv.tot + k * 6), e, w);
   aff_apply(exc, e, w);
   for (int k = w_lo; k < w_hi; ++k) {
     sv.wstate[(size_t)k * 2 + 0] = e;
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(256) void seed_finish_kernel(const WfmArgs a) {
 
 size_t pll_seed_doubles(int n1max) {
   const size_t nlanes = ((size_t)n1max + kSeedR - 1) / kSeedR, nwaves = (nlanes + 63) / 64;
-  return nlanes * 6 + nwaves * 6 + nwaves * 2 + nlanes * 2;
+  return nlanes * 6 + nwaves * 6 + nwaves * 2 + nlanes * 2 + 16 * 6;
 }
 
 // The five launches that turn (initial state, mean increment of the previous call, mpx) into the segments' start states.
@@ -265,11 +273,11 @@ int launch_wfm_seed(const WfmArgs& a, hipStream_t st) {
   const dim3 gr((nwaves + 3) / 4, a.nrx);
   hipLaunchKernelGGL(seed_reduce_kernel<1>, gr, dim3(256), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(seed_scan_kernel, dim3(a.nrx), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(seed_scan_kernel, dim3(a.nrx), dim3(256), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(seed_reduce_kernel<2>, gr, dim3(256), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(seed_scan_kernel, dim3(a.nrx), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(seed_scan_kernel, dim3(a.nrx), dim3(256), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(seed_finish_kernel, dim3((a.pll.K + 255) / 256, a.nrx), dim3(256), 0, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());

@@ -913,20 +913,42 @@ __global__ __launch_bounds__(256) void hist_roll_kernel(const float2* __restrict
 
 // ---- broadcast FM at the IF rate: polar discriminator (all lanes), then the 19 kHz pilot
 // PLL of WFM2 -- inherently serial, one lane per RX, on a 32-bit phase accumulator.
+// grid (ceil(n1 / 4096), nrx): a workgroup takes a tile of kSeedTile = 4096 samples, sixteen per thread 256 apart.  For a
+// stereo RX whose pilot loop is seeded (pllseed.hip) it also leaves mpx * norm in the seed kernels' order -- sample j of lane l
+// of the tile at j * 64 + l, i.e. the tile transposed -- through LDS, so that both copies leave as whole lines (written straight
+// from the registers the transposed copy was 32 eight-byte pieces per wave store and doubled this kernel's time: 36 -> 73 us).
 __global__ __launch_bounds__(256) void wfm_disc_kernel(const WfmArgs a) {
-  const int r = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n1) return;
-  // (nontemporal loads here measured 36.1-36.6 us against 34.6-35.8: plain)
-  const float2 yb = a.y1[r][i], ya = a.y1[r][i - 1];
-  // the 1-sample IF history of the NEXT call (this kernel is the buffer's only reader; until round 5 the pilot loop's
-  // patch-up kernel rolled it, which tied the next call's discriminator to this call's pilot loop)
-  if (i == a.n1 - 1) a.y1dst[r][1] = yb;
-  const float re = yb.x * ya.x + yb.y * ya.y;
-  const float im = yb.y * ya.x - yb.x * ya.y;
-  const float mpx = atan2f(im, re) * a.scale;
-  a.w[r][i] = make_float2(mpx, 0.f);
-  if (a.mnT[r] != nullptr) a.mnT[r][pll_seed_index(i)] = __fmul_rn(mpx, a.norm);     // the seed kernels' copy (pllseed.hip)
+  __shared__ float tile[kSeedTile + kSeedTile / kSeedRun];       // one pad word per lane run: the 64 runs start on different banks
+  const int r = blockIdx.y, t = threadIdx.x;
+  const int base = blockIdx.x * kSeedTile;
+  const bool seed_copy = a.mnT[r] != nullptr;
+#pragma unroll 4
+  for (int q = 0; q < kSeedTile / 256; ++q) {
+    const int il = q * 256 + t, i = base + il;
+    float mn = 0.f;
+    if (i < a.n1) {
+      // (nontemporal loads here measured 36.1-36.6 us against 34.6-35.8: plain)
+      const float2 yb = a.y1[r][i], ya = a.y1[r][i - 1];
+      // the 1-sample IF history of the NEXT call (this kernel is the buffer's only reader; until round 5 the pilot loop's
+      // patch-up kernel rolled it, which tied the next call's discriminator to this call's pilot loop)
+      if (i == a.n1 - 1) a.y1dst[r][1] = yb;
+      const float re = yb.x * ya.x + yb.y * ya.y;
+      const float im = yb.y * ya.x - yb.x * ya.y;
+      const float mpx = atan2f(im, re) * a.scale;
+      a.w[r][i] = make_float2(mpx, 0.f);
+      mn = __fmul_rn(mpx, a.norm);
+    }
+    if (seed_copy) tile[il + il / kSeedRun] = mn;
+  }
+  if (!seed_copy) return;
+  __syncthreads();
+  float* __restrict__ out = a.mnT[r] + (size_t)blockIdx.x * kSeedTile;   // pll_seed_index(base + il) = tile start + (il % kSeedRun) * 64 + il / kSeedRun
+#pragma unroll 4
+  for (int q = 0; q < kSeedTile / 256; ++q) {
+    const int p = q * 256 + t;                                            // position in the transposed tile: j = p >> 6, lane = p & 63
+    const int il = (p & 63) * kSeedRun + (p >> 6);
+    out[p] = tile[il + il / kSeedRun];
+  }
 }
 
 // 19 kHz pilot PLL of the stereo decoder: a recursion through cos of its own phase
@@ -1319,7 +1341,7 @@ int launch_hist_roll(const float2* x, const float2* hist_old, float2* hist_new, 
 
 int launch_wfm_disc(const WfmArgs& a, hipStream_t st) {
   if (a.n1 > 0) {
-    hipLaunchKernelGGL(wfm_disc_kernel, dim3((a.n1 + 255) / 256, a.nrx), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wfm_disc_kernel, dim3((a.n1 + kSeedTile - 1) / kSeedTile, a.nrx), dim3(256), 0, st, a);
     PYSDR_HIP_CHECK(hipGetLastError());
   }
   return PYSDR_OK;

@@ -348,8 +348,8 @@ int launch_wfm_disc(const WfmArgs& a, hipStream_t) {
 }
 
 size_t pll_seed_doubles(int n1max) {
-  const size_t nlanes = ((size_t)n1max + 31) / 32, nwaves = (nlanes + 63) / 64;
-  return nlanes * 6 + nwaves * 6 + nwaves * 2 + nlanes * 2;
+  const size_t nlanes = ((size_t)n1max + kSeedRun - 1) / kSeedRun, nwaves = (nlanes + 63) / 64;
+  return nlanes * 6 + nwaves * 6 + nwaves * 2 + nlanes * 2 + 16 * 6;
 }
 
 int launch_wfm_seed(const WfmArgs& a, hipStream_t) {
@@ -358,7 +358,7 @@ int launch_wfm_seed(const WfmArgs& a, hipStream_t) {
     if (a.stereo[r] && a.seed[r] != nullptr && a.mnT[r] != nullptr) {
       read_all(a.mnT[r], pll_seed_mnt_floats(a.n1));
       write_all(a.seed[r], pll_seed_doubles(a.n1));
-      SAN_CHECK(a.pll.T % 32 == 0 && a.pll.Wseed % 64 == 0 && a.pll.Wseed >= 0, "seed plan T %d Wseed %d", a.pll.T, a.pll.Wseed);
+      SAN_CHECK(a.pll.T % kSeedRun == 0 && a.pll.Wseed % kSeedRun == 0 && a.pll.Wseed >= 0, "seed plan T %d Wseed %d", a.pll.T, a.pll.Wseed);
     }
   return PYSDR_OK;
 }
