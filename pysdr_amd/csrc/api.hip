@@ -227,7 +227,6 @@ struct pysdr_ctx {
   int grid_override = 0;               // PYSDR_MIXDEC_GRID: workgroups of the mix+decimate launches (tests: many tiles per workgroup in a small call)
   int resamp_plain = 0;                // PYSDR_RESAMP_PLAIN: the audio resampler of broadcast FM 0 = a wave per branch, taps in scalar registers (resamp_wave_kernel),
                                        // 1 = one output per thread (resamp_small_kernel), 2 = a half-wave per branch (resamp_branch_kernel) (A/B)
-  int fir_mfma = 0;                    // PYSDR_FIR_MFMA=1: the AF FIR on the matrix cores for AF_FILT_LEN 253-264 (measured slower: profiles/r05_fir_mfma.txt)
   int mfma_enable = 1;                 // long single-RX prototypes on the matrix cores (mixdec_mfma.hip); 0: VALU form (A/B)
   int dbg_flags = 0, yflush_cap = 0;      // tuning / diagnostic switches, read from the environment once
   // carrier-PLL segmentation (PYSDR_AM_PLL = "taus,taus_exact,coarse_sweeps,kmax,tmin" overrides for A/B runs): warm-up of 16
@@ -765,7 +764,6 @@ void fill_stage2(pysdr_ctx* c, const CallSnap& snap, bool wfm, int nchunks, size
   }
   s.blkpeak = c->d_blkpeak; s.gain = c->d_gain; s.state = c->d_state;
   s.blknoise = c->d_blknoise; s.blkcnt = c->d_blkcnt;
-  s.fir_mfma = c->fir_mfma;
 }
 
 // T: the tail of a call on `stream` -- for broadcast FM the audio resamplers first, then detector + AF FIR, the block
@@ -898,7 +896,6 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
       if (nf >= 5 && tm >= 64) c->am_tmin = (tm + 63) & ~63;
     } }
   { const char* e = tuning_env("PYSDR_MIXDEC_MFMA"); if (e && *e) c->mfma_enable = atoi(e) ? 1 : 0; }
-  { const char* e = tuning_env("PYSDR_FIR_MFMA"); if (e && *e) c->fir_mfma = atoi(e) ? 1 : 0; }
   { const char* e = tuning_env("PYSDR_WFM_SEED");
     if (e && *e) { int on = 1, ws = 0; const int nf = sscanf(e, "%d,%d", &on, &ws); if (nf >= 1) c->wfm_seeded = on ? 1 : 0; if (nf >= 2 && ws >= 0) c->wfm_wseed = ws; } }
   { const char* e = tuning_env("PYSDR_OVERLAP_ORDER"); if (e && *e) c->tail_first = atoi(e); }

@@ -243,7 +243,6 @@ struct Stage2Args {
   int fir_rx[PYSDR_MAX_RX];           // the FIR kernel's blockIdx.y -> RX (one launch per kind of product)
   uint32_t bfo_fword[PYSDR_MAX_RX];
   int single_block[PYSDR_MAX_RX];     // WFM: no AGC blocks, the whole call is block 0
-  int fir_mfma;                       // AF FIR on the matrix cores where its length allows (stage2.hip demod_fir_mfma_kernel); 0: packed FMAs (A/B)
   int single_spread;                  // power of two <= min(nchunks, 32): a single-block RX spreads its peak atomics over that many
                                       // accumulators (one address for every wave of the call serialised: 14 of C4's 73 us AF FIR)
   int matrix[PYSDR_MAX_RX];           // WFM2: (S, D) -> (S+D) + j(S-D) = L + jR

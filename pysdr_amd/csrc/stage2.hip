@@ -643,119 +643,10 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   fir_epilogue<CPLX>(a, r, det, i0, H, tid, sre, acc);
 }
 
-// ---- the same stage with the inner product on the matrix cores (round 5).  A 255-tap FIR at stride 1 is a dense
-// contraction once the taps are SHIFTED along the columns of the B operand (mixdec_mfma.hip does the same for the front end,
-// where the decimation leaves 45 % of the MACs useful; here it is 94 %): with the tile's outputs o = 128 i + 16 q + j
-// (i = row 0..15, q = column block 0..7, j = column 0..15) and the staged detector output S[o + H + 3] = d[o],
-//     y[o] = sum_t A[i][t] B[t][j],   A[i][t] = S[128 i + 16 q + 4 + t],   B[t][j] = c[H - 1 + j - t]   (0 outside the taps),
-// t = 0 .. H + 14: 70 k-steps of v_mfma_f32_16x16x4_f32 per 256 outputs for H = 264, each fed by ONE 4-byte LDS read per lane
-// -- rows 128 apart sit 132 words apart under the staging's padding (fir_pad), so the 16 rows x 4 k-lanes of a step fall on
-// 32 different banks twice over: no conflicts -- against B in registers (a lane's 70 taps, read once per workgroup).
-// f32 MFMA is an ordered chain of exact FMAs; the order in which an output's taps are summed depends on j, i.e. on the
-// output's ABSOLUTE index modulo 16: tiles are anchored there (par16), so batch == chunk by chunk stays bit for bit.
-// Per wave two column blocks = 140 (280, 560 for Re(c d), complex) MFMAs of 32 cycles where the packed-FMA form issued
-// 8448 FMAs per lane pair ...: MEASURED SLOWER -- C1's AF stage 48 -> 67 us, 6 RX 178 -> 309 us (profiles/r05_fir_mfma.txt): the f32 matrix rate equals the packed-FMA rate on this part, so only the LDS traffic could have paid, and it does not.  Off by default.  Only for H = 264 (AF_FILT_LEN 253-264:
-// the reference's 255); other lengths take the packed-FMA form.
-constexpr int kFirMfmaH = 264;
-constexpr int kFirMfmaSteps = (kFirMfmaH + 15 + 3) / 4;      // 70
-typedef float fm_f4 __attribute__((ext_vector_type(4)));
-
-// one 16 x 16 tile: column block Q of the workgroup's 2048 outputs.  lane: row i = lane & 15, k-lane kk = lane >> 4
-template <int KIND, bool TR, int Q>
-__device__ __forceinline__ void fir_mfma_tile(const float* __restrict__ sre, const float* __restrict__ sim,
-                                              const float (&Br)[kFirMfmaSteps], const float (&Bi)[TR ? 1 : kFirMfmaSteps],
-                                              int lane, float* __restrict__ ore, float* __restrict__ oim) {
-  const int i = lane & 15, kk = lane >> 4;
-  const float* pr = sre + 132 * i + kk;                      // fir_pad(128 i + x) = 132 i + fir_pad(x) for x < 512
-  const float* pi = sim + 132 * i + kk;
-  fm_f4 ar = {0.f, 0.f, 0.f, 0.f}, ai = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int st = 0; st < kFirMfmaSteps; ++st) {
-    constexpr int dummy = 0; (void)dummy;
-    const int x = 16 * Q + 4 + 4 * st;                       // compile time
-    const int off = x + 4 * (x >> 7);
-    const float dr = pr[off];
-    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(dr, Br[st], ar, 0, 0, 0);
-    if (KIND != kFirRealReal) {
-      const float di = pi[off];
-      if (!TR) ar = __builtin_amdgcn_mfma_f32_16x16x4f32(di, -Bi[st], ar, 0, 0, 0);
-      if (KIND == kFirCplx) {
-        ai = __builtin_amdgcn_mfma_f32_16x16x4f32(di, Br[st], ai, 0, 0, 0);
-        if (!TR) ai = __builtin_amdgcn_mfma_f32_16x16x4f32(dr, Bi[st], ai, 0, 0, 0);
-      }
-    }
-  }
-  // D[row 4 (lane >> 4) + v][column lane & 15] -> output 128 row + 16 Q + column, into the output stage
-  const int g = lane >> 4, j = lane & 15;
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int o = 128 * (4 * g + v) + 16 * Q + j;
-    ore[fir_pad(o)] = ar[v];
-    if (KIND == kFirCplx) oim[fir_pad(o)] = ai[v];
-  }
-}
-
-template <int KIND, bool TR>
-__global__ __launch_bounds__(256) void demod_fir_mfma_kernel(const Stage2Args a) {
-  extern __shared__ __attribute__((aligned(16))) float lds_f[];
-  constexpr bool CPLX = KIND == kFirCplx;
-  const int r = a.fir_rx[blockIdx.y];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int par = (int)(a.m0_lo & 15u);                    // tiles start at a multiple of 16 of the ABSOLUTE output index
-  const int i0 = blockIdx.x * kFirOut - par;
-  const int det = a.det[r];
-  const float2* y = (det == kDetPll) ? a.ypll[r] : a.y[r];
-  constexpr int H = kFirMfmaH;
-  const int E = kFirOut + H + 12;                          // staged elements: S[e] = d[i0 - H + e - 3]
-  const int EP = (fir_pad(E) + 3) & ~3;
-  constexpr int OP = (fir_pad(kFirOut) + 3) & ~3;
-  float* sre = lds_f;                                      // [EP]
-  float* sim = lds_f + EP;                                 // [EP]
-  float* tre = lds_f + 2 * EP;                             // [H + 32]: tre[16 + k] = Re c[k], zero for 16 on either side
-  float* tim = tre + H + 32;                               // [H + 32]
-  float* ore = tim + H + 32;                               // [OP] (+ [OP] imaginary parts)
-  float* oim = ore + OP;
-  const float2* taps = a.aftaps[r];
-#pragma unroll 5
-  for (int e = tid; e < E; e += 256) {
-    const int i = i0 - H + e - 3;
-    const float2 d = (i >= -a.hy + 2) ? detect(a, r, det, y, i) : make_float2(0.f, 0.f);
-    sre[fir_pad(e)] = d.x;
-    sim[fir_pad(e)] = d.y;
-  }
-  for (int k = tid; k < H + 32; k += 256) {
-    const int kt = k - 16;
-    const float2 c = (kt >= 0 && kt < a.ntaps) ? taps[kt] : make_float2(0.f, 0.f);
-    tre[k] = c.x; tim[k] = c.y;
-  }
-  __syncthreads();
-  {
-    // this lane's share of the shifted-tap operand: B[t = 4 st + kk][j] = c[H - 1 + j - t]
-    float Br[kFirMfmaSteps], Bi[TR ? 1 : kFirMfmaSteps];
-    const int j = lane & 15, kk = lane >> 4;
-#pragma unroll
-    for (int st = 0; st < kFirMfmaSteps; ++st) {
-      const int k = H - 1 + j - 4 * st - kk + 16;          // (+ 16: the zero margin in front of the taps) in [0, H + 32)
-      Br[st] = tre[k];
-      if (!TR) Bi[st] = tim[k];
-    }
-    if (TR) Bi[0] = 0.f;
-    switch (wave) {
-      case 0: fir_mfma_tile<KIND, TR, 0>(sre, sim, Br, Bi, lane, ore, oim); fir_mfma_tile<KIND, TR, 1>(sre, sim, Br, Bi, lane, ore, oim); break;
-      case 1: fir_mfma_tile<KIND, TR, 2>(sre, sim, Br, Bi, lane, ore, oim); fir_mfma_tile<KIND, TR, 3>(sre, sim, Br, Bi, lane, ore, oim); break;
-      case 2: fir_mfma_tile<KIND, TR, 4>(sre, sim, Br, Bi, lane, ore, oim); fir_mfma_tile<KIND, TR, 5>(sre, sim, Br, Bi, lane, ore, oim); break;
-      default: fir_mfma_tile<KIND, TR, 6>(sre, sim, Br, Bi, lane, ore, oim); fir_mfma_tile<KIND, TR, 7>(sre, sim, Br, Bi, lane, ore, oim); break;
-    }
-  }
-  __syncthreads();
-  float2 acc[kW];
-#pragma unroll
-  for (int jj = 0; jj < kW; ++jj) {
-    const int o = kW * tid + jj;
-    acc[jj] = make_float2(ore[fir_pad(o)], CPLX ? oim[fir_pad(o)] : 0.f);
-  }
-  fir_epilogue<CPLX>(a, r, det, i0, H, tid, sre, acc);
-}
+// (Round 5 tried this inner product on the matrix cores -- taps shifted along the columns of B, 70 v_mfma_f32_16x16x4_f32 per
+// 256 outputs, parity green -- and measured it SLOWER on every workload: C1's AF stage 48 -> 67 us, 6 RX 178 -> 309 us
+// (profiles/r05_fir_mfma.txt).  The f32 matrix rate of this part equals its packed-FMA rate, 32 FMAs per cycle and SIMD, so
+// there was nothing to win but LDS traffic, which is not what bounds the stage.  The kernel is in the history: LABNOTES 9.5.)
 
 // ---- AGC recursion over the blocks of this call (sigs/agc.m:6-12 loop filter on decay,
 // immediate attack).  One workgroup per RX.  Only the envelope recursion is serial
@@ -1404,38 +1295,6 @@ int launch_demod_fir(const Stage2Args& a, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_done |= 1ull << (dev & 63);
     }
-  }
-  if (a.fir_mfma && H == kFirMfmaH) {
-    // matrix-core form: one launch per kind of product (the kind is a template argument there)
-    const int par16 = (int)(a.m0_lo & 15u);
-    const int EPm = (fir_pad(kFirOut + H + 12) + 3) & ~3, OPm = (fir_pad(kFirOut) + 3) & ~3;
-    for (int grp = 0; grp < 6; ++grp) {
-      // 0 real x real | 1 Re(c d), complex taps | 2 Re(c d), real taps | 3 complex out, complex taps | 4 complex out, real taps
-      if (grp == 5) break;
-      Stage2Args b = a;
-      int n = 0;
-      for (int r = 0; r < a.nrx; ++r) {
-        const bool real_det = (a.det[r] == kDetAbs || a.det[r] == kDetFm || a.det[r] == kDetPll);
-        int g;
-        if (a.out_complex[r]) g = a.taps_real[r] ? 4 : 3;
-        else if (real_det && a.taps_real[r]) g = 0;
-        else g = a.taps_real[r] ? 2 : 1;
-        if (g == grp) b.fir_rx[n++] = r;
-      }
-      if (n == 0) continue;
-      const bool cplx = grp >= 3;
-      const size_t ldsm = (size_t)(2 * EPm + 2 * (H + 32) + (cplx ? 2 : 1) * OPm) * sizeof(float);
-      dim3 grid((a.n_out + par16 + kFirOut - 1) / kFirOut, n);
-      switch (grp) {
-        case 0: hipLaunchKernelGGL((demod_fir_mfma_kernel<kFirRealReal, true>), grid, dim3(256), ldsm, st, b); break;
-        case 1: hipLaunchKernelGGL((demod_fir_mfma_kernel<kFirRePart, false>), grid, dim3(256), ldsm, st, b); break;
-        case 2: hipLaunchKernelGGL((demod_fir_mfma_kernel<kFirRePart, true>), grid, dim3(256), ldsm, st, b); break;
-        case 3: hipLaunchKernelGGL((demod_fir_mfma_kernel<kFirCplx, false>), grid, dim3(256), ldsm, st, b); break;
-        default: hipLaunchKernelGGL((demod_fir_mfma_kernel<kFirCplx, true>), grid, dim3(256), ldsm, st, b); break;
-      }
-      PYSDR_HIP_CHECK(hipGetLastError());
-    }
-    return PYSDR_OK;
   }
   for (int cplx = 0; cplx < 2; ++cplx) {
     Stage2Args b = a;

@@ -1,5 +1,6 @@
 #!/bin/bash
-# AF FIR on the matrix cores (default) against the packed-FMA form (PYSDR_FIR_MFMA=0): every workload, same box; then the
+# AF FIR on the matrix cores (default there) against the packed-FMA form (PYSDR_FIR_MFMA=0): every workload, same box; then the
+# (the matrix-core kernel was removed after this measurement; it is in commit 28d40af: check that out to re-run)
 # kernel averages of C1 and 6 RX by rocprofv3
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export PYSDR_TUNING=1
