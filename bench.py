@@ -864,6 +864,10 @@ def main():
         st = {"segments": sg.value, "patched_serially": pt.value,
               "widest_join": {"phase_words_of_2^32": jw.value, "tolerance": 1024 if synch else 512,
                               "integrator_rad_per_sample": jd.value, "tolerance_w": 2e-8 if synch else 1e-9}}
+        if synch:
+            nl = C.c_int(0)
+            _lib.check(lib.pysdr_pll_linear_starts(ctx.h, 0, C.byref(nl)), "pll_linear_starts")
+            st["linear_starts"] = nl.value        # segments whose warm-up was the linear solve (the rest walked it)
         pll, cpll = (None, st) if synch else (st, None)
     tune = (C.c_int32 * 8)()
     _lib.check(lib.pysdr_get_tuning(ctx.h, tune), "get_tuning")

@@ -123,6 +123,10 @@ int pysdr_set_pll_segments(pysdr_ctx* ctx, int max_segments);
  * |phase difference| in words of 2^32 (accepted up to 512) and |integrator difference| in rad/sample (up to 1e-9).  A
  * diagnostic of this build (no reference call site): what a shorter / cheaper warm-up setting (PYSDR_WFM_PLL) is judged by. */
 int pysdr_pll_join_margin(pysdr_ctx* ctx, int irx, int* max_words, float* max_dw);
+/* AM-Synch carrier loop of the last batch: how many of its segments got their start state from ONE LINEAR SOLVE over the
+ * warm-up window instead of walking it (the loop is linear in the phase domain while its detector does not wrap, which is
+ * checked per window; a noisy or badly guessed window is walked as before).  A diagnostic of this build. */
+int pysdr_pll_linear_starts(pysdr_ctx* ctx, int irx, int* n);
 /* NFM noise squelch (north_star "AGC/squelch"; design notes sigs/squelch.m:92-145): per chunk the
  * mean |2nd difference| of the discriminator output is smoothed (one pole) and the chunk is
  * muted while it exceeds `thresh`; thresh <= 0 disables (default). */

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "pysdr_get_overlap": (_i, [_vp]),
     "pysdr_last_call_overlapped": (_i, [_vp]),
     "pysdr_pll_join_margin": (_i, [_vp, _i, _pi, _pf]),
+    "pysdr_pll_linear_starts": (_i, [_vp, _i, _pi]),
     "pysdr_set_agc": (_i, [_vp, _i, _i, _f]),
     "pysdr_set_squelch": (_i, [_vp, _i, _f]),
     "pysdr_squelch_get": (_i, [_vp, _i, _pf, _pi]),

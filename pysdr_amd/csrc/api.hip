@@ -36,7 +36,7 @@ constexpr double kPllBwHz = 50.0, kPllZeta = 0.7071;
 constexpr double kPllZetaPlan = 0.7071;
 constexpr double kWfmPllBwHz = 30.0;
 
-constexpr int kPllSegMax = 4096;
+constexpr int kPllSegMax = 8192;
 
 // Segmentation of a serial PLL over n samples (PllPlan, common.h).  W = warm-up in samples = `taus`
 // time constants 1/(zeta*wn) of the loop; calls shorter than three warm-ups stay one segment.
@@ -50,6 +50,9 @@ PllPlan plan_pll(int n, double fs, double bw_hz, double taus, double taus_fast, 
   p.tail_cap = 0;
   p.coarse_sweeps = 0;
   p.exact_cap = 0;
+  p.seeded = 0;
+  p.Wseed = 0;
+  p.direct = 0;
   if (n < 3 * p.W || k_max <= 1) {
     p.K = 1;
     p.T = (std::max(n, 64) + 63) & ~63;
@@ -236,6 +239,9 @@ struct pysdr_ctx {
   // one, segment kernel 105 -> 97 us; 3: the noisy model leaves 2700), the last 5 to the fixed point (8-10 sweeps)
   double am_taus = 16.0, am_taus_exact = 5.0;
   int am_coarse_sweeps = 4, am_kmax = 2048, am_tmin = 512;
+  int am_seeded = 1, am_wseed = 0;     // PYSDR_AM_SEED=on[,walked]: warm-ups by the linear solve where the window allows (stage2.hip am_linear_start)
+  int am_direct = 1;                   // PYSDR_AM_DIRECT=0: blocks start from the free-running line (A/B)
+  int am_phase_on_2 = 1;               // PYSDR_AM_PHASE_STREAM=0: arg y on the front stream in the overlapped form too (A/B)
   int pll_kmax = 0;                       // pysdr_set_pll_segments: 0 = default, 1 = serial
   // pilot-PLL segmentation (PYSDR_WFM_PLL = "taus,taus_fast,taus_exact,coarse_sweeps,kmax,tmin,exact_cap" overrides for A/B runs)
   // measured on MI355X (bench.py --workload c4, scripts/diag/pll_sweep.sh; front end ms per 2048 chunks):
@@ -895,6 +901,10 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
       if (nf >= 4 && km > 0) c->am_kmax = std::min(km, kPllSegMax);
       if (nf >= 5 && tm >= 64) c->am_tmin = (tm + 63) & ~63;
     } }
+  { const char* e = tuning_env("PYSDR_AM_SEED");
+    if (e && *e) { int on = 1, ws = 0; const int nf = sscanf(e, "%d,%d", &on, &ws); if (nf >= 1) c->am_seeded = on ? 1 : 0; if (nf >= 2 && ws >= 0) c->am_wseed = ws; } }
+  { const char* e = tuning_env("PYSDR_AM_DIRECT"); if (e && *e) c->am_direct = atoi(e) ? 1 : 0; }
+  { const char* e = tuning_env("PYSDR_AM_PHASE_STREAM"); if (e && *e) c->am_phase_on_2 = atoi(e) ? 1 : 0; }
   { const char* e = tuning_env("PYSDR_MIXDEC_MFMA"); if (e && *e) c->mfma_enable = atoi(e) ? 1 : 0; }
   { const char* e = tuning_env("PYSDR_WFM_SEED");
     if (e && *e) { int on = 1, ws = 0; const int nf = sscanf(e, "%d,%d", &on, &ws); if (nf >= 1) c->wfm_seeded = on ? 1 : 0; if (nf >= 2 && ws >= 0) c->wfm_wseed = ws; } }
@@ -1134,6 +1144,19 @@ int pysdr_pll_stats(pysdr_ctx* c, int irx, int* segments, int* patched) {
   return PYSDR_OK;
 }
 
+int pysdr_pll_linear_starts(pysdr_ctx* c, int irx, int* n) {
+  if (!c || !n || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  RxDevState d;
+  rc = flush_tail(c);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  *n = d.pll_linear;
+  return PYSDR_OK;
+}
+
 int pysdr_pll_join_margin(pysdr_ctx* c, int irx, int* max_words, float* max_dw) {
   if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
   int rc = use_device(c->cfg.device);
@@ -1366,8 +1389,12 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
         s.pll.Wexact = ((int)std::ceil(c->am_taus_exact * tau) + 63) & ~63;
         s.pll.coarse_sweeps = c->am_coarse_sweeps;
       }
-      rc = launch_am_phase(s, c->stream);     // arg y of every sample: parallel, belongs to F
-      if (rc) return rc;
+      s.pll.seeded = (c->am_seeded && s.pll.K > 1) ? 1 : 0;
+      s.pll.direct = c->am_direct;
+      s.pll.Wseed = std::min((std::max(0, c->am_wseed) + 63) & ~63, std::max(0, s.pll.W - 64));
+      // arg y of every sample: parallel, no LDS.  Single-stream form: part of F.  Overlapped form: in front of the walks on
+      // their stream -- 17 us that the front stream does not wait for (profiles/r05_am_phase_stream.txt)
+      if (!(use2 && c->am_phase_on_2)) { rc = launch_am_phase(s, c->stream); if (rc) return rc; }
     }
   } else {
     // SRATE -> fs1 (video filter, all RX in one launch) and the discriminator at fs1 are F; the pilot loop is P; each
@@ -1445,6 +1472,7 @@ int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_
   // P
   if (loop_on_2) {
     PYSDR_HIP_CHECK(hipStreamWaitEvent(SP, c->front_marker, 0));
+    if (!wfm && c->am_phase_on_2) { rc = launch_am_phase(job.s, SP); if (rc) return rc; }
     rc = wfm ? launch_wfm_pll(w, SP) : launch_pll(job.s, SP);
     if (rc) return rc;
     PYSDR_HIP_CHECK(hipEventRecord(c->ev_pll[par], SP));

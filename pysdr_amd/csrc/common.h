@@ -195,6 +195,8 @@ struct RxDevState {       // one per RX, lives in device memory
   int pll_patched;          // ... and segments the serial patch-up pass had to redo
   int pll_join_words;       // the widest join of the last call's first pass, |phase difference| in words of 2^32 (tolerance: pilot 512, carrier 1024)
   float pll_join_dw;        // ... and the widest integrator difference, rad/sample (tolerance 1e-9 / 2e-8)
+  int pll_linear;           // AM-Synch: segments of the last call whose warm-up was the linear solve (stage2.hip am_linear_start)
+  int pll_linear_acc;       // ... being counted
   int wfm_slope_ok;         // the last call ran in segments and none had to be patched: wfm_slope is usable
   int wfm_redo;             // this call's short warm-ups did not meet (stream discontinuity): run the long ones
   double wfm_slope;         // its mean pilot-phase increment per sample beyond fword0 (words of 2^32)
@@ -220,6 +222,7 @@ struct PllPlan {
   int seeded;               // pilot loop: segments start from the Newton-in-time seeds (pllseed.hip) instead of a warm-up, whenever the
                             // previous call left a mean phase increment (state.wfm_slope_ok); the check pass still judges every join
   int Wseed;                // ... after walking this many samples in front of the segment from the seed (0; a multiple of 64)
+  int direct;               // carrier loop: a block's first guess by the direct linear solve (stage2.hip AmBlk) instead of the free-running line
   int tail_cap;             // sweeps per block of the exact TAIL of a warm-up (0: exact_cap)
   int exact_cap;            // sweeps per block of the "exact" walks (pilot loop; 0: until a sweep reproduces its input bit for bit)
   uint32_t* seg;            // [nrx][K][4]: S.phase, S.w, E.phase, E.w (float fields as bits)

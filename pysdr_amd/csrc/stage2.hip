@@ -129,46 +129,132 @@ __global__ __launch_bounds__(256) void am_phase_kernel(const Stage2Args a) {
   }
 }
 
+struct M2 { double a, b, c, d; };
+__device__ __forceinline__ M2 m2_mul(const M2& x, const M2& y) {
+  return M2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d};
+}
+
+// ---- A block's first guess by a DIRECT LINEAR SOLVE (round 5, late).  Around the line g[j] = theta0 + j G (G = the
+// integrator's rate rounded to words) with u[j] = wrap(phi[j] - g[j]), eps = theta - g, V = integrator - G, the 64 samples
+// of a block obey x[j+1] = A x[j] + b[j] on x = (eps, V), A = [[1 - kp - ki, 1], [-ki, 1]], b = ((kp + ki) u, ki u) while
+// the detector does not wrap: an inclusive wave scan with CONSTANT matrices -- four row_shr steps with A, A^2, A^4, A^8,
+// the two row broadcasts with per-lane powers A^((j & 15) + 1), A^((j & 31) + 1) -- yields all 64 phases at once, in float32
+// (a guess: within a word or two of the recursion's own rounding).  ~45 instructions; the sweeps that follow then only
+// CONFIRM it (2-3 until one reproduces its input, where the free-running guess needed 8-10), and they still repair it
+// sample by sample where the detector did wrap, so the walk ends on the recursion's own trajectory for any input as before.
+struct AmBlk {
+  float a1[4], a2[4], a4[4], a8[4];          // A^1, A^2, A^4, A^8 (uniform)
+  float m1[4], m2[4];                        // A^((lane & 15) + 1), A^((lane & 31) + 1)
+  float c0;                                  // (A^(lane + 1))[0][1]: what V in front of the block adds to eps behind sample `lane`
+  float kpi;
+};
+__device__ __forceinline__ void m2_to_f(const M2& m, float (&f)[4]) { f[0] = (float)m.a; f[1] = (float)m.b; f[2] = (float)m.c; f[3] = (float)m.d; }
+__device__ __forceinline__ M2 m2_pow(const M2& A, int e) {      // e < 128
+  M2 sq = A, p = M2{1.0, 0.0, 0.0, 1.0};
+#pragma unroll
+  for (int b = 0; b < 7; ++b) {
+    if ((e >> b) & 1) p = m2_mul(p, sq);
+    sq = m2_mul(sq, sq);
+  }
+  return p;
+}
+__device__ __forceinline__ AmBlk am_block_consts(const Stage2Args& a, int lane) {
+  const double kp = (double)a.pll_kp, ki = (double)a.pll_ki;
+  const M2 A = M2{1.0 - kp - ki, 1.0, -ki, 1.0};
+  AmBlk k;
+  const M2 A2 = m2_mul(A, A), A4 = m2_mul(A2, A2), A8 = m2_mul(A4, A4);
+  m2_to_f(A, k.a1); m2_to_f(A2, k.a2); m2_to_f(A4, k.a4); m2_to_f(A8, k.a8);
+  m2_to_f(m2_pow(A, (lane & 15) + 1), k.m1);
+  m2_to_f(m2_pow(A, (lane & 31) + 1), k.m2);
+  k.c0 = (float)m2_pow(A, lane + 1).b;
+  k.kpi = (float)(kp + ki);
+  return k;
+}
+template <int CTRL, int ROWS, bool BC>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xF, BC));
+}
+
 // The loop over [i_begin, i_end) from the state (ph0, w0) in front of sample i_begin; 64 samples per block.
 // max_it <= 8: a COARSE walk for the early part of a warm-up -- that many sweeps per block, no questions asked (what
 // they leave behind, ~0.6^s / s! of the first guess's error, is forgotten by the exact tail of the warm-up);
 // otherwise sweeps until one reproduces its input.  Lanes past the end of a last, partial block compute on zeros:
 // the scans only carry sums upwards, so nothing of theirs reaches a live lane.
+#ifndef AMX_DEPTH
+#define AMX_DEPTH 4
+#endif
+constexpr int kAmDepth = AMX_DEPTH;                           // blocks per group of loads
 template <bool EMIT>
 __device__ __forceinline__ void am_pll_walk(const Stage2Args& a, int r, int i_begin, int i_end, uint32_t& ph0,
-                                            float& w0, int lane, int max_it = 66) {
+                                            float& w0, int lane, const AmBlk& kc, int max_it = 66) {
   typedef float pl_v2f __attribute__((ext_vector_type(2)));
   const float2* __restrict__ y = a.y[r];
   float2* __restrict__ o = a.ypll[r];
   const float kp = a.pll_kp, ki = a.pll_ki;
-  // The next block's phase words (and, where outputs are due, its samples) are loaded from inline asm one block ahead
-  // and waited for by hand at the END of the block: a prefetch hipcc knows about costs s_waitcnt vmcnt(0) in front of
-  // the first sweep of every block (it cannot count across the back edge) = a memory latency per block on the chain.
-  // "+v": the register is zeroed BEFORE the asm and the load overwrites it in place, so no copy that merges a loaded
-  // and a zero value can land between the load and the hand-placed wait (tests/test_isa_checks.py).
-  uint32_t f_next = 0u;
-  pl_v2f y_next = (pl_v2f){0.f, 0.f};
-  if (i_begin + lane < i_end) {
-    if (EMIT)
-      asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dword %1, %3, off\n\ts_waitcnt vmcnt(0)"
-                   : "+v"(y_next), "+v"(f_next) : "v"(y + i_begin + lane), "v"(&o[i_begin + lane].y) : "memory");
-    else
-      asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "+v"(f_next) : "v"(&o[i_begin + lane].y) : "memory");
+  // Loads run a GROUP of kAmDepth blocks ahead: at the top of a group the phase words (and, where outputs are due, the
+  // samples) of the whole next group are requested, and they are first touched by the copy at the group's end, which is
+  // where hipcc then puts its s_waitcnt -- kAmDepth blocks of sweeps after the loads were issued.  History: one block
+  // ahead through inline asm with a hand-placed wait (a load issued at the top of block i and used at the top of block
+  // i + 1 made hipcc wait for it in front of the first sweep of block i: it does not count across the back edge); that was
+  // enough while a block took 8-10 sweeps; with the direct solve a block is ~130 instructions, shorter than the latency
+  // of a load (74 us per call: 32 blocks x ~2 us).  Several asm loads in flight over an unrolled loop with exits did NOT
+  // survive register allocation: copies of registers still in flight on the exit edges, found by the control-flow check
+  // of tests/test_isa_checks.py after the GPU had faulted.  Past the end of the range the index is clamped to the last
+  // sample (lanes past the end of a last, partial block thus compute on a repeated sample: the scans only carry sums
+  // upwards, so nothing of theirs reaches a live lane).
+  constexpr int D = kAmDepth;
+  if (i_begin >= i_end) return;
+  uint32_t cf[D], nf[D];
+  pl_v2f cy[D], ny[D];
+  const uint32_t* __restrict__ fo = reinterpret_cast<const uint32_t*>(o);
+  const pl_v2f* __restrict__ yl = reinterpret_cast<const pl_v2f*>(y);
+#pragma unroll
+  for (int sl = 0; sl < D; ++sl) {
+    int idx = i_begin + 64 * sl + lane;
+    idx = idx < i_end ? idx : i_end - 1;
+    cf[sl] = fo[2 * (size_t)idx + 1];
+    cy[sl] = EMIT ? yl[idx] : (pl_v2f){0.f, 0.f};
   }
-  for (int i0 = i_begin; i0 < i_end; i0 += 64) {
-    const uint32_t phi = f_next;
-    const pl_v2f yv = y_next;
-    const int nidx = i0 + 64 + lane;
-    f_next = 0u;
-    y_next = (pl_v2f){0.f, 0.f};
-    if (nidx < i_end) {                                    // in flight during the sweeps below
-      if (EMIT) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(y_next) : "v"(y + nidx) : "memory");
-      asm volatile("global_load_dword %0, %1, off" : "+v"(f_next) : "v"(&o[nidx].y) : "memory");
-    }
+  for (int ib = i_begin; ib < i_end; ib += 64 * D) {
+#pragma unroll
+  for (int sl = 0; sl < D; ++sl) {
+    int idx = ib + 64 * (D + sl) + lane;
+    idx = idx < i_end ? idx : i_end - 1;
+    nf[sl] = fo[2 * (size_t)idx + 1];
+    ny[sl] = EMIT ? yl[idx] : (pl_v2f){0.f, 0.f};
+  }
+#pragma unroll
+  for (int sl = 0; sl < D; ++sl) {
+    const int i0 = ib + 64 * sl;
+    if (i0 >= i_end) break;
+    const uint32_t phi = cf[sl];
+    const pl_v2f yv = cy[sl];
     const int count = (i_end - i0 < 64) ? i_end - i0 : 64;
     // in words of 2^32: e and its scan as floats, the integrator's rate w0 R once per block
     const float w0r = __fmul_rn(w0, kRad2Word);
-    uint32_t ph = ph0 + (uint32_t)lane * (uint32_t)__float2int_rn(w0r);   // guess: free running at the integrator's rate
+    const int g0 = __float2int_rn(w0r);
+    uint32_t ph = ph0 + (uint32_t)lane * (uint32_t)g0;     // guess: free running at the integrator's rate ...
+    if (a.pll.direct) {                                    // ... corrected by the linear solve of the block around that line
+      const float u = (float)(int)(phi - ph);
+      float s0 = kc.kpi * u, s1 = ki * u;
+#define PYSDR_AM_STEP(CTRL, ROWS, BC, M)                                                      \
+      {                                                                                       \
+        const float t0 = dpp_f<CTRL, ROWS, BC>(s0), t1 = dpp_f<CTRL, ROWS, BC>(s1);           \
+        const float n0 = __fmaf_rn(M[0], t0, __fmaf_rn(M[1], t1, s0));                        \
+        const float n1 = __fmaf_rn(M[2], t0, __fmaf_rn(M[3], t1, s1));                        \
+        s0 = n0; s1 = n1;                                                                     \
+      }
+      PYSDR_AM_STEP(0x111, 0xF, true, kc.a1)
+      PYSDR_AM_STEP(0x112, 0xF, true, kc.a2)
+      PYSDR_AM_STEP(0x114, 0xF, true, kc.a4)
+      PYSDR_AM_STEP(0x118, 0xF, true, kc.a8)
+      PYSDR_AM_STEP(0x142, 0xA, false, kc.m1)
+      PYSDR_AM_STEP(0x143, 0xC, false, kc.m2)
+#undef PYSDR_AM_STEP
+      s0 = __fmaf_rn(kc.c0, w0r - (float)g0, s0);          // eps behind sample `lane` ...
+      const float eps = dpp_f<0x138, 0xF, false>(s0);      // ... is eps in front of the next (wave_shr:1; lane 0 keeps 0)
+      ph += (uint32_t)__float2int_rn(eps);
+    }
     uint32_t tot = 0u;
     float sj = 0.f;
     auto sweep = [&](uint32_t pin) -> uint32_t {
@@ -195,9 +281,6 @@ __device__ __forceinline__ void am_pll_walk(const Stage2Args& a, int r, int i_be
         if (!(__ballot(ph != p1) & mine) || ++it >= max_it) break;
       }
     }
-    // the next block's loads (issued a block of sweeps ago) and the previous block's store
-    if (EMIT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(f_next), "+v"(y_next) :: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(f_next) :: "memory");
     if (EMIT && lane < count) {
       const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
       const float s = __builtin_amdgcn_sinf(rev), c = __builtin_amdgcn_cosf(rev);
@@ -208,6 +291,9 @@ __device__ __forceinline__ void am_pll_walk(const Stage2Args& a, int r, int i_be
     ph0 = ph0 + (uint32_t)__builtin_amdgcn_readlane((int)tot, count - 1);
     w0 = __fmaf_rn(ki * kWord2Rad, lane_bcast(sj, count - 1), w0);
   }
+#pragma unroll
+  for (int sl = 0; sl < D; ++sl) { cf[sl] = nf[sl]; cy[sl] = ny[sl]; }
+  }
 }
 
 // 1024 words of 2^32 = 1.5e-6 rad of carrier phase (x sin(e) ~ 0 in the output); the integrator within 2e-8 rad/sample.
@@ -216,6 +302,61 @@ __device__ __forceinline__ void am_pll_walk(const Stage2Args& a, int r, int i_be
 __device__ __forceinline__ bool am_state_differs(uint32_t ph_a, float w_a, uint32_t ph_b, float w_b) {
   const int d = (int)(ph_a - ph_b);
   return !(d <= 1024 && d >= -1024 && fabsf(w_a - w_b) <= 2.0e-8f);
+}
+
+// ---- The warm-up as ONE LINEAR SOLVE (round 5; scripts/experiments/am_linear_seed.py).  Around the straight line
+// g[j] = a + j G over the window (a, G: the guess below), with u[j] = wrap(phi[j] - g[j]) taken per sample, eps = theta - g
+// and V = integrator - G in words, the recursion is, while the detector does not wrap,
+//     eps[j+1] = (1 - kp - ki) eps[j] + V[j-1] + (kp + ki) u[j],      V[j] = V[j-1] - ki eps[j] + ki u[j]
+// -- a CONSTANT matrix A and an input, so the state behind N samples is sum_k A^(N-1-k) b[k] (+ A^N x[0], which 16 time
+// constants forget like the walk does).  Lane l takes the samples 64 j + l of the window (coalesced, all loads
+// independent of the arithmetic), Horner in A^64 (4 fp64 FMAs per sample), then A^(63-l) and a wave sum: ~12
+// instructions per 64 samples where the walk spends 4-10 sweeps of 21 DEPENDENT ones.  fp64: eps is up to 2^30 words and
+// must come out to the word.  The detector does not wrap, provably, while |u| <= 0.2 revolutions throughout (eps follows u
+// with < 20 % overshoot: |u - eps| < 0.44): that is checked, and a window that fails it -- noise in the troughs of deep
+// modulation, a carrier more than ~2.7 Hz from the integrator's guess -- is walked as before.  Result against the exact
+// walk on a clean carrier: 8 words of 2^32 (model), the integrator 1e-10.  It is a START, like the walked warm-up's: the
+// joins are held to the same tolerance by the patch kernel.
+constexpr int kAmLinearMaxU = 858993459;                    // 0.2 revolutions
+
+// the state in front of sample s0 from the window [wb, s0) (multiples of 64 apart) and the line (anchor a, slope G);
+// false: the window left the linear range
+__device__ __forceinline__ bool am_linear_start(const Stage2Args& a, int r, int wb, int s0, uint32_t anchor, uint32_t G,
+                                                int lane, uint32_t& ph, float& w) {
+  const float2* __restrict__ o = a.ypll[r];
+  const double kp = (double)a.pll_kp, ki = (double)a.pll_ki, kpi = kp + ki;
+  // A^64 for the rows, A^(63 - lane) for this lane's place in a row (powers of one matrix commute)
+  M2 sq = M2{1.0 - kp - ki, 1.0, -ki, 1.0}, pl = M2{1.0, 0.0, 0.0, 1.0};
+  const int ex = 63 - lane;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    if ((ex >> b) & 1) pl = m2_mul(pl, sq);
+    sq = m2_mul(sq, sq);
+  }
+  const M2 A64 = sq;
+  const int m = (s0 - wb) >> 6;
+  double c0 = 0.0, c1 = 0.0;
+  int umax = 0;
+  uint32_t gl = anchor + (uint32_t)lane * G;                // the line at this lane's sample of row j
+  const uint32_t* f = reinterpret_cast<const uint32_t*>(o + wb + lane) + 1;
+#pragma unroll 6
+  for (int j = 0; j < m; ++j) {
+    const int u = (int)(f[128 * j] - gl);
+    gl += 64u * G;
+    umax = max(umax, u < 0 ? -u : u);                       // (INT_MIN stays negative: it fails the test below as it should)
+    const double ud = (double)u;
+    const double n0 = fma(A64.a, c0, fma(A64.b, c1, kpi * ud));
+    const double n1 = fma(A64.c, c0, fma(A64.d, c1, ki * ud));
+    c0 = n0; c1 = n1;
+  }
+  double x0 = pl.a * c0 + pl.b * c1, x1 = pl.c * c0 + pl.d * c1;
+  bool lin = umax >= 0 && umax <= kAmLinearMaxU;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { x0 += __shfl_xor(x0, d); x1 += __shfl_xor(x1, d); }
+  if (__ballot(!lin)) return false;
+  ph = anchor + (uint32_t)(s0 - wb) * G + (uint32_t)(int)__double2ll_rn(x0);
+  w = (float)(((double)(int)G + x1) * (6.283185307179586476925 / 4294967296.0));
+  return true;
 }
 
 // grid (K, nrx): segment k of RX r.  Segment k > 0 starts W samples early from a guess: the integrator as the call
@@ -229,6 +370,7 @@ __global__ __launch_bounds__(64) void am_pll_seg_kernel(const Stage2Args a) {
   RxDevState* st = a.state + r;
   const int n = a.n_out;
   const int s0 = k * pl.T, s1 = (s0 + pl.T < n) ? s0 + pl.T : n;
+  const AmBlk kc = am_block_consts(a, lane);
   uint32_t ph = st->pll_phase;
   float w = st->pll_w;
   int wb = s0 - pl.W;
@@ -242,21 +384,34 @@ __global__ __launch_bounds__(64) void am_pll_seg_kernel(const Stage2Args a) {
   } else {
     wb = 0;                                  // the true state of the call: exact, however short
   }
+  bool linear = false;
+  if (wb > 0 && pl.seeded) {
+    const uint32_t inc0 = (uint32_t)__float2int_rn(__fmul_rn(w, kRad2Word));
+    uint32_t ph_l = 0u; float w_l = 0.f;
+    // the window up to s0 - Wseed, then Wseed samples of the exact walk (default 0)
+    if (am_linear_start(a, r, wb, s0 - pl.Wseed, ph, inc0, lane, ph_l, w_l)) {
+      linear = true;
+      ph = ph_l; w = w_l;
+      wb = s0 - pl.Wseed;
+      if (lane == 0) atomicAdd(&st->pll_linear_acc, 1);
+    }
+  }
   if (wb < s0) {
     // coarse sweeps first, the last Wexact samples to the fixed point (both bounds on multiples of 64)
-    const int sx = (pl.coarse_sweeps > 0 && s0 - pl.Wexact > wb) ? s0 - pl.Wexact : wb;
-    if (wb < sx) am_pll_walk<false>(a, r, wb, sx, ph, w, lane, pl.coarse_sweeps);
-    am_pll_walk<false>(a, r, sx, s0, ph, w, lane);
+    const int sx = (!linear && pl.coarse_sweeps > 0 && s0 - pl.Wexact > wb) ? s0 - pl.Wexact : wb;
+    if (wb < sx) am_pll_walk<false>(a, r, wb, sx, ph, w, lane, kc, pl.coarse_sweeps);
+    am_pll_walk<false>(a, r, sx, s0, ph, w, lane, kc);
   }
   uint32_t* sg = pl.seg + ((size_t)r * pl.K + k) * 4;
   if (lane == 0) { sg[0] = ph; sg[1] = __float_as_uint(w); }
-  am_pll_walk<true>(a, r, s0, s1, ph, w, lane);
+  am_pll_walk<true>(a, r, s0, s1, ph, w, lane, kc);
   if (lane == 0) {
     sg[2] = ph; sg[3] = __float_as_uint(w);
     if (pl.K == 1) {                         // every live call: nothing to join, no patch-up launch
       st->pll_phase = ph; st->pll_w = w;
       st->pll_segments = 1; st->pll_patched = 0;
       st->pll_join_words = 0; st->pll_join_dw = 0.f;
+      st->pll_linear = 0;
     }
   }
 }
@@ -267,6 +422,7 @@ __global__ __launch_bounds__(64) void am_pll_patch_kernel(const Stage2Args a) {
   if (a.det[r] != kDetPll) return;
   const PllPlan& pl = a.pll;
   const int K = pl.K, n = a.n_out;
+  const AmBlk kc = am_block_consts(a, lane);
   const uint32_t* sg = pl.seg + (size_t)r * K * 4;
   uint32_t ph_fin = sg[(size_t)(K - 1) * 4 + 2];
   float w_fin = __uint_as_float(sg[(size_t)(K - 1) * 4 + 3]);
@@ -308,7 +464,7 @@ __global__ __launch_bounds__(64) void am_pll_patch_kernel(const Stage2Args a) {
     bool joined = false;
     while (j < K) {
       const int s0 = j * pl.T, s1 = (s0 + pl.T < n) ? s0 + pl.T : n;
-      am_pll_walk<true>(a, r, s0, s1, ph, w, lane);
+      am_pll_walk<true>(a, r, s0, s1, ph, w, lane, kc);
       ++patched;
       ++j;
       if (j < K && !am_state_differs(ph, w, sg[(size_t)j * 4 + 0], __uint_as_float(sg[(size_t)j * 4 + 1]))) {
@@ -329,6 +485,8 @@ __global__ __launch_bounds__(64) void am_pll_patch_kernel(const Stage2Args a) {
     st->pll_patched = patched;
     st->pll_join_words = jw;
     st->pll_join_dw = jd;
+    st->pll_linear = st->pll_linear_acc;       // segments that started from the linear solve (every segment has ended: stream order)
+    st->pll_linear_acc = 0;
   }
 }
 

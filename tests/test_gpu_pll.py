@@ -269,6 +269,64 @@ def test_am_synch_hard_carriers_equal_the_serial_oracle(f_off, noise, jumps):
     assert relerr(am[1024:], want[1024:]) <= TOL, (stats, relerr(am[1024:], want[1024:]))
 
 
+def _linear_starts(ctx, irx=0):
+    n = C.c_int(-1)
+    _lib.check(_lib.lib().pysdr_pll_linear_starts(ctx.h, irx, C.byref(n)), "pll_linear_starts")
+    return n.value
+
+
+def test_am_synch_linear_starts_where_the_window_allows_and_walks_where_not(monkeypatch):
+    """Round 5, late: a segment's warm-up as ONE LINEAR SOLVE over its window (am_linear_start, stage2.hip) -- the carrier
+    loop is linear in the phase domain while its detector does not wrap, which the kernel checks per window (|phi - line|
+    <= 0.2 revolutions throughout).  (i) a clean carrier 7 Hz off tune: every segment with a full window in front of it
+    starts that way, the joins are as tight as the walked warm-ups', the audio equals the walked build's
+    (PYSDR_AM_SEED=0) and the serial oracle's; (ii) noise without a carrier: no window qualifies, everything is walked and
+    patched as before; (iii) deep modulation under noise: some do, some do not -- whichever, the audio is the oracle's
+    (test_am_synch_hard_carriers_equal_the_serial_oracle runs with the solve enabled)."""
+    cfg = dict(so.CONFIGS['C1'])
+    cfg['ntaps_dec'] = 255
+    cfg['rx'] = [dict(frq=100e3 - 7.0, mode='AM-Synch', video_bw=10e3, af_bw=5e3)]
+    B = 150
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    x = so.synth_iq(cfg, B * L, 5)
+
+    def run(xx, nb):
+        P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[7e6], mode='AM-Synch', nfilt=255, max_batch_chunks=nb)
+        P.VIDEO_BW = 10e3
+        g = sig_proc.Receiver(P, 100e3 - 7.0, 0, '1')
+        g.mode, g.af_bw = 'AM-Synch', 5e3
+        ctx = P._pysdr_stream
+        out, info = [], []
+        for h in range(2):
+            ctx.process_batch(xx, nb, L, on_device=False)
+            out.append(ctx.fetch(0, nb)[0].copy())
+            jw, jd = C.c_int(0), C.c_float(0)
+            _lib.check(_lib.lib().pysdr_pll_join_margin(ctx.h, 0, C.byref(jw), C.byref(jd)), "pll_join_margin")
+            info.append((pll_stats(ctx), _linear_starts(ctx), jw.value, jd.value))
+        ctx.close()
+        return np.concatenate(out), info
+    lin, i1 = run(x, B)
+    for (seg, pat), nlin, jw, jd in i1:
+        assert seg >= 290 and pat <= 2, i1
+        assert jw <= 512 and jd <= 1e-8, i1
+    # the first call starts from a reset loop: its integrator (the slope of every window's line) is 0 with the carrier 7 Hz
+    # away = half a revolution across a window, so the windows fail the test and are walked; the second call knows the slope:
+    # all but the segments whose window would start before the call
+    assert i1[0][1] == 0 and i1[1][1] >= i1[1][0][0] - 8, i1
+    rng = np.random.default_rng(11)
+    xn = (0.05 * (rng.standard_normal(40 * L) + 1j * rng.standard_normal(40 * L))).astype(np.complex64)
+    _, i2 = run(xn, 40)
+    assert all(nlin == 0 for _, nlin, _, _ in i2), i2
+    monkeypatch.setenv("PYSDR_TUNING", "1")
+    monkeypatch.setenv("PYSDR_AM_SEED", "0")
+    walked, i0 = run(x, B)
+    assert all(nlin == 0 for _, nlin, _, _ in i0), i0
+    assert relerr(lin, walked) <= TOL
+    o = so.make_receivers(cfg, np.float32)[0]
+    want = np.concatenate([o.demod_data(x[(k % B) * L:(k % B + 1) * L]) for k in range(2 * B)])
+    assert relerr(lin[1024:], want[1024:]) <= TOL
+
+
 def test_two_am_synch_receivers_beside_other_modes_in_one_overlapped_context():
     """Four sub-receivers on one stream, two of them AM-Synch (two carrier loops walk side by side: grid (K, nrx)),
     in a batch context (the facade's default: calls overlapped, tails deferred): every sub-receiver's audio against

@@ -39,45 +39,148 @@ def _regs(tok):
     return set()
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_nothing_touches_an_asm_load_destination_before_its_wait():
-    lines = _isa("stage2.hip", ["-fno-slp-vectorize"])
-    in_asm, pending, checked = False, {}, 0          # pending: register -> line number of the load that defines it
+def _functions(lines):
+    """[(symbol, [(line number, instruction text, inside inline asm)])] for every function of an assembly listing"""
+    out, cur, name, in_asm = [], None, None, False
     for no, raw in enumerate(lines, 1):
         ln = raw.strip()
+        m = re.fullmatch(r"(_Z\w+):", ln.split(";")[0].strip())
+        if m and cur is None:
+            name, cur, in_asm = m.group(1), [], False
+            continue
+        if cur is None:
+            continue
+        if ln.startswith(".Lfunc_end"):
+            out.append((name, cur))
+            cur = None
+            continue
         if ln.startswith(";;#ASMSTART"):
             in_asm = True
             continue
         if ln.startswith(";;#ASMEND"):
             in_asm = False
             continue
-        if not ln or ln.startswith(";") or ln.startswith(".") or ln.endswith(":"):
-            continue
         code = ln.split(";")[0].strip()
+        if not code or (code.startswith(".") and not code.endswith(":")):
+            continue
+        cur.append((no, code, in_asm))
+    return out
+
+
+def _pending_load_violations(insns):
+    """Forward data flow over the control-flow graph of ONE function (round 5: the walks keep several blocks of loads in
+    flight across a loop's back edge, which a scan in layout order does not follow).  State = the asm loads that may
+    still be in flight, in issue order, each with its destination registers.  `s_waitcnt vmcnt(N)` -- hand-placed or
+    the compiler's -- leaves at most N operations outstanding; loads return in order, so all but the N newest load
+    instructions have landed (stores in between, which gfx9 does not order against loads, can only mean that fewer
+    loads than N are outstanding).  Any vector / memory instruction that names a register of a load still in flight is a
+    violation: the hardware does not interlock on vmcnt, and a register the compiler believes free while a load is
+    about to land in it is how a wild address is made.  Returns (violations, loads seen waited for)."""
+    # basic blocks
+    blocks, label_at, cur = [], {}, []
+    for no, code, in_asm in insns:
+        if code.endswith(":"):
+            if cur:
+                blocks.append(cur)
+                cur = []
+            label_at[code[:-1]] = len(blocks)
+            continue
+        cur.append((no, code, in_asm))
+        op = code.split(" ")[0]
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64") or op.startswith("s_cbranch"):
+            blocks.append(cur)
+            cur = []
+    if cur:
+        blocks.append(cur)
+    succ = []
+    for i, blk in enumerate(blocks):
+        no, code, _ = blk[-1] if blk else (0, "", False)
         op, _, rest = code.partition(" ")
-        toks = [t.strip() for t in re.split(r",\s*(?![^\[]*\])", rest) if t.strip()]
-        if in_asm and op.startswith("global_load_dword"):
-            for r in _regs(toks[0]):
-                pending[r] = no
+        if op == "s_branch":
+            succ.append([label_at[rest.strip()]])
+        elif op.startswith("s_cbranch"):
+            succ.append([label_at[rest.strip()]] + ([i + 1] if i + 1 < len(blocks) else []))
+        elif op in ("s_endpgm", "s_setpc_b64"):
+            succ.append([])
+        else:
+            succ.append([i + 1] if i + 1 < len(blocks) else [])
+    violations, waited = [], set()
+    seen = [set() for _ in blocks]
+    work = [(0, ())]
+    while work:
+        bi, state = work.pop()
+        if bi >= len(blocks) or state in seen[bi]:
             continue
-        if op == "s_waitcnt" and "vmcnt(0)" in rest:
-            checked += len(pending)
-            pending.clear()
-            continue
-        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
-            pending.clear()                           # layout order stops being execution order (no CFG here: the check
-            continue                                  # follows the fall-through path from a load to its wait)
-        if pending and op.startswith("s_waitcnt") and "vmcnt" in rest:
-            continue                                  # a partial wait: the loads stay pending
-        if pending and (op.startswith("v_") or op.startswith("global_") or op.startswith("ds_") or op.startswith("buffer_")
-                        or op.startswith("flat_") or op.startswith("scratch_")):
-            used = set()
-            for t in toks:
-                used |= _regs(t.split(" ")[0])
-            hit = used & set(pending)
-            assert not hit, (f"stage2.hip ISA line {no}: `{code}` touches v{sorted(hit)} between the asm load of line "
-                             f"{pending[sorted(hit)[0]]} and its s_waitcnt vmcnt(0)")
-    assert checked >= 9, f"expected the PLL kernels' asm prefetches in the ISA, saw {checked} load registers waited for"
+        seen[bi].add(state)
+        assert len(seen[bi]) <= 256, "state explosion: a loop issues asm loads without ever waiting for them?"
+        st = list(state)
+        for no, code, in_asm in blocks[bi]:
+            op, _, rest = code.partition(" ")
+            toks = [t.strip() for t in re.split(r",\s*(?![^\[]*\])", rest) if t.strip()]
+            m = re.search(r"vmcnt\((\d+)\)", rest) if op == "s_waitcnt" else None
+            if m:
+                n = int(m.group(1))
+                for ld in st[:max(0, len(st) - n)]:
+                    waited.add(ld[0])
+                st = st[max(0, len(st) - n):]
+                continue
+            if op.startswith(("v_", "global_", "ds_", "buffer_", "flat_", "scratch_")):
+                used = set()
+                for t in toks:
+                    used |= _regs(t.split(" ")[0])
+                pend = {r: ld[0] for ld in st for r in ld[1]}
+                hit = used & set(pend)
+                if hit:
+                    violations.append((no, code, sorted(hit), pend[sorted(hit)[0]]))
+                if in_asm and op.startswith("global_load_dword"):
+                    st = [ld for ld in st if ld[0] != no]     # (an older instance of the same load is older than everything kept)
+                    st.append((no, tuple(sorted(_regs(toks[0])))))
+        for sx in succ[bi]:
+            work.append((sx, tuple(st)))
+    return violations, len(waited)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_nothing_touches_an_asm_load_destination_before_its_wait():
+    lines = _isa("stage2.hip", ["-fno-slp-vectorize"])
+    checked, bad = 0, []
+    for name, insns in _functions(lines):
+        v, n = _pending_load_violations(insns)
+        checked += n
+        bad += [(name[:60],) + x for x in v]
+    assert not bad, "stage2.hip: an instruction touches the destination of an asm load still in flight:\n" + \
+        "\n".join(f"  {n}: line {no} `{code}` touches v{hit} (load of line {at})" for n, no, code, hit, at in bad[:12])
+    assert checked >= 9, f"expected the PLL kernels' asm prefetches in the ISA, saw {checked} asm loads waited for"
+
+
+def test_the_pending_load_check_finds_a_copy_on_a_back_edge():
+    """the checker itself: a loop that copies an in-flight register at its bottom (what hipcc does to a loop-carried value
+    whose two definitions got different registers) is found although no fall-through path leads from the load to the copy"""
+    fn = """
+_Z4testv:
+	v_mov_b32_e32 v1, 0
+.LBB0_1:
+	;;#ASMSTART
+	global_load_dword v2, v[4:5], off
+	;;#ASMEND
+	s_cbranch_scc1 .LBB0_3
+	s_branch .LBB0_2
+.LBB0_3:
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	s_endpgm
+.LBB0_2:
+	v_mov_b32_e32 v3, v2
+	s_branch .LBB0_1
+.Lfunc_end0:
+"""
+    (name, insns), = _functions(fn.splitlines())
+    v, n = _pending_load_violations(insns)
+    assert 16 in [x[0] for x in v] and n == 1, (v, n)       # (+ the load itself, re-issued into a register still in flight)
+    ok = fn.replace("\tv_mov_b32_e32 v3, v2\n", "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n\tv_mov_b32_e32 v3, v2\n")
+    (name, insns), = _functions(ok.splitlines())
+    assert _pending_load_violations(insns)[0] == []
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
