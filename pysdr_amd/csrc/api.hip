@@ -61,6 +61,7 @@ PllPlan plan_pll(int n, double fs, double bw_hz, double taus, double taus_fast, 
     p.K = (n + p.T - 1) / p.T;
   }
   p.seg = seg;
+  p.lin = seg + (size_t)PYSDR_MAX_RX * kPllSegMax * 4;
   return p;
 }
 
@@ -218,7 +219,7 @@ struct pysdr_ctx {
   float* d_blknoise = nullptr;   // [MAX_RX][max_chunks]
   unsigned* d_blkcnt = nullptr;  // [MAX_RX][max_chunks]
   RxDevState* d_state = nullptr; // [MAX_RX]
-  uint32_t* d_pllseg = nullptr;  // [MAX_RX][kPllSegMax][4] start/end states of the time-parallel PLLs
+  uint32_t* d_pllseg = nullptr;  // [MAX_RX][kPllSegMax][4] start/end states of the time-parallel PLLs + [MAX_RX][kPllSegMax] flags (PllPlan::lin)
   // last call
   int last_nout = 0, last_nchunks = 0, last_nrx = 0;
   size_t last_chunk_len = 0;
@@ -964,7 +965,7 @@ int pysdr_create(const pysdr_cfg* cfg, pysdr_ctx** out) {
   CK(hipMemsetAsync(c->d_blkcnt, 0, (size_t)PYSDR_MAX_RX * cfg->max_chunks * kBlkStride * sizeof(unsigned), c->stream));
   CK(hipMalloc(&c->d_state, PYSDR_MAX_RX * sizeof(RxDevState)));
   CK(hipMemsetAsync(c->d_state, 0, PYSDR_MAX_RX * sizeof(RxDevState), c->stream));
-  CK(hipMalloc(&c->d_pllseg, (size_t)PYSDR_MAX_RX * kPllSegMax * 4 * sizeof(uint32_t)));
+  CK(hipMalloc(&c->d_pllseg, (size_t)PYSDR_MAX_RX * kPllSegMax * 5 * sizeof(uint32_t)));
   for (int k = 0; k < pysdr_ctx::kSlots; ++k)
     for (int i = 0; i < 4; ++i) CK(hipEventCreate(&c->ev[k][i]));
   CK(hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming));

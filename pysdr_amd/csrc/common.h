@@ -196,7 +196,6 @@ struct RxDevState {       // one per RX, lives in device memory
   int pll_join_words;       // the widest join of the last call's first pass, |phase difference| in words of 2^32 (tolerance: pilot 512, carrier 1024)
   float pll_join_dw;        // ... and the widest integrator difference, rad/sample (tolerance 1e-9 / 2e-8)
   int pll_linear;           // AM-Synch: segments of the last call whose warm-up was the linear solve (stage2.hip am_linear_start)
-  int pll_linear_acc;       // ... being counted
   int wfm_slope_ok;         // the last call ran in segments and none had to be patched: wfm_slope is usable
   int wfm_redo;             // this call's short warm-ups did not meet (stream discontinuity): run the long ones
   double wfm_slope;         // its mean pilot-phase increment per sample beyond fword0 (words of 2^32)
@@ -226,6 +225,8 @@ struct PllPlan {
   int tail_cap;             // sweeps per block of the exact TAIL of a warm-up (0: exact_cap)
   int exact_cap;            // sweeps per block of the "exact" walks (pilot loop; 0: until a sweep reproduces its input bit for bit)
   uint32_t* seg;            // [nrx][K][4]: S.phase, S.w, E.phase, E.w (float fields as bits)
+  uint32_t* lin;            // [nrx][K]: carrier loop, 1 where the segment started from the linear solve (counted by the patch kernel: 2047
+                            // atomics on one word would serialise at the L2, common.h PYSDR_BLK_STRIDE)
 };
 
 struct Stage2Args {

@@ -321,8 +321,12 @@ constexpr int kAmLinearMaxU = 858993459;                    // 0.2 revolutions
 
 // the state in front of sample s0 from the window [wb, s0) (multiples of 64 apart) and the line (anchor a, slope G);
 // false: the window left the linear range
+// exact: (anchor, v0) IS the loop's state in front of sample wb (the call's own start: eps = 0, V = v0) and its term
+// A^N x[0] is added, instead of a guess that N samples are trusted to forget -- the first segments of a call, whose window
+// would begin before it (walked from the true state they cost 2 T samples where every other segment walks T: segment 1
+// was the kernel's longest wave, 64 blocks against 32 + this solve).
 __device__ __forceinline__ bool am_linear_start(const Stage2Args& a, int r, int wb, int s0, uint32_t anchor, uint32_t G,
-                                                int lane, uint32_t& ph, float& w) {
+                                                int lane, uint32_t& ph, float& w, bool exact = false, double v0 = 0.0) {
   const float2* __restrict__ o = a.ypll[r];
   const double kp = (double)a.pll_kp, ki = (double)a.pll_ki, kpi = kp + ki;
   // A^64 for the rows, A^(63 - lane) for this lane's place in a row (powers of one matrix commute)
@@ -354,6 +358,15 @@ __device__ __forceinline__ bool am_linear_start(const Stage2Args& a, int r, int 
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { x0 += __shfl_xor(x0, d); x1 += __shfl_xor(x1, d); }
   if (__ballot(!lin)) return false;
+  if (exact) {
+    M2 sqn = M2{1.0 - kp - ki, 1.0, -ki, 1.0}, an = M2{1.0, 0.0, 0.0, 1.0};
+    for (int e = s0 - wb; e > 0; e >>= 1) {
+      if (e & 1) an = m2_mul(an, sqn);
+      sqn = m2_mul(sqn, sqn);
+    }
+    x0 += an.b * v0;
+    x1 += an.d * v0;
+  }
   ph = anchor + (uint32_t)(s0 - wb) * G + (uint32_t)(int)__double2ll_rn(x0);
   w = (float)(((double)(int)G + x1) * (6.283185307179586476925 / 4294967296.0));
   return true;
@@ -385,15 +398,17 @@ __global__ __launch_bounds__(64) void am_pll_seg_kernel(const Stage2Args a) {
     wb = 0;                                  // the true state of the call: exact, however short
   }
   bool linear = false;
-  if (wb > 0 && pl.seeded) {
-    const uint32_t inc0 = (uint32_t)__float2int_rn(__fmul_rn(w, kRad2Word));
+  if (k > 0 && pl.seeded && s0 - pl.Wseed - wb >= 64) {
+    const float w0r = __fmul_rn(w, kRad2Word);
+    const int g0 = __float2int_rn(w0r);
+    const uint32_t inc0 = (uint32_t)g0;
     uint32_t ph_l = 0u; float w_l = 0.f;
-    // the window up to s0 - Wseed, then Wseed samples of the exact walk (default 0)
-    if (am_linear_start(a, r, wb, s0 - pl.Wseed, ph, inc0, lane, ph_l, w_l)) {
+    // the window up to s0 - Wseed, then Wseed samples of the exact walk (default 0); from the call's own state where the
+    // window would begin before the call
+    if (am_linear_start(a, r, wb, s0 - pl.Wseed, ph, inc0, lane, ph_l, w_l, wb == 0, (double)w0r - (double)g0)) {
       linear = true;
       ph = ph_l; w = w_l;
       wb = s0 - pl.Wseed;
-      if (lane == 0) atomicAdd(&st->pll_linear_acc, 1);
     }
   }
   if (wb < s0) {
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(64) void am_pll_seg_kernel(const Stage2Args a) {
     am_pll_walk<false>(a, r, sx, s0, ph, w, lane, kc);
   }
   uint32_t* sg = pl.seg + ((size_t)r * pl.K + k) * 4;
-  if (lane == 0) { sg[0] = ph; sg[1] = __float_as_uint(w); }
+  if (lane == 0) { sg[0] = ph; sg[1] = __float_as_uint(w); pl.lin[(size_t)r * pl.K + k] = linear ? 1u : 0u; }
   am_pll_walk<true>(a, r, s0, s1, ph, w, lane, kc);
   if (lane == 0) {
     sg[2] = ph; sg[3] = __float_as_uint(w);
@@ -475,8 +490,16 @@ __global__ __launch_bounds__(64) void am_pll_patch_kernel(const Stage2Args a) {
     if (!joined) { ph_fin = ph; w_fin = w; break; }
     k = j + 1;
   }
+  int nlin = 0;
+  for (int base = 0; base < K; base += 512) {                 // eight independent loads per lane
+    uint32_t fl[8];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { jw = max(jw, __shfl_xor(jw, o)); jd = fmaxf(jd, __shfl_xor(jd, o)); }
+    for (int u = 0; u < 8; ++u) { const int kk = base + 64 * u + lane; fl[u] = kk < K ? pl.lin[(size_t)r * K + kk] : 0u; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) nlin += (int)fl[u];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { jw = max(jw, __shfl_xor(jw, o)); jd = fmaxf(jd, __shfl_xor(jd, o)); nlin += __shfl_xor(nlin, o); }
   if (lane == 0) {
     RxDevState* st = a.state + r;
     st->pll_phase = ph_fin;
@@ -485,8 +508,7 @@ __global__ __launch_bounds__(64) void am_pll_patch_kernel(const Stage2Args a) {
     st->pll_patched = patched;
     st->pll_join_words = jw;
     st->pll_join_dw = jd;
-    st->pll_linear = st->pll_linear_acc;       // segments that started from the linear solve (every segment has ended: stream order)
-    st->pll_linear_acc = 0;
+    st->pll_linear = nlin;                     // segments that started from the linear solve
   }
 }
 

@@ -310,9 +310,10 @@ def test_am_synch_linear_starts_where_the_window_allows_and_walks_where_not(monk
         assert seg >= 290 and pat <= 2, i1
         assert jw <= 512 and jd <= 1e-8, i1
     # the first call starts from a reset loop: its integrator (the slope of every window's line) is 0 with the carrier 7 Hz
-    # away = half a revolution across a window, so the windows fail the test and are walked; the second call knows the slope:
-    # all but the segments whose window would start before the call
-    assert i1[0][1] == 0 and i1[1][1] >= i1[1][0][0] - 8, i1
+    # away = half a revolution across a window, so the windows fail the test and are walked (all but the first few segments,
+    # which solve from the call's own state over the 512 .. 1024 samples in front of them: 0.07 .. 0.15 revolutions); the
+    # second call knows the slope: every segment but the first
+    assert i1[0][1] <= 4 and i1[1][1] >= i1[1][0][0] - 1, i1
     rng = np.random.default_rng(11)
     xn = (0.05 * (rng.standard_normal(40 * L) + 1j * rng.standard_normal(40 * L))).astype(np.complex64)
     _, i2 = run(xn, 40)
