@@ -1169,21 +1169,39 @@ __global__ __launch_bounds__(256) void wfm_disc_kernel(const WfmArgs a) {
 // off by about 0.06^s of the first guess's error (the loop gain over 64 samples), i.e. two sweeps leave
 // ~1e-5 rad per block, which the exact tail of the warm-up (6 loop time constants: e^-6) forgets to
 // below the 512-word join tolerance.  The patch-up pass still checks every join.
+#ifndef WFMX_DEPTH
+#define WFMX_DEPTH 8
+#endif
+constexpr int kWfmDepth = WFMX_DEPTH;                          // blocks per group of loads
 template <bool EMIT>
 __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restrict__ o, int i_begin, int i_end,
                                              uint32_t& ph0, float& w0, int lane, int max_it = 66) {
-  // The block's mpx samples are loaded from inline asm one block ahead and waited for by hand at the END of the
-  // previous block: a prefetch hipcc knows about costs s_waitcnt vmcnt(0) in front of the first sweep of every block
-  // (it cannot count across the back edge), i.e. the NEXT block's memory latency on the chain of this one.
-  float m_next = 0.f;
-  if (i_begin + lane < i_end)
-    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(m_next) : "v"(&o[i_begin + lane].x) : "memory");
-  for (int i0 = i_begin; i0 < i_end; i0 += 64) {
-    const float m = m_next;
-    const int nidx = i0 + 64 + lane;
-    m_next = 0.f;
-    if (nidx < i_end)                                      // in flight during the sweeps below ("+v": see am_pll_walk)
-      asm volatile("global_load_dword %0, %1, off" : "+v"(m_next) : "v"(&o[nidx].x) : "memory");
+  // The mpx samples are loaded a GROUP of kWfmDepth blocks ahead (plain loads, first touched by the copy at the group's end:
+  // am_pll_walk has the history -- one block ahead through inline asm until round 5, which left this walk waiting for its
+  // loads: a block of five capped sweeps is ~0.35 us of issue, a load 1-2 us away; 112 us per call where the arithmetic
+  // is ~60).  Past the end the index is clamped; dead lanes of a last partial block are zeroed below.
+  constexpr int D = kWfmDepth;
+  if (i_begin >= i_end) return;
+  float cm[D], nm[D];
+  const float* __restrict__ mo = reinterpret_cast<const float*>(o);
+#pragma unroll
+  for (int sl = 0; sl < D; ++sl) {
+    int idx = i_begin + 64 * sl + lane;
+    idx = idx < i_end ? idx : i_end - 1;
+    cm[sl] = mo[2 * (size_t)idx];
+  }
+  for (int ib = i_begin; ib < i_end; ib += 64 * D) {
+#pragma unroll
+  for (int sl = 0; sl < D; ++sl) {
+    int idx = ib + 64 * (D + sl) + lane;
+    idx = idx < i_end ? idx : i_end - 1;
+    nm[sl] = mo[2 * (size_t)idx];
+  }
+#pragma unroll
+  for (int sl = 0; sl < D; ++sl) {
+    const int i0 = ib + 64 * sl;
+    if (i0 >= i_end) break;
+    const float m = cm[sl];
     const int count = (i_end - i0 < 64) ? i_end - i0 : 64;
     // once per block instead of once per sweep: the sample times the detector's normalisation, zero in the dead lanes of
     // a last partial block (e = (m norm) cos, where the oracle rounds (m cos) norm: one ulp of e, far inside the join tolerance)
@@ -1223,8 +1241,6 @@ __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restric
         if (!__any(ph != p1) || ++it >= max_it) break;
       }
     }
-    // the next block's samples (issued a block of sweeps ago) and the previous block's store
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(m_next) :: "memory");
     if (EMIT && lane < count) {
       const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
       const float s2 = __builtin_amdgcn_sinf(2.f * rev);
@@ -1234,6 +1250,9 @@ __device__ __forceinline__ void wfm_pll_walk(const WfmArgs& a, float2* __restric
     }
     ph0 = ph0 + (uint32_t)count * a.fword0 + (uint32_t)__builtin_amdgcn_readlane((int)tot, count - 1);
     w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wj), count - 1));
+  }
+#pragma unroll
+  for (int sl = 0; sl < D; ++sl) cm[sl] = nm[sl];
   }
 }
 

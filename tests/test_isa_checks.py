@@ -1,8 +1,8 @@
 """Build-time checks on the generated ISA (CPU: hipcc cross-compiles for gfx950 without a GPU).
 
 ADVICE r3: the hand-rolled asynchronous loads of the serial-PLL kernels (stage2.hip: am_pll_lanes_kernel,
-wfm_pll_walk) are `asm volatile("global_load_dword[x2] %0, ...")` with the `s_waitcnt vmcnt(0)` in a separate, later asm
-statement.  The hardware does not interlock on vmcnt: any instruction the compiler places between the load and the wait
+wfm_pll_walk) were `asm volatile("global_load_dword[x2] %0, ...")` with the `s_waitcnt vmcnt(0)` in a separate, later asm
+statement (rounds 3-5; gone since: see test_nothing_touches_...).  The hardware does not interlock on vmcnt: any instruction the compiler places between the load and the wait
 that READS the destination register (a merge copy, a spill) sees the register before the data lands.  The sources tie the
 register "+v" so that no merge copy is needed; this test looks at what hipcc actually emitted and fails if any instruction
 between such a load and the next wait for it touches its destination (along the fall-through path: the scan is in
@@ -142,15 +142,17 @@ def _pending_load_violations(insns):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_nothing_touches_an_asm_load_destination_before_its_wait():
-    lines = _isa("stage2.hip", ["-fno-slp-vectorize"])
-    checked, bad = 0, []
-    for name, insns in _functions(lines):
-        v, n = _pending_load_violations(insns)
-        checked += n
-        bad += [(name[:60],) + x for x in v]
-    assert not bad, "stage2.hip: an instruction touches the destination of an asm load still in flight:\n" + \
-        "\n".join(f"  {n}: line {no} `{code}` touches v{hit} (load of line {at})" for n, no, code, hit, at in bad[:12])
-    assert checked >= 9, f"expected the PLL kernels' asm prefetches in the ISA, saw {checked} asm loads waited for"
+    """(Since the end of round 5 the PLL walks prefetch with plain loads a group of blocks ahead and hipcc places the waits;
+    the check stays for whatever inline-asm load the stage-2 sources grow next, and its own test below keeps it honest.)"""
+    bad, nfun = [], 0
+    for src in ("stage2.hip", "pllseed.hip", "resamp_small.hip"):
+        for name, insns in _functions(_isa(src, ["-fno-slp-vectorize"])):
+            nfun += 1
+            v, _ = _pending_load_violations(insns)
+            bad += [(src, name[:60]) + x for x in v]
+    assert nfun >= 12, nfun
+    assert not bad, "an instruction touches the destination of an asm load still in flight:\n" + \
+        "\n".join(f"  {f} {n}: line {no} `{code}` touches v{hit} (load of line {at})" for f, n, no, code, hit, at in bad[:12])
 
 
 def test_the_pending_load_check_finds_a_copy_on_a_back_edge():
