@@ -328,6 +328,46 @@ def test_am_synch_linear_starts_where_the_window_allows_and_walks_where_not(monk
     assert relerr(lin[1024:], want[1024:]) <= TOL
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_am_synch_random_carriers_segments_equal_the_one_segment_walk(seed):
+    """Randomised: carrier offset, noise, modulation depth, phase jumps and the batch size (hence segment length and count)
+    drawn per seed; three calls of a continuous stream in segments -- linear warm-ups where their windows allow, walked ones
+    where not, direct block solves, joins, patch-up -- against the SAME stream walked as ONE segment per call from the true
+    state (pysdr_set_pll_segments(ctx, 1): nothing guessed, nothing joined).  Whatever mix of paths a draw exercises, the
+    audio must agree within the parity bar."""
+    rng = np.random.default_rng(1000 + seed)
+    cfg = dict(so.CONFIGS['C1'])
+    cfg['ntaps_dec'] = 255
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    B = int(rng.choice([13, 24, 40, 61, 97]))
+    f_off = float(rng.uniform(-35.0, 35.0))
+    noise = float(rng.choice([1e-3, 1e-2, 5e-2, 0.15]))
+    depth = float(rng.uniform(0.3, 0.97))
+    n = 3 * B * L
+    jumps = tuple((int(rng.integers(L, n - L)), float(rng.uniform(-3.0, 3.0))) for _ in range(int(rng.integers(0, 3))))
+    x = _carrier_stream(n, cfg['fs'], f_off, noise, jumps, seed=50 + seed, depth=depth)
+
+    def run(serial):
+        P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[7e6], mode='AM-Synch', nfilt=255, max_batch_chunks=B)
+        P.VIDEO_BW = 10e3
+        g = sig_proc.Receiver(P, 100e3, 0, '1')
+        g.mode, g.af_bw = 'AM-Synch', 5e3
+        ctx = P._pysdr_stream
+        if serial:
+            _lib.check(_lib.lib().pysdr_set_pll_segments(ctx.h, 1), "set_pll_segments")
+        out, info = [], []
+        for h in range(3):
+            ctx.process_batch(x[h * B * L:(h + 1) * B * L], B, L, on_device=False)
+            out.append(ctx.fetch(0, B)[0].copy())
+            info.append((pll_stats(ctx), _linear_starts(ctx)))
+        ctx.close()
+        return np.concatenate(out), info
+    seg, i_seg = run(False)
+    one, i_one = run(True)
+    assert all(st == (1, 0) and nl == 0 for st, nl in i_one), i_one
+    assert relerr(seg, one) <= TOL, (dict(B=B, f_off=f_off, noise=noise, depth=depth, jumps=jumps), i_seg, relerr(seg, one))
+
+
 def test_two_am_synch_receivers_beside_other_modes_in_one_overlapped_context():
     """Four sub-receivers on one stream, two of them AM-Synch (two carrier loops walk side by side: grid (K, nrx)),
     in a batch context (the facade's default: calls overlapped, tails deferred): every sub-receiver's audio against
