@@ -221,7 +221,16 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
   const unsigned lane_off = lds0 + (unsigned)((b_blk * 16 + (lane & 15)) * G::SEGB + (a.d + (lane >> 4)) * 8);
   const unsigned lane_dB = ((lane >> 4) + a.d >= 4) ? 16u : 0u;
   // where this wave parks its partial tile: [b][q][col][row], 16 bytes = rows 4*(lane>>4) .. +3 of column lane & 15
-  const unsigned part_off = part0 + (unsigned)((b_blk * G::WK + Q) * 1024 + (lane & 15) * 64 + (lane >> 4) * 16);
+  // (the 16-byte slot of a column is XOR-swizzled with the column pair: as [col][4 rows] the eight lanes a ds_write_b128
+  //  group serves sat on two 16-byte slots of the 128-byte bank window, 4-way, and the epilogue's reads of one row across the
+  //  column pairs on ONE bank, 6-way -- SQ_LDS_BANK_CONFLICT was 51 % (C1) / 63 % (C4) of this kernel's LDS cycles,
+  //  profiles/r05_c{1,4}_pmc_sq.json; MM_PART_PLAIN: the old layout, A/B)
+#ifdef MM_PART_PLAIN
+  const unsigned part_sw = (unsigned)(lane >> 4);
+#else
+  const unsigned part_sw = (unsigned)((lane >> 4) ^ ((lane >> 1) & 3));
+#endif
+  const unsigned part_off = part0 + (unsigned)((b_blk * G::WK + Q) * 1024 + (lane & 15) * 64) + part_sw * 16u;
   auto rd = [&](mm_lds_cf2 pa, mm_lds_cf2 pb, int ls) {
     const int j0 = 4 * (kS + ls);
     const int off8 = j0 + 2 * (j0 / G::P);                 // 8-byte units
@@ -328,7 +337,12 @@ __device__ __forceinline__ bool mm_epilogue(const MixMfmaArgs& a, int tb, unsign
   const int idx = a.mrel0 + tb * G::OUT_PER_TILE + e;
   if (idx < 0 || idx >= a.n_out) return false;
   // partial tiles [b][q][col][row]
-  const mm_lds_cf pr = (mm_lds_cf)(size_t)(part + (unsigned)(b * G::WK * 1024 + (2 * rem) * 64 + i * 4));
+#ifdef MM_PART_PLAIN
+  const int isw = i;
+#else
+  const int isw = (((i >> 2) ^ (rem & 3)) << 2) | (i & 3);   // the slot swizzle of mm_consumer's partial store
+#endif
+  const mm_lds_cf pr = (mm_lds_cf)(size_t)(part + (unsigned)(b * G::WK * 1024 + (2 * rem) * 64 + isw * 4));
   float sr = pr[0], si = pr[16];
 #pragma unroll
   for (int q = 1; q < G::WK; ++q) { sr += pr[q * 256]; si += pr[q * 256 + 16]; }
