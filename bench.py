@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the pySDR receiver hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c1|c1synch|c2|c3|rx6|c4|c4mono] [--split stream|rx]
+    python bench.py --gpus N --steps K --warmup W [--workload c1|c1synch|c2|c3|rx6|c4|c4mono|ft8tri|test2rx] [--ntaps N] [--split stream|rx]
 
 One "step" = one pass of the hot path over one device-resident batch of `--chunks` chunks of one
 synthetic wideband stream.  Default workload = SURVEY.md 8(d) config C3: the fused mix+decimate
@@ -9,7 +9,9 @@ kernel for all 4 sub-receivers (USB/CW/NBFM/AM), the 48 kHz detector/AF/AGC kern
 PSD (chunk 32768 -> 64k FFT, every sample PSD'd).  The other BASELINE configurations run through
 the same tool: c1 (am.py path: 2.048 MS/s, 1 RX AM, 1001 taps), c1synch (the same with the AM-Synch carrier PLL,
 Tables.py:34, receiver.py:649), c2 (8 MS/s, 1 RX NBFM), rx6 (C3's stream through MAX_RX = 6 sub-receivers, params.py:33,
-no PSD), c4 / c4mono (10 MS/s broadcast FM, pilot-PLL stereo / mono).
+no PSD), c4 / c4mono (10 MS/s broadcast FM, pilot-PLL stereo / mono), and the reference's own multi-receiver launch scripts with
+its default 1001-tap prototype (params.py:134): ft8tri (FT8tri:47-74: 8 MS/s, 3 RX USB, -vid_bw 45 -af_bw 5) and test2rx
+(TEST:13-32: 4 MS/s, 2 RX NFM).  --ntaps re-runs any workload with another prototype length (c2 / c3 at 1001).
 
 N > 1: one process per GPU.  Started by `torch.distributed.run` (RANK/LOCAL_RANK/WORLD_SIZE in the
 environment) or, when those are absent, by this script itself: the parent starts N children
@@ -42,20 +44,21 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PSD_CHUNK, PSD_NFFT = 32768, 65536
-DEFAULT_CHUNKS = {"c1": 4096, "c1synch": 4096, "c2": 2048, "c3": 2048, "rx6": 2048, "c4": 2048, "c4mono": 2048}
+DEFAULT_CHUNKS = {"c1": 4096, "c1synch": 4096, "c2": 2048, "c3": 2048, "rx6": 2048, "c4": 2048, "c4mono": 2048,
+                  "ft8tri": 2048, "test2rx": 4096}
 TUNING_ENV = ("PYSDR_TUNING", "PYSDR_MIXDEC_WGS", "PYSDR_MIXDEC_YFLUSH", "PYSDR_DEBUG_FLAGS", "PYSDR_PSD_GROUP",
               "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_PSD_STREAMS", "PYSDR_PSD_PACKED", "PYSDR_WFM_PLL", "PYSDR_MIXDEC_MFMA", "PYSDR_MIXDEC_GRID", "PYSDR_RESAMP_PLAIN",
               "PYSDR_AM_PLL", "PYSDR_OVERLAP", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS", "PYSDR_MFMA_FLAGS")
 # the single-GPU configurations the default line carries next to C3: BASELINE.json configs[0], [1], [3], and the three the
 # reference also runs that the driver's record did not hold until round 5 (mono broadcast FM, MAX_RX = 6, AM-Synch)
-OTHER_CONFIGS = ("c1", "c2", "c4", "c4mono", "rx6", "c1synch")
+OTHER_CONFIGS = ("c1", "c2", "c4", "c4mono", "rx6", "c1synch", "ft8tri", "test2rx")
 # A timed bracket carries ~1 ms that no step owns (the first steps after the idle barrier run slower: 10 / 30 / 100 / 300 steps of
 # C1 = 0.422 / 0.398 / 0.373 / 0.369 ms per step): the workloads whose step is a fraction of a millisecond time at least this
 # many steps (~60 ms) -- as other_configs children whatever K the driver passed for the C3 loop, and by default on their own.
-MIN_STEPS = {"c1": 150, "c1synch": 150, "c2": 120, "rx6": 80, "c4": 60, "c4mono": 80}
+MIN_STEPS = {"c1": 150, "c1synch": 150, "c2": 120, "rx6": 80, "c4": 60, "c4mono": 80, "ft8tri": 80, "test2rx": 80}
 # ... and warm up for ~20 ms (five C1 steps are 2 ms of GPU work: the clocks have not come up yet -- 30 timed steps after 5 / 50 / 300
 # warm-up steps = 0.390 / 0.364 / 0.367 ms per step; C3's five steps are 15 ms, and 20 or 60 change nothing there)
-MIN_WARMUP = {"c1": 60, "c1synch": 60, "c2": 40, "rx6": 25, "c4": 20, "c4mono": 25}
+MIN_WARMUP = {"c1": 60, "c1synch": 60, "c2": 40, "rx6": 25, "c4": 20, "c4mono": 25, "ft8tri": 25, "test2rx": 25}
 
 
 def parse(argv=None):
@@ -68,6 +71,9 @@ def parse(argv=None):
     ap.add_argument("--split", default="stream", choices=["stream", "rx"])
     ap.add_argument("--chunks", type=int, default=0, help="chunks per step (batch resident in HBM); 0 = workload default")
     ap.add_argument("--nrx", type=int, default=0, help="c3 only: first NRX of a 6-RX list (reference MAX_RX), 0 = the 4 of C3")
+    ap.add_argument("--ntaps", type=int, default=0,
+                    help="length of the decimator's prototype (the reference's -nfilt, default 1001: params.py:134); 0 = the workload's own "
+                         "(BASELINE's 255 for c2 / c3 / rx6 / c4, 1001 for c1 / ft8tri / test2rx)")
     ap.add_argument("--no-psd", action="store_true")
     ap.add_argument("--no-cpu-mp", action="store_true", help="skip the one-process-per-RX CPU figure")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
@@ -154,8 +160,18 @@ RX6 = [dict(frq=200e3, mode='USB', video_bw=10e3, af_bw=3e3),
 def workload_cfg(args):
     """cfg dict in the shape of pysdr_amd.synth.CONFIGS (+ 'wfm': mono/stereo for C4)."""
     from pysdr_amd.synth import CONFIGS
+    cfg = _workload_cfg(args)
+    if args.ntaps:
+        cfg['ntaps_dec'] = args.ntaps
+    return cfg
+
+
+def _workload_cfg(args):
+    from pysdr_amd.synth import CONFIGS
     w = args.workload
-    if w in ("c1", "c2", "c3"):
+    if w in ("c1", "c2", "c3", "ft8tri", "test2rx"):
+        # ft8tri / test2rx: the reference's own multi-receiver launch scripts (FT8tri:47-74, TEST:13-32) with its default
+        # 1001-tap prototype -- what pySDR really runs, where c2 / c3 are BASELINE's 255-tap configurations
         cfg = dict(CONFIGS[w.upper()])
         if w == "c3" and args.nrx:
             cfg['rx'] = RX6[:args.nrx]
@@ -301,7 +317,7 @@ def cpu_baseline_per_rx(args, cfg, nchunks, with_psd, seed):
         env.pop(k, None)
     t0 = time.perf_counter()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i),
-                               "--workload", args.workload, "--nrx", str(args.nrx),
+                               "--workload", args.workload, "--nrx", str(args.nrx), "--ntaps", str(args.ntaps),
                                "--cpu-chunks", str(nchunks), "--cpu-seed", str(seed)],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT)
              for i in ids]
@@ -537,9 +553,9 @@ def measured_traffic(args, nrx, B, kernel_prefix, sources):
     """HBM bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950
     correction of MI355X_MICROARCH.md), or None: valid only for the profiled configuration AND only
     while the kernel sources still hash to what was profiled (the profile file carries the hashes)."""
-    if B != DEFAULT_CHUNKS[args.workload] or args.nrx:
+    if B != DEFAULT_CHUNKS[args.workload] or args.nrx or args.ntaps:
         return None, None
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         # C3 (the demod kernels are the same with and without the PSD) or the workload's own passes
         name = f"{tag}_pmc_traffic.json" if args.workload == "c3" else f"{tag}_{args.workload}_pmc_traffic.json"
         p = os.path.join(ROOT, "profiles", name)
@@ -1018,7 +1034,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if (rank == 0 and world == 1 and args.workload == "c3" and not args.no_other_configs and not args.no_demod
-            and not args.nrx and not args.no_psd and not args.chunks):
+            and not args.nrx and not args.no_psd and not args.chunks and not args.ntaps):
         out["other_configs"] = other_configs(args)
     if rank == 0:
         try:                     # RCCL prints a version banner through C stdio: the JSON stays the LAST line

@@ -59,6 +59,24 @@ CONFIGS = {
                    dict(frq=-310e3, mode='CW', video_bw=10e3, af_bw=500.0, bfo=700.0),
                    dict(frq=455e3, mode='NFM', video_bw=20e3, af_bw=4e3),
                    dict(frq=-1.2e6, mode='AM', video_bw=10e3, af_bw=5e3)]),
+    # The reference's largest evidenced operating point (FT8tri:26,47,56,74): `-fc 18100 21074 24915 -fs 8 -IF 0
+    # -foffset 0 -mode USB -fsout 48 -af_bw 5 -vid_bw 45`, filter length left at its default 1001 (params.py:134).
+    # Sub-receiver frq = FC[irx] - FC[0] (receiver.py:834): 0, +2974 kHz, +6815 kHz -- the last one beyond fs/2, which the
+    # 32-bit LO word wraps to -1185 kHz; the synthetic USB signals sit where those LOs listen.
+    'FT8TRI': dict(fs=8e6, fs_out=48e3, ntaps_dec=1001, noise=2e-3,
+                   carriers=[dict(f=0.0, kind='usb', amp=0.15, tone=1200.0),
+                             dict(f=2974e3, kind='usb', amp=0.2, tone=900.0),
+                             dict(f=-1185e3, kind='usb', amp=0.1, tone=1500.0)],
+                   rx=[dict(frq=0.0, mode='USB', video_bw=45e3, af_bw=5e3),
+                       dict(frq=2974e3, mode='USB', video_bw=45e3, af_bw=5e3),
+                       dict(frq=6815e3, mode='USB', video_bw=45e3, af_bw=5e3)]),
+    # TEST:13,30,32 `-fc 145300 144700 -fs 4 -IF 0 -af_bw 5 -mode NFM -fsout 48`: a repeater's output and input, two NFM
+    # sub-receivers 600 kHz apart at 4 MS/s (3/250), default 1001-tap prototype, default video bandwidth (10 kHz, params.py:329)
+    'TEST2RX': dict(fs=4e6, fs_out=48e3, ntaps_dec=1001, noise=2e-3,
+                    carriers=[dict(f=0.0, kind='fm', amp=0.25, tone=1000.0, dev=3000.0),
+                              dict(f=-600e3, kind='fm', amp=0.2, tone=700.0, dev=2500.0)],
+                    rx=[dict(frq=0.0, mode='NFM', video_bw=10e3, af_bw=5e3),
+                        dict(frq=-600e3, mode='NFM', video_bw=10e3, af_bw=5e3)]),
 }
 
 
