@@ -48,7 +48,7 @@ DEFAULT_CHUNKS = {"c1": 4096, "c1synch": 4096, "c2": 2048, "c3": 2048, "rx6": 20
                   "ft8tri": 2048, "test2rx": 4096}
 TUNING_ENV = ("PYSDR_TUNING", "PYSDR_MIXDEC_WGS", "PYSDR_MIXDEC_YFLUSH", "PYSDR_DEBUG_FLAGS", "PYSDR_PSD_GROUP",
               "PYSDR_PSD_ROCFFT", "PYSDR_PSD_PATH", "PYSDR_PSD_STREAMS", "PYSDR_PSD_PACKED", "PYSDR_WFM_PLL", "PYSDR_MIXDEC_MFMA", "PYSDR_MIXDEC_GRID", "PYSDR_RESAMP_PLAIN",
-              "PYSDR_AM_PLL", "PYSDR_OVERLAP", "PYSDR_USE_DIAG_LIB", "PYSDR_MIXDEC_FLAGS", "PYSDR_MFMA_FLAGS")
+              "PYSDR_AM_PLL", "PYSDR_OVERLAP", "PYSDR_USE_DIAG_LIB", "PYSDR_LIB_VARIANT", "PYSDR_MIXDEC_FLAGS", "PYSDR_MFMA_FLAGS")
 # the single-GPU configurations the default line carries next to C3: BASELINE.json configs[0], [1], [3], and the three the
 # reference also runs that the driver's record did not hold until round 5 (mono broadcast FM, MAX_RX = 6, AM-Synch)
 OTHER_CONFIGS = ("c1", "c2", "c4", "c4mono", "rx6", "c1synch", "ft8tri", "test2rx")

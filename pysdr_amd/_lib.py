@@ -10,8 +10,10 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # the diagnostic build (work-skipping ablation switches compiled in) is a different file and is
 # only ever loaded on explicit request
+# ... and so is an A/B variant (python -m pysdr_amd.build --variant NAME): only under the tuning master switch
+_variant = os.environ.get("PYSDR_LIB_VARIANT", "") if os.environ.get("PYSDR_TUNING", "0") not in ("", "0") else ""
 LIB_PATH = os.path.join(HERE, "libpysdr_hip_diag.so" if os.environ.get("PYSDR_USE_DIAG_LIB") == "1"
-                        else "libpysdr_hip.so")
+                        else (f"libpysdr_hip_{_variant}.so" if _variant else "libpysdr_hip.so"))
 
 MAX_RX = 8
 

@@ -68,13 +68,43 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 
 def _newest_source_mtime():
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     files.append(os.path.join(HERE, "..", "include", "pysdr_hip.h"))
     return max(os.path.getmtime(f) for f in files)
 
 
 def needs_build():
     return (not os.path.exists(LIB)) or os.path.getmtime(LIB) < _newest_source_mtime()
+
+
+def build_variant(name, verbose=True):
+    """A/B builds without a hipcc on the critical path of a GPU call: ``PYSDR_TUNING=1 PYSDR_MIXDEC_FLAGS=-DMD_LONG_TPB=512
+    python -m pysdr_amd.build --variant tpb512`` compiles ONLY the sources that got extra flags (into ``*.<name>.o``), links
+    them with the shipped objects of the others into ``libpysdr_hip_<name>.so``; ``PYSDR_TUNING=1 PYSDR_LIB_VARIANT=<name>``
+    loads it (``_lib.py``).  Variant libraries are never loaded otherwise and are git-ignored like every ``.so``."""
+    build(force=False, verbose=verbose)
+    hipcc = os.path.join(ROCM, "bin", "hipcc")
+    extra, fhash = extra_flags(False)
+    objs, procs = [], []
+    for src in SOURCES:
+        if extra.get(src) or (src == "api.hip" and fhash):
+            obj = os.path.join(CSRC, src.replace(".hip", f".{name}.o"))
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=off",
+                   *([f"-DPYSDR_EXTRA_FLAGS_HASH={fhash}"] if (src == "api.hip" and fhash) else []),
+                   *flags_for(src, extra), "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+        else:
+            obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    out = os.path.join(HERE, f"libpysdr_hip_{name}.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs +
+                          ["-L" + os.path.join(ROCM, "lib"), "-lrocfft", "-ldl", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+    return out
 
 
 def build(force=False, verbose=True, diag=False):
@@ -112,4 +142,7 @@ def build(force=False, verbose=True, diag=False):
 
 
 if __name__ == "__main__":
-    print("built", build(force="--force" in sys.argv, diag="--diag" in sys.argv))
+    if "--variant" in sys.argv:
+        print("built", build_variant(sys.argv[sys.argv.index("--variant") + 1]))
+    else:
+        print("built", build(force="--force" in sys.argv, diag="--diag" in sys.argv))

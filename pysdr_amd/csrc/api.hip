@@ -478,7 +478,13 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   a.magic = (up == 1) ? 0u : (uint32_t)(4294967296ULL / (unsigned)up) + 1u;
   a.nrx = nrx;
   const int ratio = (down + up - 1) / up;
-  const size_t taps_bytes = (size_t)nrx * up * d.kpad * sizeof(float2);
+  // Which instantiation runs this shape (mixdec.hip md_dispatch): its thread count, and whether its waves can hold their taps
+  // in registers.  The long-prototype multi-RX shapes (768 threads) then read the taps from memory once per launch and the
+  // LDS holds tiles and the output stage only; the BASELINE shapes (1024 threads) keep their taps in LDS as before.
+  const MixdecVariant var = mixdec_variant(nrx, up, d.kpad, c->threads);
+  const int threads = std::min(c->threads, var.tpb);
+  const int hold_step = (threads / 64) / (up * var.nh);           // waves per (branch, RX group); 0: not enough waves to hold
+  bool taps_lds = !(var.tpb != 1024 && var.can_hold && hold_step >= 1);
   // two tile buffers + the taps must fit the LDS share of one workgroup
   const int wgs = c->wgs_per_cu;
   const long lds_share = (160L * 1024) / wgs - 512;
@@ -487,31 +493,41 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   // (yflush tiles of outputs per RX); if that is less than 4 tiles' worth the tile shrinks.
   const long slack = d.kpad + 2L * ratio + 8 + 128;   // halo, ownership overhang, whole 64-pair DMA pieces
   long cap = 0, tile_out = 0, yflush = 0;
-  long reserve = 0;
-  for (int pass = 0; pass < 2; ++pass) {
-    cap = c->tile_bytes > 0 ? c->tile_bytes / (long)sizeof(float2) : (1L << 30);
-    if (2 * cap * (long)sizeof(float2) + (long)taps_bytes + reserve > lds_share)
-      cap = (lds_share - (long)taps_bytes - reserve) / (2 * (long)sizeof(float2));
-    tile_out = ((cap - slack) * up) / down;
-    if (tile_out >= 4L * up) tile_out -= tile_out % (4L * up);   // whole quads of every polyphase branch
-    tile_out &= ~1L;
-    if (tile_out < 2) {
-      tile_out = 2;
-      cap = slack + (2L * down + up - 1) / up + 2;
-    } else {
-      cap = std::min(cap, slack + (tile_out * down + up - 1) / up + 2);   // no more LDS than the tile needs
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const size_t taps_bytes = taps_lds ? (size_t)nrx * up * d.kpad * sizeof(float2) : 0;
+    long reserve = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      cap = c->tile_bytes > 0 ? c->tile_bytes / (long)sizeof(float2) : (1L << 30);
+      if (2 * cap * (long)sizeof(float2) + (long)taps_bytes + reserve > lds_share)
+        cap = (lds_share - (long)taps_bytes - reserve) / (2 * (long)sizeof(float2));
+      tile_out = ((cap - slack) * up) / down;
+      // whole quads of every polyphase branch -- and, where the waves hold their taps, the same number of quads for every
+      // wave of a (branch, RX group): a tile of 60 outputs at 3/500 would give one wave in four a second task
+      const long quantum = 4L * up * ((!taps_lds && tile_out >= 4L * up * hold_step) ? hold_step : 1);
+      if (tile_out >= quantum) tile_out -= tile_out % quantum;
+      tile_out &= ~1L;
+      if (tile_out < 2) {
+        tile_out = 2;
+        cap = slack + (2L * down + up - 1) / up + 2;
+      } else {
+        cap = std::min(cap, slack + (tile_out * down + up - 1) / up + 2);   // no more LDS than the tile needs
+      }
+      cap = (cap + 1) & ~1L;
+      const long per_tile = (long)nrx * tile_out * (long)sizeof(float2);
+      const long left = lds_share - (long)taps_bytes - 2 * cap * (long)sizeof(float2);
+      yflush = left > 0 ? std::min(16L, left / per_tile) : 0;
+      if (yflush >= 4 || pass == 1) break;
+      reserve = 4 * per_tile;
     }
-    cap = (cap + 1) & ~1L;
-    const long per_tile = (long)nrx * tile_out * (long)sizeof(float2);
-    const long left = lds_share - (long)taps_bytes - 2 * cap * (long)sizeof(float2);
-    yflush = left > 0 ? std::min(16L, left / per_tile) : 0;
-    if (yflush >= 4 || pass == 1) break;
-    reserve = 4 * per_tile;
+    // hold mode needs every tile to start on the same polyphase branch; a tile too small for that reads its taps from LDS
+    if (taps_lds || (tile_out % up) == 0) break;
+    taps_lds = true;
   }
   if (yflush < 1) {
     set_last_error("decimator: filter (%d taps, %d rx, up %d) does not fit LDS", d.ntaps, nrx, up);
     return PYSDR_ERR_ARG;
   }
+  a.taps_lds = taps_lds ? 1 : 0;
   a.tile_out = (int)tile_out;
   a.tile_cap = (int)cap;
   if (c->yflush_cap > 0 && c->yflush_cap < yflush) yflush = c->yflush_cap;
@@ -546,7 +562,7 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
   a.zero = peak ? c->d_peak2[c->peak_cur ^ 1] : nullptr;
   a.zero_n = peak ? c->cfg.max_chunks : 0;
   int rc = small ? launch_resamp_small(a, c->grid_override, c->resamp_plain, st)
-                 : launch_mixdec(a, c->threads, c->grid_override > 0 ? c->grid_override : c->num_cus * wgs, st);
+                 : launch_mixdec(a, c->threads, c->grid_override > 0 ? c->grid_override : c->num_cus * wgs, st);   // (the REQUESTED thread count: it selects the instantiation, which then clamps it to its own)
   if (rc) return rc;
   if (small && n_out <= 0) {          // the resampler starts no kernel for a call without outputs: the roll on its own
     rc = launch_hist_roll(d_x, d.d_hist[d.hist_cur], d.d_hist[d.hist_cur ^ 1], d.hist_len, (uint32_t)n, a.zero, a.zero_n, st);

@@ -78,7 +78,11 @@ struct MixDecArgs {
   int dq_tile, dr_tile;   // divmod(tile_out*down, up)
   int dq_last, dr_last;   // divmod((tile_out-1)*down, up)
   int yflush, ycap;       // LDS output stage: flushed every yflush tiles; ycap = yflush*tile_out per RX
+  int taps_lds;           // 1: the taps are staged in LDS ([nrx][up][kpad] behind the tile buffers); 0: every wave holds its taps in
+                          // registers for the whole launch and reads them from memory once (mixdec_variant: the host guarantees hold mode)
 };
+struct MixdecVariant { int tpb, can_hold, nh; };
+MixdecVariant mixdec_variant(int nrx, int up, int kpad, int threads);
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st);
 size_t mixdec_lds_bytes(const MixDecArgs& a);
 

@@ -220,20 +220,130 @@ __device__ __forceinline__ void fold_rotate_stage(const float2 (&A)[N], const fl
   }
 }
 
-// NJ = kpad/16 known at compile time (fully unrolled tap loop) or 0 for a runtime loop.
-template <int R, int NJ>
-__global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
+// Compile-time shape of one instantiation.  NJ = kpad/16 known at compile time (fully unrolled tap loop) or 0 for a runtime
+// loop; TPB = threads per workgroup (the register budget of a wave follows from it: 128 at 1024 threads, 168 at 768);
+// NHX = RX groups a tile's work is dealt out in (0: the default of that TPB).
+//   TPB = 1024 (the BASELINE configurations, 255-tap prototypes): up to 24 tap pairs per lane are held in registers, the
+//        sub-receivers split into two halves above 4.
+//   TPB = 768 (round 6: the reference's DEFAULT 1001-tap prototype with SEVERAL sub-receivers -- FT8tri:47-74, TEST:30,
+//        params.py:134 -- 21 tap pairs per lane and RX): 12 waves of 168 registers hold the taps of up to THREE sub-receivers
+//        (126 registers), so one LDS read of x still serves every RX of the group; with the taps in LDS (<R,0>, where these
+//        shapes ran until now) every tap step was 1 + R LDS reads: ft8tri 0.50, 4 RX 0.44, 6 RX 0.30 of the HBM peak
+//        (profiles/r06_baseline_long_prototype_multirx.txt).
+#ifndef MD_LONG_TPB
+#define MD_LONG_TPB 768      // threads of the long-prototype multi-RX shapes (A/B: 512, 768, 1024)
+#endif
+#ifndef MD_LONG_MM
+#define MD_LONG_MM 1         // the long-prototype shapes of 2 - 4 sub-receivers on the matrix cores (A/B: 0 = vector form)
+#endif
+#ifndef MD_LONG_NH
+#define MD_LONG_NH 0         // their RX groups: 0 = as few as the registers allow, n = n groups (A/B)
+#endif
+#ifndef MD_XGROUP
+#define MD_XGROUP 7          // x reads per group of the register-tight shapes (A/B)
+#endif
+//   MM = 1 (round 6, the same shapes): the dot products of a task on the MATRIX cores, v_mfma_f32_4x4x1_16b_f32 -- sixteen
+//        independent 4x4 blocks with K = 1.  A task is still (branch, quad of outputs); the sixteen blocks are the sixteen tap
+//        residues k mod 16 (what the sixteen lanes of a DPP row are in the vector form), the four ROWS of a block the four
+//        outputs of the quad, its four COLUMNS (Re, Im) of two sub-receivers.  So lane 4 b + i reads x[n_i - 16 jj - b] from
+//        LDS (one 8-byte read per step, as before), Re x and Im x go through two MFMAs per pair of sub-receivers against the
+//        wave's tap registers ([Re g | Im g] and [-Im g | Re g]) -- 256 MACs per instruction, every one of them useful
+//        when R is even (75 % at R = 3), where the 16x16x4 shape of mixdec_mfma.hip would fill 2 R of 16 columns.  The tap
+//        operands of 2 / 3-4 sub-receivers are 42 / 84 registers (126 held as complex pairs for the vector form), so 12
+//        waves fit with nothing spilled; the 16 block sums meet through two DPP row rotations and three permlane swaps.
+//        Why: the vector form at these shapes is bound by how many INSTRUCTIONS its few, register-heavy waves can issue
+//        (126 packed FMAs per task at 3 RX; profiles/r06_long_multirx_variants.txt), not by arithmetic throughput.
+template <int R, int NJ, int TPB, int NHX, int MM = 0>
+struct MdShape {
+  static constexpr bool kMm = MM != 0;
+  static constexpr int G = (R + 1) / 2;                       // MM: pairs of sub-receivers = 4-column groups
+  static constexpr int kBudget = TPB > 768 ? 128 : (TPB > 512 ? 168 : 256);     // registers per lane
+  static constexpr int kMaxHeld = TPB > 768 ? 24 : (kBudget - 80) / 2;          // tap pairs per lane that may stay in registers (everything else
+                                                                                // of the tile loop takes ~75: <1,21> = 42 + 75)
+  static constexpr int nh_default() {
+    if (MM) return 1;
+    if (TPB > 768) return R > 4 ? 2 : 1;
+    int nh = 1;
+    while (NJ > 0 && ((R + nh - 1) / nh) * NJ > kMaxHeld && nh < R) ++nh;
+    return nh;
+  }
+  static constexpr int NH = NHX > 0 ? NHX : nh_default();     // RX groups
+  static constexpr int RH = (R + NH - 1) / NH;                // RX per task in hold mode
+  static constexpr bool kCanHold = (NJ > 0) && (MM ? (2 * G * NJ + 60 <= kBudget) : (RH * NJ <= kMaxHeld));
+};
+
+typedef float md_f4 __attribute__((ext_vector_type(4)));
+// (a, b) -> [a.row0 + a.row1, b.row0 + b.row1, a.row2 + a.row3, b.row2 + b.row3]   (rows of 16 lanes; v_permlane16_swap:
+// the odd rows of the first operand change places with the even rows of the second)
+__device__ __forceinline__ float swap16_add(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// (a, b) -> [a.row0 + a.row2, a.row1 + a.row3, b.row0 + b.row2, b.row1 + b.row3]   (v_permlane32_swap: the upper half of the
+// first operand changes places with the lower half of the second)
+__device__ __forceinline__ float swap32_add(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float dpp_row_ror4(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_row_ror8(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+}
+
+// The matrix-core form's epilogue.  acc[g][i] of lane 4 b + j = block b's sum for output i of the quad, column j of RX pair g
+// (the Re x chain and the Im x chain already added).  The sixteen blocks meet in a fixed order -- the four of a 16-lane row by
+// two rotations, the four rows by swaps -- which leaves output rho's totals in row rho; there lane (q = pair, j even) has
+// Re, its neighbour Im: it rotates RX 2 q + j / 2 by the LO phase and stages the sample like fold_rotate_stage.
+template <int G, int R>
+__device__ __forceinline__ void mm_fold_rotate_stage(const md_f4 (&acc)[G], int lane, bool valid, uint32_t rel, uint32_t p0,
+                                                     uint32_t fw, float2* ys, int ycap, int io) {
+  float tot[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = acc[g][i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] += dpp_row_ror4(c[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] += dpp_row_ror8(c[i]);
+    tot[g] = swap32_add(swap16_add(c[0], c[1]), swap16_add(c[2], c[3]));
+  }
+  const int q = (lane >> 2) & 3, j = lane & 3;
+  float t = tot[0];
+#pragma unroll
+  for (int g = 1; g < G; ++g)
+    if (q == g) t = tot[g];
+  const float other = dpp_quad_xor1(t);               // the Im column beside a Re column
+  const int rx = 2 * q + (j >> 1);
+  if (valid && q < G && (j & 1) == 0 && rx < R) {
+    const uint32_t ph = p0 + fw * rel;
+    const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+    const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+    float2 o;
+    o.x = t * cs - other * sn;
+    o.y = t * sn + other * cs;
+    ys[rx * ycap + io] = o;
+  }
+}
+
+template <int R, int NJ, int TPB, int NHX, int MM>
+__global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   float2* const buf0 = lds;                    // [tile_cap]
   float2* const buf1 = lds + a.tile_cap;       // [tile_cap]
-  float2* const tl = lds + 2 * a.tile_cap;     // [R][up][kpad]
-  float2* const ys = tl + R * a.up * a.kpad;   // [R][ycap] output stage
+  float2* const tl = lds + 2 * a.tile_cap;     // [R][up][kpad] (taps_lds) or nothing (the waves hold their taps, read from memory)
+  float2* const ys = tl + (a.taps_lds ? R * a.up * a.kpad : 0);   // [R][ycap] output stage
 
   const int tid = threadIdx.x;
   const int nthr = blockDim.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;   // wave-uniform: SALU
   const int lane = tid & 63;
-  const int g = lane >> 4, s = lane & 15;       // DPP row, lane within the row
+  // vector form: g = DPP row (the output of a quad), s = lane within the row (tap residue k mod 16);
+  // matrix-core form (MdShape::kMm): lane 4 b + i = block b (tap residue) and row i of the block (the output of the quad)
+  const int g = MM ? (lane & 3) : (lane >> 4), s = MM ? (lane >> 2) : (lane & 15);
 
   // contiguous run of tiles for this workgroup
   const int ng = gridDim.x;
@@ -244,7 +354,9 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   if (t_begin >= t_end) return;
 
   // ---- stage the LO-modulated taps once
-  if (a.aligned16) {
+  if (!a.taps_lds) {
+    // (hold mode guaranteed by the host, mixdec_variant(): every wave reads its own taps straight from memory below)
+  } else if (a.aligned16) {
     const int nt4 = (R * a.up * a.kpad) >> 1;                   // taps as 16-B slots
     const float4* src = reinterpret_cast<const float4*>(a.taps);
     float4* dst = reinterpret_cast<float4*>(tl);
@@ -262,9 +374,11 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   // reads of a C3 task disappear).  For that the tasks are dealt out by (branch, RX half): wave w
   // belongs to group w % (UP*NH), works on that group's branch and -- above 4 RX -- on one half
   // of the sub-receivers only, and walks the quads with stride nwaves / (UP*NH).
-  constexpr int NH = (R > 4) ? 2 : 1;                   // RX halves
-  constexpr int RH = (R + NH - 1) / NH;                 // RX per task in hold mode
-  constexpr bool kCanHold = (NJ > 0) && (RH * NJ <= 24);
+  typedef MdShape<R, NJ, TPB, NHX, MM> Sh;
+  constexpr bool kMm = Sh::kMm;
+  constexpr int NH = Sh::NH;                            // RX groups (halves at 1024 threads)
+  constexpr int RH = Sh::RH;                            // RX per task in hold mode
+  constexpr bool kCanHold = Sh::kCanHold;
   const int ngrp = a.up * NH;
   const bool hold = kCanHold && ngrp <= nwaves && (a.tile_out % a.up) == 0;
   const int hold_grp = wave % ngrp;
@@ -273,16 +387,26 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   const int hold_rcount = hold ? ((R - hold_rbase < RH) ? R - hold_rbase : RH) : R;
   const int hold_step = nwaves / ngrp;                  // waves per group
   const int hold_q0 = (wave < ngrp * hold_step) ? wave / ngrp : (1 << 29);
-  float2 greg[kCanHold ? RH : 1][kCanHold ? NJ : 1];
+  float2 greg[(kCanHold && !kMm) ? RH : 1][(kCanHold && !kMm) ? NJ : 1];
+  // matrix-core form: the B operands of the two chains, lane 4 b + j = tap residue b, column j of the RX pair
+  constexpr int kG = kMm ? Sh::G : 1;
+  float bre[kG][kMm ? NJ : 1], bim[kG][kMm ? NJ : 1];
   // per-lane constants of the epilogue: lane s of every row finishes RX hold_rbase + s
   // (kTight: instantiations whose tap registers leave no room -- 2*RH*NJ >= 40 of the 128 a
   // 1024-thread workgroup may use -- recompute these four per task instead: a spilled one is reloaded
   // with a scratch load, and the s_waitcnt vmcnt(0) behind it also waits for the NEXT tile's copies,
   // i.e. serialises the DMA with the dot products: mixdec<1,21> ran at 0.36 of HBM for that reason)
-  constexpr bool kTight = kCanHold && (2 * RH * NJ >= 40) && (R != 4);
+  constexpr bool kTight = !kMm && kCanHold && (2 * RH * NJ >= Sh::kBudget - 88) && (R != 4 || TPB != 1024);
   uint32_t my_p0 = 0u, my_fw = 0u;
   int v_gup = g * a.up, v_gdown = g * a.down - s;
-  if (!kTight) {
+  if (kMm) {
+    // the lane of the matrix-core epilogue: row rho = lane >> 4 finishes output rho of the quad, (pair q, column j) RX 2 q + j / 2
+    const int rx = 2 * ((lane >> 2) & 3) + ((lane & 3) >> 1);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (rx == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; }
+    asm volatile("" : "+v"(my_p0), "+v"(my_fw), "+v"(v_gup), "+v"(v_gdown));
+  } else if (!kTight) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
       if (hold_rbase + s == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; }
@@ -302,18 +426,35 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   if (kCanHold && hold) {
     // this wave's taps: one branch (p_f is the same for every tile: tile_out*DOWN is a multiple of UP),
     // one RX half, read from LDS once for the whole launch
-    dma_wait();
-    __syncthreads();
+    if (a.taps_lds) {
+      dma_wait();
+      __syncthreads();
+    }
     uint32_t qc0, pc0;
     divmod_magic((uint32_t)cur.p_f + (uint32_t)hold_c * (uint32_t)a.down, (uint32_t)a.up, a.magic, qc0, pc0);
     const int kp0 = (NJ > 0) ? 16 * NJ : a.kpad;
-    const float2* th = tl + (int)pc0 * kp0 + s + hold_rbase * a.up * kp0;
+    const float2* th = (a.taps_lds ? tl : a.taps) + (int)pc0 * kp0 + s + hold_rbase * a.up * kp0;
+    if constexpr (kMm) {
+      // column j of pair gq: RX 2 gq + j / 2, part j & 1.  y = sum g x:  Re x chain against [Re g | Im g], Im x chain against [-Im g | Re g]
+      const int j = lane & 3;
 #pragma unroll
-    for (int r = 0; r < RH; ++r)
+      for (int gq = 0; gq < kG; ++gq) {
+        const int rx = 2 * gq + (j >> 1);
 #pragma unroll
-      for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj) {
-        greg[r][jj] = (r < hold_rcount) ? th[r * a.up * kp0 + 16 * jj] : make_float2(0.f, 0.f);
+        for (int jj = 0; jj < NJ; ++jj) {
+          const float2 gg = (rx < R) ? th[rx * a.up * kp0 + 16 * jj] : make_float2(0.f, 0.f);
+          bre[gq][jj] = (j & 1) ? gg.y : gg.x;
+          bim[gq][jj] = (j & 1) ? gg.x : -gg.y;
+        }
       }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RH; ++r)
+#pragma unroll
+        for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj) {
+          greg[r][jj] = (r < hold_rcount) ? th[r * a.up * kp0 + 16 * jj] : make_float2(0.f, 0.f);
+        }
+    }
   }
 
   for (int tb = t_begin; tb < t_end; ++tb) {
@@ -435,7 +576,43 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
       const float2* tp = tl + (int)pc * kp + s;
       // A += g*x.re, B += g*x.im per RX (two packed FMAs per tap, no operand shuffles);
       // y = (A.re - B.im, A.im + B.re)
-      if (kCanHold && hold) {
+      if (kCanHold && hold && kMm) {
+        // ---- matrix cores: 16 blocks = 16 tap residues, rows = the quad's outputs, columns = (Re, Im) of an RX pair
+        md_f4 accA[kG], accB[kG];
+#pragma unroll
+        for (int gq = 0; gq < kG; ++gq) { accA[gq] = (md_f4){0.f, 0.f, 0.f, 0.f}; accB[gq] = (md_f4){0.f, 0.f, 0.f, 0.f}; }
+        constexpr int kTop = 16 * ((NJ > 0 ? NJ : 1) - 1);
+        const lds_cf2 xr = to_lds(xp - kTop);
+        constexpr int kNJ = kMm ? NJ : 1;
+        constexpr int kXG = MD_XGROUP;          // reads of x per group (a compiler fence between groups: see below)
+#pragma unroll
+        for (int j0 = 0; j0 < kNJ; j0 += kXG) {
+          float2 xg[kXG];
+#pragma unroll
+          for (int u = 0; u < kXG; ++u)
+            if (j0 + u < kNJ) xg[u] = lds_ld(xr, kTop - 16 * (j0 + u));
+#pragma unroll
+          for (int u = 0; u < kXG; ++u) {
+            if (j0 + u >= kNJ) continue;
+#pragma unroll
+            for (int gq = 0; gq < kG; ++gq) {
+              accA[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xg[u].x, bre[gq][j0 + u], accA[gq], 0, 0, 0);
+              accB[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xg[u].y, bim[gq][j0 + u], accB[gq], 0, 0, 0);
+            }
+          }
+          if (j0 + kXG < kNJ) asm volatile("" ::: "memory");
+        }
+        md_f4 acc[kG];
+#pragma unroll
+        for (int gq = 0; gq < kG; ++gq) acc[gq] = accA[gq] + accB[gq];
+        // the epilogue's lane finishes output rho = lane >> 4 of the quad (the reads above were for output lane & 3)
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        const int rho = lane_l >> 4;
+        const int i_ep = cur.i_first + c + 4 * qq * upc + rho * upc;
+        const uint32_t rel_ep = (uint32_t)(sb + cur.lo + rho * a.down);
+        mm_fold_rotate_stage<kG, R>(acc, lane_l, i_ep <= i_last, rel_ep, my_p0, my_fw, ys, a.ycap, i_ep - i_base);
+      } else if (kCanHold && hold) {
         float2 A[RH], B[RH];
 #pragma unroll
         for (int r = 0; r < RH; ++r) { A[r] = make_float2(0.f, 0.f); B[r] = make_float2(0.f, 0.f); }
@@ -443,17 +620,30 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
         //  so xp[-16*jj] cost one VALU address add per read)
         constexpr int kTop = 16 * ((NJ > 0 ? NJ : 1) - 1);
         const lds_cf2 xr = to_lds(xp - kTop);
+        // Where the taps leave few registers (three RX x 21 tap pairs = 126 of 168) the reads of x come in GROUPS of kXG with a
+        // compiler fence between them: left alone hipcc hoists all 21 reads to the top (42 more registers) and spills.
+        constexpr int kNJ = kCanHold ? NJ : 1;
+        constexpr int kXG = (Sh::kBudget - 2 * RH * NJ < 64) ? MD_XGROUP : kNJ;
 #pragma unroll
-        for (int jj = 0; jj < (kCanHold ? NJ : 1); ++jj) {
-          const float2 xv = lds_ld(xr, kTop - 16 * jj);
+        for (int j0 = 0; j0 < kNJ; j0 += kXG) {
+          float2 xg[kXG];
 #pragma unroll
-          for (int r = 0; r < RH; ++r) {
-            const float2 gg = greg[r][jj];
-            A[r].x = fmaf(gg.x, xv.x, A[r].x);
-            A[r].y = fmaf(gg.y, xv.x, A[r].y);
-            B[r].x = fmaf(gg.x, xv.y, B[r].x);
-            B[r].y = fmaf(gg.y, xv.y, B[r].y);
+          for (int u = 0; u < kXG; ++u)
+            if (j0 + u < kNJ) xg[u] = lds_ld(xr, kTop - 16 * (j0 + u));
+#pragma unroll
+          for (int u = 0; u < kXG; ++u) {
+            if (j0 + u >= kNJ) continue;
+            const float2 xv = xg[u];
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+              const float2 gg = greg[r][j0 + u];
+              A[r].x = fmaf(gg.x, xv.x, A[r].x);
+              A[r].y = fmaf(gg.y, xv.x, A[r].y);
+              B[r].x = fmaf(gg.x, xv.y, B[r].x);
+              B[r].y = fmaf(gg.y, xv.y, B[r].y);
+            }
           }
+          if (kXG < kNJ && j0 + kXG < kNJ) asm volatile("" ::: "memory");
         }
         fold_rotate_stage<RH>(A, B, hold_rcount, hold_rbase, s, valid, rel, my_p0, my_fw, ys, a.ycap, i - i_base);
       } else {
@@ -512,7 +702,7 @@ __global__ __launch_bounds__(1024) void mixdec_kernel(const MixDecArgs a) {
   if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
 }
 
-template <int R, int NJ>
+template <int R, int NJ, int TPB, int NHX, int MM>
 int launch_rj(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
   // the attribute is per (function, device): one bit per device, guarded against contexts on
   // other threads / other devices of the same process (P.GPU_DEVICE, cfg.device)
@@ -523,40 +713,91 @@ int launch_rj(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_
     PYSDR_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(attr_mu);
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mixdec_kernel<R, NJ>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mixdec_kernel<R, NJ, TPB, NHX, MM>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) {
-        set_last_error("hipFuncSetAttribute(mixdec<%d,%d>): %s", R, NJ, hipGetErrorString(e));
+        set_last_error("hipFuncSetAttribute(mixdec<%d,%d,%d,%d,%d>): %s", R, NJ, TPB, NHX, MM, hipGetErrorString(e));
         return PYSDR_ERR_HIP;
       }
       attr_done |= 1ull << (dev & 63);
     }
   }
-  hipLaunchKernelGGL((mixdec_kernel<R, NJ>), dim3(grid), dim3(threads), lds, st, a);
+  if (threads > TPB) threads = TPB;
+  hipLaunchKernelGGL((mixdec_kernel<R, NJ, TPB, NHX, MM>), dim3(grid), dim3(threads), lds, st, a);
   PYSDR_HIP_CHECK(hipGetLastError());
   return PYSDR_OK;
 }
 
-template <int R>
-int launch_r(const MixDecArgs& a, int threads, int grid, size_t lds, hipStream_t st) {
+// Which instantiation a decimator's shape runs on -- ONE table for the launch and for the host's plan (mixdec_variant).
+//   f.template go<R, NJ, TPB, NHX, MM>()
+template <int R, class F>
+int md_dispatch_r(int up, int kpad, int threads, F& f) {
   // 255-tap prototypes at UP = 3 (the BASELINE configurations) have 96 taps per branch
-  if (a.kpad == 96) return launch_rj<R, 6>(a, threads, grid, lds, st);
+  if (kpad == 96) return f.template go<R, 6, 1024, 0, 0>();
   // single-RX long filters: the 255-tap video filter of the broadcast-FM front end (UP = 1, 256
   // taps in one branch) and the reference's default 1001-tap prototype at UP = 3 (336 per branch)
   if constexpr (R == 1) {
     // the fs1 -> FS_OUT resampler of broadcast FM: 24/125 with 64 taps per branch (more branches than waves: generic
     // task order, but a compile-time tap loop)
-    if (a.kpad == 64) return launch_rj<R, 4>(a, threads, grid, lds, st);
-    if (a.kpad == 256) return launch_rj<R, 16>(a, threads, grid, lds, st);
-    if (a.kpad == 336) return launch_rj<R, 21>(a, threads, grid, lds, st);
+    if (kpad == 64) return f.template go<R, 4, 1024, 0, 0>();
+    if (kpad == 256) return f.template go<R, 16, 1024, 0, 0>();
+    if (kpad == 336) return f.template go<R, 21, 1024, 0, 0>();
   }
-  return launch_rj<R, 0>(a, threads, grid, lds, st);
+  // the default 1001-tap prototype at UP = 3 with several sub-receivers (8 and 4 MS/s -> 48 kHz: FT8tri, TEST): 12 waves that
+  // hold their taps.  Only with the default thread count: pysdr_set_tile(threads) asks for the generic form (A/B).
+  if constexpr (R >= 2 && R <= 6) {
+    if (kpad == 336 && up == 3 && threads == 1024) {
+#if MD_LONG_MM
+      if constexpr (R <= 4) return f.template go<R, 21, 768, 0, 1>();
+#endif
+      return f.template go<R, 21, MD_LONG_TPB, (MD_LONG_NH <= R ? MD_LONG_NH : R), 0>();
+    }
+  }
+  return f.template go<R, 0, 1024, 0, 0>();
 }
+template <class F>
+int md_dispatch(int nrx, int up, int kpad, int threads, F& f) {
+  switch (nrx) {
+    case 1: return md_dispatch_r<1>(up, kpad, threads, f);
+    case 2: return md_dispatch_r<2>(up, kpad, threads, f);
+    case 3: return md_dispatch_r<3>(up, kpad, threads, f);
+    case 4: return md_dispatch_r<4>(up, kpad, threads, f);
+    case 5: return md_dispatch_r<5>(up, kpad, threads, f);
+    case 6: return md_dispatch_r<6>(up, kpad, threads, f);
+    case 7: return md_dispatch_r<7>(up, kpad, threads, f);
+    case 8: return md_dispatch_r<8>(up, kpad, threads, f);
+    default: set_last_error("mixdec: nrx=%d", nrx); return PYSDR_ERR_ARG;
+  }
+}
+
+struct MdLaunch {
+  const MixDecArgs& a; int threads, grid; size_t lds; hipStream_t st;
+  template <int R, int NJ, int TPB, int NHX, int MM> int go() { return launch_rj<R, NJ, TPB, NHX, MM>(a, threads, grid, lds, st); }
+};
+struct MdQuery {
+  MixdecVariant v;
+  template <int R, int NJ, int TPB, int NHX, int MM> int go() {
+    typedef MdShape<R, NJ, TPB, NHX, MM> Sh;
+    v.tpb = TPB;
+    v.can_hold = Sh::kCanHold ? 1 : 0;
+    v.nh = Sh::NH;
+    return PYSDR_OK;
+  }
+};
 
 }  // namespace
 
 size_t mixdec_lds_bytes(const MixDecArgs& a) {
-  return (2 * (size_t)a.tile_cap + (size_t)a.nrx * a.up * a.kpad + (size_t)a.nrx * a.ycap) * sizeof(float2);
+  return (2 * (size_t)a.tile_cap + (a.taps_lds ? (size_t)a.nrx * a.up * a.kpad : 0) + (size_t)a.nrx * a.ycap) * sizeof(float2);
+}
+
+// What the host's plan needs to know about the instantiation a shape runs on: its thread count, and whether its waves hold
+// their taps in registers when there are at least up * nh of them and tile_out is a multiple of up (then the taps need no LDS).
+MixdecVariant mixdec_variant(int nrx, int up, int kpad, int threads) {
+  MdQuery q;
+  q.v.tpb = 1024; q.v.can_hold = 0; q.v.nh = 1;
+  (void)md_dispatch(nrx, up, kpad, threads, q);
+  return q.v;
 }
 
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st) {
@@ -567,17 +808,8 @@ int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t st) {
   }
   if (grid > a.ntiles) grid = a.ntiles;
   if (grid < 1) grid = 1;
-  switch (a.nrx) {
-    case 1: return launch_r<1>(a, threads, grid, lds, st);
-    case 2: return launch_r<2>(a, threads, grid, lds, st);
-    case 3: return launch_r<3>(a, threads, grid, lds, st);
-    case 4: return launch_r<4>(a, threads, grid, lds, st);
-    case 5: return launch_r<5>(a, threads, grid, lds, st);
-    case 6: return launch_r<6>(a, threads, grid, lds, st);
-    case 7: return launch_r<7>(a, threads, grid, lds, st);
-    case 8: return launch_r<8>(a, threads, grid, lds, st);
-    default: set_last_error("mixdec: nrx=%d", a.nrx); return PYSDR_ERR_ARG;
-  }
+  MdLaunch l{a, threads, grid, lds, st};
+  return md_dispatch(a.nrx, a.up, a.kpad, threads, l);
 }
 
 }  // namespace pysdr

@@ -498,6 +498,68 @@ def test_device_batch_at_an_odd_sample_offset(name):
     assert relerr(odd[1], want) <= TOL          # the baseband IQ (the stage under test; the NFM audio's start-up has its own allowance)
 
 
+@pytest.mark.parametrize("name", ["FT8TRI", "TEST2RX"])
+def test_reference_launch_scripts_multi_rx_1001_taps(name):
+    """What pySDR really runs: FT8tri:47-74 (8 MS/s, three USB sub-receivers at 18100 / 21074 / 24915 kHz,
+    -vid_bw 45 -af_bw 5) and TEST:13-32 (4 MS/s, two NFM sub-receivers 600 kHz apart), filter length at its default 1001
+    (params.py:134): every sample of ragged and whole chunks against the oracle."""
+    cfg = so.CONFIGS[name]
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    run_both(cfg, [L, L, 1000, 7, L - 13, 2 * L + 5, 333], seed=41)
+
+
+@pytest.mark.parametrize("grid", [0, 3])
+@pytest.mark.parametrize("name,nrx", [("FT8TRI", 3), ("TEST2RX", 2), ("FT8TRI", 2), ("C3", 4), ("C3", 6)])
+def test_multi_rx_long_prototype_does_not_depend_on_the_cut(name, nrx, grid, monkeypatch):
+    """The tap-holding shapes of the vector mix + decimate kernel (mixdec.hip, 768 threads: 2 - 6 sub-receivers, 1001 taps at
+    UP = 3; 4 and 6 RX on C3's stream re-run with the long prototype): chunk by chunk == one batch == cut at random
+    places, bit for bit, for every sub-receiver -- at the default grid and held to three workgroups (many tiles per
+    workgroup: the output stage's flush cadence, peaks carried across chunks) -- and the baseband IQ equals the oracle."""
+    if grid:
+        monkeypatch.setenv("PYSDR_TUNING", "1")
+        monkeypatch.setenv("PYSDR_MIXDEC_GRID", str(grid))
+    cfg = dict(so.CONFIGS[name], ntaps_dec=1001)
+    if name == "C3":
+        import bench
+        cfg['rx'] = bench.RX6[:nrx]
+    else:
+        cfg['rx'] = cfg['rx'][:nrx]
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    B = 10
+    x = so.synth_iq(cfg, B * L, 33)
+    P1, g1 = make_gpu_receivers(cfg)
+    am1, iq1 = [[] for _ in g1], [[] for _ in g1]
+    for k in range(B):
+        for i, rx in enumerate(g1):
+            am1[i].append(rx.demod_data(x[k * L:(k + 1) * L]).copy())
+            iq1[i].append(rx.iq.copy())
+    P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    ctx = P2._pysdr_stream
+    ctx.process_batch(x, B, L, on_device=False)
+    pk_batch = None
+    for i in range(len(g2)):
+        am, iq, cn, pk = ctx.fetch(i, B)
+        pk_batch = pk
+        assert list(cn) == [len(a) for a in am1[i]]
+        assert np.array_equal(iq, np.concatenate(iq1[i])), i
+        assert np.array_equal(am, np.concatenate(am1[i])), i
+    want_pk = [np.max(np.abs(x[k * L:(k + 1) * L].astype(np.complex128)) ** 2) for k in range(B)]
+    assert np.allclose(pk_batch, want_pk, rtol=1e-6)
+    rng = np.random.default_rng(6)
+    cuts = np.sort(rng.choice(np.arange(1, B * L), 7, replace=False))
+    P3, g3 = make_gpu_receivers(cfg, max_batch_chunks=4)
+    iq3 = [[] for _ in g3]
+    for a, b in zip(np.r_[0, cuts], np.r_[cuts, B * L]):
+        for c in range(a, b, 4 * L):                      # a call may not exceed the context's capacity
+            for i, rx in enumerate(g3):
+                rx.demod_data(x[c:min(c + 4 * L, b)]); iq3[i].append(rx.iq.copy())
+    for i in range(len(g3)):
+        assert np.array_equal(np.concatenate(iq1[i]), np.concatenate(iq3[i])), i
+    for i, o in enumerate(so.make_receivers(cfg, np.float32)):
+        want = np.concatenate([(o.demod_data(x[k * L:(k + 1) * L]), o.iq.copy())[1] for k in range(B)])
+        assert relerr(np.concatenate(iq1[i]), want) <= TOL, (i, o.mode)
+
+
 def test_long_prototype_1001_taps_and_10msps():
     cfg = dict(so.CONFIGS['C2'], fs=10e6, ntaps_dec=1001,
                carriers=[dict(f=455e3, kind='fm', amp=0.3, tone=1000.0, dev=3000.0)])
@@ -882,11 +944,13 @@ def test_waterfall_backend_equals_the_executed_reference_text():
     assert seen == 4
 
 
-@pytest.mark.parametrize("name,B", [("C3", 2048), ("C2", 2048), ("C1", 4096)])
+@pytest.mark.parametrize("name,B", [("C3", 2048), ("C2", 2048), ("C1", 4096), ("FT8TRI", 2048), ("TEST2RX", 4096)])
 def test_full_size_batch_is_independent_of_how_it_is_cut(name, B):
     """BASELINE full size, every narrow-band configuration at the batch bench.py times (C3: 2048 chunks x
     170666 samples = 2.8 GB resident in HBM, 4 RX; C2: the same stream, 1 RX NBFM; C1: 4096 chunks x 43690
-    at 2.048 MS/s with the reference's default 1001-tap prototype): one launch sequence over the whole batch
+    at 2.048 MS/s with the reference's default 1001-tap prototype; FT8TRI / TEST2RX: the reference's own
+    multi-receiver launch scripts -- 8 MS/s x 3 RX USB, 4 MS/s x 2 RX NFM, 1001 taps, FT8tri:47-74, TEST:30 --
+    on the tap-holding long-prototype shapes of mixdec.hip): one launch sequence over the whole batch
     = two over its halves, bit for bit (audio, baseband IQ, per-chunk output counts and raw peaks), the
     last chunks of the batch equal its first ones' continuation (the input repeats every 8 chunks), and the
     first chunks equal the oracle."""
