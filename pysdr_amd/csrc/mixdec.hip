@@ -183,6 +183,75 @@ __device__ __forceinline__ void stage_tile(const MixDecArgs& a, const Tile& t, f
   }
 }
 
+// The raw-peak scan of one tile as a function, for the matrix-core shapes (which call it at different points of the tile loop);
+// the same code as the block in mixdec_kernel's tile loop, which the vector shapes keep inline: their code generation is pinned
+// by measurements.  (Interleaving the copies of the next tile with this scan -- one 1 KiB copy, one pair per lane, ... -- so that
+// the 69 copy instructions of a tile do not queue up in front of the CU's address unit measured neutral: ft8tri 0.674 / 0.666
+// fused against 0.688 / 0.672 plain, profiles/r06_long_multirx_variants.txt.)
+__device__ __forceinline__ void peak_scan(const MixDecArgs& a, const Tile& cur, const float2* xs, int tid, int nthr, int lane,
+                                          float& pk_run, uint32_t& pk_chunk, int& pk_lo, int& pk_hi) {
+  if (cur.own_hi >= cur.own_lo) {
+    const float4* xv = reinterpret_cast<const float4*>(xs);
+    const int e_lo = cur.own_lo & ~1, e_hi = cur.own_hi | 1;
+    if (e_lo >= pk_lo && e_hi <= pk_hi) {
+      // whole pairs inside the current chunk: a maximum does not mind the neighbour
+      // sample being counted by two tiles
+      const int p_hi = (e_hi - cur.lo) >> 1;
+      int pi = ((e_lo - cur.lo) >> 1) + tid;
+      // four reads in flight per thread: a tile is 4-5 trips of this loop, and one read per trip
+      // put 4-5 LDS latencies in front of every tile's dot products (0.04 of C1's 0.43 ms)
+      for (; pi + 3 * nthr <= p_hi; pi += 4 * nthr) {
+        const float4 v0 = xv[pi], v1 = xv[pi + nthr], v2 = xv[pi + 2 * nthr], v3 = xv[pi + 3 * nthr];
+        const float m0 = fmaxf(fmaf(v0.x, v0.x, v0.y * v0.y), fmaf(v0.z, v0.z, v0.w * v0.w));
+        const float m1 = fmaxf(fmaf(v1.x, v1.x, v1.y * v1.y), fmaf(v1.z, v1.z, v1.w * v1.w));
+        const float m2 = fmaxf(fmaf(v2.x, v2.x, v2.y * v2.y), fmaf(v2.z, v2.z, v2.w * v2.w));
+        const float m3 = fmaxf(fmaf(v3.x, v3.x, v3.y * v3.y), fmaf(v3.z, v3.z, v3.w * v3.w));
+        pk_run = fmaxf(fmaxf(pk_run, fmaxf(m0, m1)), fmaxf(m2, m3));
+      }
+      for (; pi <= p_hi; pi += nthr) {
+        const float4 v = xv[pi];
+        pk_run = fmaxf(pk_run, fmaxf(fmaf(v.x, v.x, v.y * v.y), fmaf(v.z, v.z, v.w * v.w)));
+      }
+    } else {
+      // the tile straddles chunk boundaries (or the odd end of the call): one masked scan
+      // per chunk it touches
+      const uint32_t c_lo = div_magic((uint32_t)cur.own_lo, a.chunk_len, a.magic_chunk);
+      const uint32_t c_hi = div_magic((uint32_t)cur.own_hi, a.chunk_len, a.magic_chunk);
+      for (uint32_t c = c_lo; c <= c_hi; ++c) {
+        const long long cb = (long long)c * a.chunk_len;
+        const int s_lo = cur.own_lo > cb ? cur.own_lo : (int)cb;
+        const long long ce = cb + a.chunk_len - 1;
+        const int s_hi = cur.own_hi < ce ? cur.own_hi : (int)ce;
+        const int p_lo = (s_lo - cur.lo) >> 1, p_hi = (s_hi - cur.lo) >> 1;
+        if (c != pk_chunk) {
+          pk_run = wave_max63(pk_run);
+          if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
+          pk_run = 0.f;
+          pk_chunk = c;
+        }
+        // interior pairs need no masking; the two edge pairs are handled by one lane
+        for (int pi = p_lo + 1 + tid; pi < p_hi; pi += nthr) {
+          const float4 v = xv[pi];
+          pk_run = fmaxf(pk_run, fmaxf(fmaf(v.x, v.x, v.y * v.y), fmaf(v.z, v.z, v.w * v.w)));
+        }
+        if (tid == 0) {
+          const float4 v0 = xv[p_lo], v1 = xv[p_hi];
+          const int r0 = cur.lo + 2 * p_lo, r1 = cur.lo + 2 * p_hi;
+          if (r0 >= s_lo) pk_run = fmaxf(pk_run, fmaf(v0.x, v0.x, v0.y * v0.y));
+          if (r0 + 1 <= s_hi) pk_run = fmaxf(pk_run, fmaf(v0.z, v0.z, v0.w * v0.w));
+          if (r1 >= s_lo) pk_run = fmaxf(pk_run, fmaf(v1.x, v1.x, v1.y * v1.y));
+          if (r1 + 1 <= s_hi) pk_run = fmaxf(pk_run, fmaf(v1.z, v1.z, v1.w * v1.w));
+        }
+      }
+      const long long cb = (long long)pk_chunk * a.chunk_len;
+      const long long ce = cb + a.chunk_len < (long long)a.n_total ? cb + a.chunk_len : (long long)a.n_total;
+      pk_lo = (int)cb;
+      pk_hi = (int)ce - 1;
+    }
+  }
+
+}
+
 // Fold the 16 lanes of each row for N sub-receivers (all 2N partial sums advance one DPP step
 // at a time, so consecutive instructions are independent: no DPP hazard stalls), then lane
 // s < ncount of every row rotates RX rbase + s by its LO phase and puts the sample into the LDS
@@ -236,8 +305,21 @@ __device__ __forceinline__ void fold_rotate_stage(const float2 (&A)[N], const fl
 #ifndef MD_LONG_MM
 #define MD_LONG_MM 1         // the long-prototype shapes of 2 - 4 sub-receivers on the matrix cores (A/B: 0 = vector form)
 #endif
+#ifndef MD_MM_EPCONST
+#define MD_MM_EPCONST -1     // matrix-core shapes: the epilogue lane's LO constants looked up per task (1) or held in registers (0); -1: held
+                             // up to 2 RX (hipcc then hoists more of the task's index arithmetic out of the tile loop: test2rx 0.55 -> 0.58), looked up from 3 (registers)
+#endif
+#ifndef MD_MM_ONEACC
+#define MD_MM_ONEACC 1       // matrix-core shapes with >= 2 RX pairs: one accumulator per pair (0: one per chain; A/B)
+#endif
+#ifndef MD_PHASE_ORDERS
+#define MD_PHASE_ORDERS 2    // matrix-core shapes: how many different phase orders the three waves of a SIMD run (A/B: 1, 2, 3)
+#endif
 #ifndef MD_LONG_NH
 #define MD_LONG_NH 0         // their RX groups: 0 = as few as the registers allow, n = n groups (A/B)
+#endif
+#ifndef MD_XAHEAD
+#define MD_XAHEAD 8          // matrix-core shapes: reads of x in flight ahead of the MFMAs (A/B)
 #endif
 #ifndef MD_XGROUP
 #define MD_XGROUP 7          // x reads per group of the register-tight shapes (A/B)
@@ -376,6 +458,7 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
   // of the sub-receivers only, and walks the quads with stride nwaves / (UP*NH).
   typedef MdShape<R, NJ, TPB, NHX, MM> Sh;
   constexpr bool kMm = Sh::kMm;
+  constexpr bool kEpConst = (MD_MM_EPCONST < 0) ? (R >= 3) : (MD_MM_EPCONST != 0);
   constexpr int NH = Sh::NH;                            // RX groups (halves at 1024 threads)
   constexpr int RH = Sh::RH;                            // RX per task in hold mode
   constexpr bool kCanHold = Sh::kCanHold;
@@ -400,12 +483,14 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
   uint32_t my_p0 = 0u, my_fw = 0u;
   int v_gup = g * a.up, v_gdown = g * a.down - s;
   if (kMm) {
-    // the lane of the matrix-core epilogue: row rho = lane >> 4 finishes output rho of the quad, (pair q, column j) RX 2 q + j / 2
-    const int rx = 2 * ((lane >> 2) & 3) + ((lane & 3) >> 1);
+    if (!kEpConst) {     // the lane of the matrix-core epilogue: row rho = lane >> 4 finishes output rho, (pair q, column j) RX 2 q + j / 2
+      const int rx = 2 * ((lane >> 2) & 3) + ((lane & 3) >> 1);
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (rx == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; }
-    asm volatile("" : "+v"(my_p0), "+v"(my_fw), "+v"(v_gup), "+v"(v_gdown));
+      for (int r = 0; r < R; ++r)
+        if (rx == r) { my_p0 = a.phase0[r]; my_fw = a.fword[r]; }
+      asm volatile("" : "+v"(my_p0), "+v"(my_fw));
+    }
+    asm volatile("" : "+v"(v_gup), "+v"(v_gdown));
   } else if (!kTight) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -468,9 +553,22 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
     __syncthreads();
     PYSDR_STAMP(2);
     Tile nxt = cur;
-    if (tb + 1 < t_end) {
+    // Matrix-core shapes: the three waves that share a SIMD (w, w + 4, w + 8) would run their MFMA chains at the same time, and
+    // the matrix pipe then idle through everybody's copy / peak phases (scripts/diag/mixdec_stamps.py ft8tri,
+    // profiles/r06_ft8tri_stamps.txt: the dot-product phase of a task took 2800 cycles where 84 MFMAs alone take ~900).
+    // Each of the three takes the phases of a tile in its own order:  0: copies, peak, DOTS   1: DOTS, copies, peak
+    // 2: copies, DOTS, peak   (MD_PHASE_ORDERS = 1: all of them order 0, 2: orders 0 1 0; A/B)
+    const int ord = (kMm && MD_PHASE_ORDERS > 1) ? ((MD_PHASE_ORDERS == 2) ? ((wave >> 2) & 1) : (wave >> 2) % 3) : 0;
+    const bool have_next = tb + 1 < t_end;
+    if (have_next) {
       nxt = (tb + 2 < a.ntiles) ? tile_advance(a, cur) : tile_geometry(a, tb + 1);
-      if (!PYSDR_DBG(a, 2)) stage_tile(a, nxt, xn, tid, nthr);
+      if constexpr (!kMm) {
+        if (!PYSDR_DBG(a, 2)) stage_tile(a, nxt, xn, tid, nthr);
+      }
+    }
+    if constexpr (kMm) {
+      if (ord != 1 && have_next && !PYSDR_DBG(a, 2)) stage_tile(a, nxt, xn, tid, nthr);
+      if (ord == 0 && !PYSDR_DBG(a, 4)) peak_scan(a, cur, xs, tid, nthr, lane, pk_run, pk_chunk, pk_lo, pk_hi);
     }
     PYSDR_STAMP(3);
 
@@ -478,7 +576,7 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
     // The running maximum of a chunk stays in a register across tiles; the atomic is only
     // issued when the run moves on to another chunk (and once at the end): same-address
     // atomics are slow, and one per tile would sit in vmcnt and stall the next dma_wait.
-    if (cur.own_hi >= cur.own_lo && !PYSDR_DBG(a, 4)) {
+    if (!kMm && cur.own_hi >= cur.own_lo && !PYSDR_DBG(a, 4)) {
       const float4* xv = reinterpret_cast<const float4*>(xs);
       const int e_lo = cur.own_lo & ~1, e_hi = cur.own_hi | 1;
       if (e_lo >= pk_lo && e_hi <= pk_hi) {
@@ -578,40 +676,65 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
       // y = (A.re - B.im, A.im + B.re)
       if (kCanHold && hold && kMm) {
         // ---- matrix cores: 16 blocks = 16 tap residues, rows = the quad's outputs, columns = (Re, Im) of an RX pair
-        md_f4 accA[kG], accB[kG];
+        // G = 1: the Re x chain and the Im x chain have an accumulator each (a chain on ONE accumulator issues every 15 cycles
+        // instead of 8: scripts/diag/mfma4x4_probe.hip); G >= 2: the pairs alternate, one accumulator per pair is enough
+        constexpr int kNA = (kG == 1 || !MD_MM_ONEACC) ? 2 * kG : kG;
+        md_f4 accs[kNA];
 #pragma unroll
-        for (int gq = 0; gq < kG; ++gq) { accA[gq] = (md_f4){0.f, 0.f, 0.f, 0.f}; accB[gq] = (md_f4){0.f, 0.f, 0.f, 0.f}; }
+        for (int q = 0; q < kNA; ++q) accs[q] = (md_f4){0.f, 0.f, 0.f, 0.f};
         constexpr int kTop = 16 * ((NJ > 0 ? NJ : 1) - 1);
         const lds_cf2 xr = to_lds(xp - kTop);
         constexpr int kNJ = kMm ? NJ : 1;
-        constexpr int kXG = MD_XGROUP;          // reads of x per group (a compiler fence between groups: see below)
+        // The reads of x go through a RING of kXA registers pairs, kXA steps ahead of the MFMAs that use them, pinned by
+        // sched_group_barrier: left alone hipcc reuses four registers and puts a full s_waitcnt lgkmcnt(0) in front of every
+        // four MFMAs -- one exposed LDS latency per 40 cycles of matrix work (the same finding as mixdec_mfma.hip's consumer).
+        constexpr int kXA = (MD_XAHEAD < kNJ) ? MD_XAHEAD : kNJ;
+        float2 ring[kXA];
 #pragma unroll
-        for (int j0 = 0; j0 < kNJ; j0 += kXG) {
-          float2 xg[kXG];
+        for (int u = 0; u < kXA; ++u) ring[u] = lds_ld(xr, kTop - 16 * u);
+        __builtin_amdgcn_sched_group_barrier(0x100, kXA, 0);
 #pragma unroll
-          for (int u = 0; u < kXG; ++u)
-            if (j0 + u < kNJ) xg[u] = lds_ld(xr, kTop - 16 * (j0 + u));
-#pragma unroll
-          for (int u = 0; u < kXG; ++u) {
-            if (j0 + u >= kNJ) continue;
+        for (int jj = 0; jj < kNJ; ++jj) {
+          const float2 xv = ring[jj % kXA];
+          if constexpr (kNA == 2 * kG) {
 #pragma unroll
             for (int gq = 0; gq < kG; ++gq) {
-              accA[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xg[u].x, bre[gq][j0 + u], accA[gq], 0, 0, 0);
-              accB[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xg[u].y, bim[gq][j0 + u], accB[gq], 0, 0, 0);
+              accs[2 * gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.x, bre[gq][jj], accs[2 * gq], 0, 0, 0);
+              accs[2 * gq + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.y, bim[gq][jj], accs[2 * gq + 1], 0, 0, 0);
             }
+          } else {
+#pragma unroll
+            for (int gq = 0; gq < kG; ++gq) accs[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.x, bre[gq][jj], accs[gq], 0, 0, 0);
+#pragma unroll
+            for (int gq = 0; gq < kG; ++gq) accs[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.y, bim[gq][jj], accs[gq], 0, 0, 0);
           }
-          if (j0 + kXG < kNJ) asm volatile("" ::: "memory");
+          if (jj + kXA < kNJ) ring[jj % kXA] = lds_ld(xr, kTop - 16 * (jj + kXA));
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * kG, 0);
+          if (jj + kXA < kNJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         md_f4 acc[kG];
+        if constexpr (kNA == 2 * kG) {
 #pragma unroll
-        for (int gq = 0; gq < kG; ++gq) acc[gq] = accA[gq] + accB[gq];
+          for (int gq = 0; gq < kG; ++gq) acc[gq] = accs[2 * gq] + accs[2 * gq + 1];
+        } else {
+#pragma unroll
+          for (int gq = 0; gq < kG; ++gq) acc[gq] = accs[gq];
+        }
         // the epilogue's lane finishes output rho = lane >> 4 of the quad (the reads above were for output lane & 3)
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));
         const int rho = lane_l >> 4;
         const int i_ep = cur.i_first + c + 4 * qq * upc + rho * upc;
         const uint32_t rel_ep = (uint32_t)(sb + cur.lo + rho * a.down);
-        mm_fold_rotate_stage<kG, R>(acc, lane_l, i_ep <= i_last, rel_ep, my_p0, my_fw, ys, a.ycap, i_ep - i_base);
+        // (its RX's LO constants are looked up here, per task: kept in registers across the tile loop they were what spilled at 4 RX)
+        uint32_t ep_p0 = my_p0, ep_fw = my_fw;
+        if (kEpConst) {
+          const int rx = 2 * ((lane_l >> 2) & 3) + ((lane_l & 3) >> 1);
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (rx == r) { ep_p0 = a.phase0[r]; ep_fw = a.fword[r]; }
+        }
+        mm_fold_rotate_stage<kG, R>(acc, lane_l, i_ep <= i_last, rel_ep, ep_p0, ep_fw, ys, a.ycap, i_ep - i_base);
       } else if (kCanHold && hold) {
         float2 A[RH], B[RH];
 #pragma unroll
@@ -671,6 +794,10 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
         }
         fold_rotate_stage<R>(A, B, R, 0, s, valid, rel, my_p0, my_fw, ys, a.ycap, i - i_base);
       }
+    }
+    if constexpr (kMm) {
+      if (ord == 1 && have_next && !PYSDR_DBG(a, 2)) stage_tile(a, nxt, xn, tid, nthr);
+      if (ord != 0 && !PYSDR_DBG(a, 4)) peak_scan(a, cur, xs, tid, nthr, lane, pk_run, pk_chunk, pk_lo, pk_hi);
     }
     PYSDR_STAMP(5);
     // ---- flush the output stage: RX r, 64 outputs per wave-store (512 contiguous bytes)
@@ -748,9 +875,12 @@ int md_dispatch_r(int up, int kpad, int threads, F& f) {
   if constexpr (R >= 2 && R <= 6) {
     if (kpad == 336 && up == 3 && threads == 1024) {
 #if MD_LONG_MM
+      // 2 - 4 RX: 12 waves; 5, 6 RX (three RX pairs = 126 registers of tap operands): 8 waves of up to 256 registers
       if constexpr (R <= 4) return f.template go<R, 21, 768, 0, 1>();
-#endif
+      else return f.template go<R, 21, 512, 0, 1>();
+#else
       return f.template go<R, 21, MD_LONG_TPB, (MD_LONG_NH <= R ? MD_LONG_NH : R), 0>();
+#endif
     }
   }
   return f.template go<R, 0, 1024, 0, 0>();

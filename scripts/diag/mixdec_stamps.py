@@ -11,12 +11,21 @@ from pysdr_amd import _lib, sig_proc
 from pysdr_amd.params import RunTimeParams
 from pysdr_amd.synth import CONFIGS, synth_iq
 wl = sys.argv[1] if len(sys.argv) > 1 else 'c1'
-B = int(sys.argv[2]) if len(sys.argv) > 2 else (4096 if wl == 'c1' else 2048)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else (4096 if wl in ('c1', 'test2rx') else 2048)
 lib = _lib.lib()
 if wl == 'c1':
     cfg = CONFIGS['C1']
     P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[7e6], mode='AM', nfilt=cfg['ntaps_dec'], max_batch_chunks=B)
     g = sig_proc.Receiver(P, 100e3, 0, '1')
+elif wl in ('ft8tri', 'test2rx'):
+    cfg = CONFIGS[wl.upper()]
+    P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[14e6] * len(cfg['rx']), mode=cfg['rx'][0]['mode'], nfilt=cfg['ntaps_dec'], max_batch_chunks=B)
+    gs = []
+    for i, r in enumerate(cfg['rx']):
+        P.VIDEO_BW = r['video_bw']
+        gs.append(sig_proc.Receiver(P, r['frq'], i, str(i + 1)))
+        gs[-1].mode = r['mode']
+    g = gs[0]
 elif wl == 'c3':
     cfg = CONFIGS['C3']
     P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[146e6], mode='USB', nfilt=255, max_batch_chunks=B)
