@@ -15,14 +15,14 @@ run_cfg() {  # name, pmc(0/1), bench args...
   local name=$1 pmc=$2; shift 2
   mkdir -p "$OUT/$name"
   CFG_NAMES+=("$name"); CFG_ARGS+=("$* ${PYSDR_PSD_STREAMS:+@1stream}")
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name/kt" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify > "$OUT/$name/bench_kt.json" 2> "$OUT/$name/kt.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name/kt" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --full-line > "$OUT/$name/bench_kt.json" 2> "$OUT/$name/kt.err"
   if [ "$pmc" = 1 ]; then
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$name/pmc_fetch" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 3 --warmup 1 > "$OUT/$name/pmc_fetch.json" 2> "$OUT/$name/pmc_fetch.err"
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$name/pmc_write" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 3 --warmup 1 > "$OUT/$name/pmc_write.json" 2> "$OUT/$name/pmc_write.err"
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$name/pmc_fetch" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --full-line --steps 3 --warmup 1 > "$OUT/$name/pmc_fetch.json" 2> "$OUT/$name/pmc_fetch.err"
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$name/pmc_write" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --full-line --steps 3 --warmup 1 > "$OUT/$name/pmc_write.json" 2> "$OUT/$name/pmc_write.err"
     # wave-level counters of the same kernels (LDS bank conflicts, VALU / LDS activity, parked cycles)
-    rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/$name/pmc_sq" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 3 --warmup 1 > "$OUT/$name/pmc_sq.json" 2> "$OUT/$name/pmc_sq.err"
+    rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/$name/pmc_sq" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --full-line --steps 3 --warmup 1 > "$OUT/$name/pmc_sq.json" 2> "$OUT/$name/pmc_sq.err"
     # the matrix pipe (mixdec_mfma.hip: C1, C4)
-    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/$name/pmc_mfma" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --steps 3 --warmup 1 > "$OUT/$name/pmc_mfma.json" 2> "$OUT/$name/pmc_mfma.err"
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/$name/pmc_mfma" -- python3 bench.py "$@" --no-cpu-baseline --no-host-fed --no-other-configs --no-verify --full-line --steps 3 --warmup 1 > "$OUT/$name/pmc_mfma.json" 2> "$OUT/$name/pmc_mfma.err"
   fi
   # keep only the small summaries (the per-dispatch traces are tens of MB)
   find "$OUT/$name" -name "*kernel_trace.csv" -delete
@@ -46,9 +46,9 @@ python3 scripts/summarize_profiles.py "$OUT" profiles "$TAG" > "$OUT/summarize.l
 for i in "${!CFG_NAMES[@]}"; do
   name=${CFG_NAMES[$i]}; args=${CFG_ARGS[$i]}
   if [[ "$args" == *@1stream* ]]; then
-    PYSDR_TUNING=1 PYSDR_PSD_STREAMS=1 python3 bench.py ${args%@1stream} --no-other-configs > "$OUT/$name/bench.json" 2> "$OUT/$name/bench.err"
+    PYSDR_TUNING=1 PYSDR_PSD_STREAMS=1 python3 bench.py ${args%@1stream} --no-other-configs --full-line > "$OUT/$name/bench.json" 2> "$OUT/$name/bench.err"
   else
-    python3 bench.py $args --no-other-configs > "$OUT/$name/bench.json" 2> "$OUT/$name/bench.err"
+    python3 bench.py $args --no-other-configs --full-line > "$OUT/$name/bench.json" 2> "$OUT/$name/bench.err"
   fi
   echo "$name: $(python3 -c "
 import json,sys

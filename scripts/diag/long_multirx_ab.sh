@@ -4,7 +4,7 @@
 #   VARIANTS="main tpb512 nh3" WLS="ft8tri test2rx" REPS=2 bash scripts/diag/long_multirx_ab.sh
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="--no-cpu-baseline --no-host-fed --no-other-configs"
+B="--no-cpu-baseline --no-host-fed --no-other-configs --full-line"
 for rep in $(seq 1 ${REPS:-2}); do
  for w in ${WLS:-ft8tri test2rx}; do
   for v in ${VARIANTS:-main}; do

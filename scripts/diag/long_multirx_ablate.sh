@@ -4,7 +4,7 @@
 # copies, 4 no raw-peak scan, 8 no output stores) -- results WRONG by design, timing only.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="--no-cpu-baseline --no-host-fed --no-other-configs --no-verify"
+B="--no-cpu-baseline --no-host-fed --no-other-configs --no-verify --full-line"
 for w in ${WLS:-ft8tri test2rx}; do
  for f in ${FLAGS:-0 1 2 4 8 5 6 3 7}; do
   PYSDR_TUNING=1 PYSDR_USE_DIAG_LIB=1 PYSDR_DEBUG_FLAGS=$f python3 bench.py --workload $w $B 2>/dev/null | tail -1 | python3 -c "

@@ -4,7 +4,7 @@ set -u
 OUT=${1:-gpurun_out/r06_base}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$OUT" && mkdir -p "$OUT"
-B="--no-cpu-baseline --no-host-fed --no-other-configs"
+B="--no-cpu-baseline --no-host-fed --no-other-configs --full-line"
 for w in ft8tri test2rx; do
   python3 bench.py --workload $w $B > "$OUT/$w.json" 2> "$OUT/$w.err"
 done

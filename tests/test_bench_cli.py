@@ -57,6 +57,12 @@ def test_workloads_cover_the_single_gpu_baseline_configs():
     assert cfgs["c4"]["fs"] == 10e6 and cfgs["c4"]["rx"][0]["mode"] == "WFM2" and cfgs["c4mono"]["rx"][0]["mode"] == "WFM"
     six = bench.workload_cfg(bench.parse(["--nrx", "6"]))
     assert len(six["rx"]) == 6
+    # the reference's own launch scripts (FT8tri:47-74, TEST:13-32) with its default filter length (params.py:134)
+    ft8, t2 = cfgs["ft8tri"], cfgs["test2rx"]
+    assert ft8["fs"] == 8e6 and ft8["ntaps_dec"] == 1001 and [r["mode"] for r in ft8["rx"]] == ["USB"] * 3
+    assert [r["frq"] for r in ft8["rx"]] == [0.0, 2974e3, 6815e3] and all(r["video_bw"] == 45e3 and r["af_bw"] == 5e3 for r in ft8["rx"])
+    assert t2["fs"] == 4e6 and t2["ntaps_dec"] == 1001 and [(r["mode"], r["frq"]) for r in t2["rx"]] == [("NFM", 0.0), ("NFM", -600e3)]
+    assert bench.workload_cfg(bench.parse(["--workload", "c3", "--ntaps", "1001"]))["ntaps_dec"] == 1001
 
 
 def test_stale_profile_means_no_traffic_figure(tmp_path, monkeypatch):
@@ -122,3 +128,25 @@ def test_primed_oracle_joins_the_stream_where_a_full_run_is(which):
                 # the AGC's memory is longer than this test (--verify primes 192 chunks): compare the audio per unit gain
                 gf, go = float(f.agc.gain), float(o.agc.gain)
                 assert bench._relerr(np.asarray(ao) / go, np.asarray(af) / gf) <= 2e-6, (which, f.mode, k)
+
+
+def test_the_printed_line_fits_the_drivers_record():
+    """The driver keeps a 2000-character tail of stdout: the printed line must fit with every other configuration in it
+    (round 5's 14 KB line left the record with fragments of two of six).  Input: round 5's verbose object
+    (profiles/r05_bench_default.json) with two more children, as the default command now has eight."""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    oc = full["other_configs"]
+    assert len(oc) == 6
+    oc["ft8tri"] = dict(oc["rx6"])
+    oc["test2rx"] = dict(oc["c2"])
+    line = bench.compact_line(full, "gpurun_out/bench_full.json")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= 1900, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio", "traffic_source"}
+    assert abs(line["roofline"]["traffic_ratio"] - full["roofline"]["traffic"] / full["roofline"]["algorithmic_bytes_per_launch"]) < 1e-3
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
+    assert set(line["other_configs"]) == set(bench.OTHER_CONFIGS) and all(len(v) == 6 for v in line["other_configs"].values())
+    assert line["full"] == "gpurun_out/bench_full.json" and abs(line["value"] - full["value"]) <= 1e-6 * full["value"]

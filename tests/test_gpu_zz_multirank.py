@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(*argv, timeout=600):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, env=env,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv, "--full-line"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=timeout)
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
     return p, (json.loads(lines[-1]) if lines else None)
@@ -63,7 +63,7 @@ def test_a_world_of_eight_on_one_device():
 def test_a_wrong_answer_fails_the_line():
     """--verify is a gate, not a decoration: with the checker's tolerance forced to zero the same run exits non-zero."""
     code = ("import sys; sys.argv = ['bench.py', '--chunks', '16', '--steps', '1', '--warmup', '1', '--verify', "
-            "'--no-cpu-baseline', '--no-host-fed']; import bench; bench.VERIFY_TOL = 0.0; sys.exit(bench.main())")
+            "'--no-cpu-baseline', '--no-host-fed', '--full-line']; import bench; bench.VERIFY_TOL = 0.0; sys.exit(bench.main())")
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 3 and "--verify FAILED" in p.stderr, (p.returncode, p.stderr[-2000:])
     out = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1])
