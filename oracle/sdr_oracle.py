@@ -311,7 +311,10 @@ class CarrierPLL:
             c, s = rd(np.cos(th)), rd(np.sin(th))
             vr = yr[i] * c + yi[i] * s
             vi = yi[i] * c - yr[i] * s
-            e = rd(np.arctan2(vi, vr))
+            # a sample without amplitude steers nothing: the loop coasts on its integrator.  (Written out because
+            # atan2(+0, -0) = pi: for theta in the third quadrant y = +0 + 0j gives v = -0 + 0j, and the "atan2(0, 0) = 0"
+            # of the spec would depend on the signs of zeros.)
+            e = rd(0) if (vr == 0 and vi == 0) else rd(np.arctan2(vi, vr))
             w = rd(w + ki * e)
             th = rd(th + rd(w + kp * e))
             if th >= pi:

@@ -167,6 +167,13 @@ struct pysdr_ctx {
   int nrx = 0;
   RxHost rx[PYSDR_MAX_RX];
   std::mutex mu;
+  // Everything that queues work on the context's streams or moves the deferred tail -- process / process_batch, fetch, sync,
+  // the state getters (they queue the deferred tail: flush_tail), get_elapsed_ms, set_overlap, a spectrum ordering itself
+  // against the context, the ingest ring's submit / collect, the broadcast -- runs under this lock: the reference reads the
+  // AGC fields from its GUI / watchdog thread (watchdog.py:298-302) while the RX thread is inside demod_data, and a getter
+  // that ran the tail beside pysdr_process_batch's `c->tail = job` could run it twice or from a half-copied job.
+  // Recursive: pysdr_process is process_batch + fetch.  The setters keep to `mu` (they only mark work as pending).
+  std::recursive_mutex run_mu;
   hipStream_t stream = nullptr;
   // pysdr_set_overlap: a call is three groups of launches --
   //   F  the front end (mix + decimate; + the short parallel kernels in front of a serial loop: arg y for the carrier
@@ -1135,6 +1142,7 @@ int pysdr_set_squelch(pysdr_ctx* c, int irx, float thresh) {
 
 int pysdr_squelch_get(pysdr_ctx* c, int irx, float* level, int* open) {
   if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
@@ -1149,6 +1157,7 @@ int pysdr_squelch_get(pysdr_ctx* c, int irx, float* level, int* open) {
 
 int pysdr_pll_stats(pysdr_ctx* c, int irx, int* segments, int* patched) {
   if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
@@ -1163,6 +1172,7 @@ int pysdr_pll_stats(pysdr_ctx* c, int irx, int* segments, int* patched) {
 
 int pysdr_pll_linear_starts(pysdr_ctx* c, int irx, int* n) {
   if (!c || !n || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
@@ -1176,6 +1186,7 @@ int pysdr_pll_linear_starts(pysdr_ctx* c, int irx, int* n) {
 
 int pysdr_pll_join_margin(pysdr_ctx* c, int irx, int* max_words, float* max_dw) {
   if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
@@ -1196,6 +1207,7 @@ int pysdr_set_pll_segments(pysdr_ctx* c, int max_segments) {
 
 int pysdr_agc_get(pysdr_ctx* c, int irx, pysdr_agc_state* st) {
   if (!c || !st || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   RxDevState d;
@@ -1254,8 +1266,13 @@ int pysdr_set_tile(pysdr_ctx* c, int tile_bytes, int threads) {
 
 int pysdr_get_elapsed_ms(pysdr_ctx* c, int which, int back, float* ms) {
   if (!c || !ms || which < 0 || which > 3 || back < 0 || back >= pysdr_ctx::kSlots - (which == 3 ? 1 : 0)) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   if ((unsigned long long)back + (which == 3 ? 1u : 0u) >= c->ncalls) { set_last_error("pysdr_get_elapsed_ms: no such call"); return PYSDR_ERR_STATE; }
   int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  // the end mark of an overlapped context's LAST call is recorded by its deferred tail: queue that first (otherwise the event
+  // is unrecorded, or still holds the record of 64 calls ago: ADVICE r5)
+  rc = flush_tail(c);
   if (rc) return rc;
   hipEvent_t* ev = c->ev[(c->ncalls - 1 - back) % pysdr_ctx::kSlots];
   PYSDR_HIP_CHECK(hipEventSynchronize(ev[3]));
@@ -1272,6 +1289,7 @@ int pysdr_get_elapsed_ms(pysdr_ctx* c, int which, int back, float* ms) {
 
 int pysdr_sync(pysdr_ctx* c) {
   if (!c) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   rc = flush_tail(c);
@@ -1283,6 +1301,7 @@ int pysdr_sync(pysdr_ctx* c) {
 
 int pysdr_set_overlap(pysdr_ctx* c, int enable) {
   if (!c || enable < 0 || enable > 2) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   if (enable && c->n_ingest > 0) {
@@ -1336,6 +1355,7 @@ int pysdr_set_wfm_taps(pysdr_ctx* c, int irx, const double* video, int nv, const
 
 int pysdr_process_batch(pysdr_ctx* c, const void* iq, int nchunks, size_t chunk_len, int on_device) {
   if (!c || !iq || nchunks < 1 || chunk_len < 1) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   if (c->nrx < 1) { set_last_error("pysdr_process_batch: no receivers"); return PYSDR_ERR_STATE; }
   const size_t n = (size_t)nchunks * chunk_len;
   if (nchunks > c->cfg.max_chunks || n > c->cap_samples) {
@@ -1536,6 +1556,7 @@ static void last_chunk_counts(pysdr_ctx* c, int* chunk_nout) {
 int pysdr_fetch(pysdr_ctx* c, int irx, float* am, float* iq, int cap, int* n_out,
                 int* am_is_complex, int* chunk_nout, float* peaks) {
   if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   rc = flush_tail(c);                     // a deferred tail (pysdr_set_overlap) is queued now: its results are what is asked for
@@ -1561,6 +1582,7 @@ int pysdr_fetch(pysdr_ctx* c, int irx, float* am, float* iq, int cap, int* n_out
 
 int pysdr_process(pysdr_ctx* c, const float* iq, size_t n, pysdr_out* outs) {
   if (!c || !iq || !outs || n < 1) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = pysdr_process_batch(c, iq, 1, n, 0);
   if (rc) return rc;
   rc = flush_tail(c);                     // (an overlapped context deferred the call's tail: its results are wanted now)
@@ -1855,6 +1877,7 @@ int pysdr_spectrum_elapsed_ms(pysdr_spectrum* sp, float* ms) {
 
 int pysdr_spectrum_order(pysdr_spectrum* sp, pysdr_ctx* c, int direction) {
   if (!sp || !c || direction < 0 || direction > 2 || sp->device != c->cfg.device) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = use_device(sp->device);
   if (rc) return rc;
   if (direction == 2) {
@@ -2003,6 +2026,7 @@ int pysdr_ingest_submit(pysdr_ingest* g, int slot, size_t n) {
   if (!g || slot < 0 || slot >= g->nslots || n < 1 || n > g->cap) return PYSDR_ERR_ARG;
   if (g->in_flight[slot]) { set_last_error("pysdr_ingest_submit: slot %d is already in flight", slot); return PYSDR_ERR_STATE; }
   pysdr_ctx* c = g->c;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   const int b = (int)(g->seq & 1ull);
@@ -2143,6 +2167,7 @@ int pysdr_comm_init(pysdr_ctx* c, const char id[128], int rank, int nranks) {
 int pysdr_comm_bcast(pysdr_ctx* c, void* d_buf, size_t bytes, int root) {
   if (!c || !d_buf) return PYSDR_ERR_ARG;
   if (!c->comm) { set_last_error("pysdr_comm_bcast: communicator not initialised"); return PYSDR_ERR_STATE; }
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
   int rc = use_device(c->cfg.device);
   if (rc) return rc;
   ncclResult_t r = g_rccl.Broadcast(d_buf, d_buf, bytes, ncclUint8, root, c->comm, c->stream);

@@ -35,8 +35,9 @@
 //               over an older one).  A non-finite INPUT sample poisons all S*UP outputs of its
 //               rows instead of only those whose taps reach it -- the one observable difference
 //               (tests/test_gpu_parity.py::test_non_finite_input_on_the_matrix_core_path).
-// DESIGN.md 4.1b has the measurements that led here; MM_NO_* / MM_*_PRIO / MM_C?_* are compile-time A/B switches for
-// scripts/diag/mfma_ablate.sh (work-skipping ones give WRONG results and exist for timing only).
+// LABNOTES.md 4.1b has the measurements that led here.  MM_*_PRIO / MM_C?_* / MM_EPI_PLAIN / MM_PART_PLAIN are compile-time A/B
+// switches that keep the results right; the work-skipping ablation branches those measurements used (MM_NO_* and friends:
+// scripts/diag/mfma_ablate.sh) live in scripts/experiments/ablation_switches.patch.txt, not in this file.
 #include "common.h"
 #include "mixdec_geom.h"
 #include "mixdec_mfma_geom.h"
@@ -144,11 +145,7 @@ __device__ __forceinline__ void mm_stage_interior(const float2* src0, unsigned i
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int pc = pw + i * npw;
-#ifdef MM_NO_HALO                     // experiment: only the 16 segments a tile owns are copied (results WRONG): what a halo-free image would save
-    if (pc < (16 * G::NB * G::SPS + 63) / 64)
-#else
     if (pc < G::IMG_PIECES)
-#endif
     {
       if (G::NT) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(__float_as_uint(roff[i])), "s"(src0), "s"(img + (unsigned)pc * 1024u) : "memory");
       else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(__float_as_uint(roff[i])), "s"(src0), "s"(img + (unsigned)pc * 1024u) : "memory");
@@ -276,25 +273,16 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
     }
     mm_f4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     float m_prev = 0.f;
-#ifdef MM_NO_CONS                     // experiment: the consumers only keep the barrier (results WRONG): the copy pipeline alone
-    if (a.n_out < 0)
-#endif
 #pragma unroll
     for (int ls = 0; ls < kN; ++ls) {
       const mm_f2 v = ring[ls % kA];
-#ifdef MM_NO_MFMA                     // experiment: the copy / LDS side alone (results WRONG)
-      acc1[0] += v.x * B1[ls];
-      acc2[0] += v.y * B2[ls];
-#else
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, B1[ls], acc1, 0, 0, 0);
       acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, B2[ls], acc2, 0, 0, 0);
-#endif
       // peak steps of this slice, in pairs: |x|^2 of the odd ones waits for the even one behind it
       constexpr int kFirst = 4 * kS;
       const bool pk_step = (kFirst + 4 * ls) < G::P + 4;
       const int n_pk = (G::P + 4 - kFirst + 3) / 4;          // peak steps of this slice (<= 0: none; may exceed SPW)
       int nv = 0;
-#ifndef MM_NO_PK
       if (pk_step) {
         const float m = fmaf(v.x, v.x, v.y * v.y);
         const bool last = (ls + 1 == kN) || (ls + 1 >= n_pk);
@@ -302,7 +290,6 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
         else if ((ls & 1) == 0) { if (pk_on) pk_run = fmaxf(pk_run, m); nv = 3; }
         else { if (pk_on) pk_run = __builtin_fmaxf(__builtin_fmaxf(pk_run, m_prev), m); nv = 3; }
       }
-#endif
       const bool nxt = ls + kA >= kN;                               // refill from the next image
       if (!nxt) ring[ls % kA] = rd(pa, pb, ls + kA);
       else if (G::CARRY) ring[ls % kA] = rd(na, nb, ls % kA);
@@ -316,9 +303,6 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
     slot = nslot;
     one_chunk = ch.advance(a, origin, G::IMG_PIECES * 128);
     const mm_f4 sum = acc1 + acc2;
-#ifdef MM_NO_PART                     // experiment (results WRONG)
-    if (sum[0] == 1.2345f)
-#endif
     *(mm_lds_f4)(size_t)(part_off + (par ? (unsigned)G::PART_BYTES : 0u)) = sum;
     par ^= 1;
   }
@@ -389,29 +373,16 @@ __device__ __forceinline__ void mm_epi(const MixMfmaArgs& a, unsigned part0, int
       hold[j] = make_float2(0.f, 0.f);
       if (i0 + j < n) {               // tile i0+j is complete behind the barrier of the trip after it (or the last one)
         mm_barrier_lds_only();
-#if defined(MM_EPI_ZERO)              // experiment (results WRONG): the stores alone, no partial sums read
-        have[j] = etid < G::OUT_PER_TILE && a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + etid >= 0 &&
-                  a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + etid < a.n_out;
-#elif !defined(MM_NO_EPI)             // experiment (results WRONG)
         have[j] = mm_epilogue<G>(a, t_begin + i0 + j, part0 + (((i0 + j) & 1) ? (unsigned)G::PART_BYTES : 0u), etid, hold[j]);
-#endif
       }
     }
 #pragma unroll
     for (int j = 0; j < kFlush; ++j) {
-#if defined(MM_EPI_NO_STORE)          // experiment (results WRONG): everything but the store
-      if (have[j] && hold[j].x == 1.2345e30f)
-#else
       if (have[j])
-#endif
 #if defined(MM_EPI_PLAIN)            // A/B: plain stores
         a.y[a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + etid] = hold[j];
 #elif defined(MM_EPI_SC)             // experiment: system-scope write-through stores
         asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(a.y + a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + etid), "v"(hold[j]) : "memory");
-#elif defined(MM_EPI_SAMEPLACE)      // experiment (results WRONG): every tile's outputs go to the workgroup's first slot (stays in the L2)
-        a.y[a.mrel0 + t_begin * G::OUT_PER_TILE + etid] = hold[j];
-#elif defined(MM_EPI_WIDE)           // experiment (results WRONG): the same bytes as 16-byte stores from half the lanes
-        { if (etid < G::OUT_PER_TILE / 2) *(mm_f4*)(a.y + a.mrel0 + (t_begin + i0 + j) * G::OUT_PER_TILE + 2 * etid) = (mm_f4){hold[j].x, hold[j].y, hold[j].x, hold[j].y}; }
 #else
         // nontemporal: these 768-byte pieces are 2.3 % of the kernel's bytes, but as plain stores they cost 4.5 % of its time
         // (copy pipeline alone: 8 %; scripts/diag/mfma_ablate.sh MM_EPI_*: plain 0.3155-0.3181 ms, nt 0.3027, no store at all
@@ -441,16 +412,9 @@ __device__ __forceinline__ void mm_dma(const MixMfmaArgs& a, unsigned lds0, int 
     if (w == G::P / 2) w -= 1;
     roff[i] = __uint_as_float((unsigned)((seg * G::P + 2 * w) * 8));
   }
-#ifdef MM_NO_HALO
-  const int my_pieces = ((16 * G::NB * G::SPS + 63) / 64 - pw + npw - 1) / npw;
-#else
   const int my_pieces = (G::IMG_PIECES - pw + npw - 1) / npw;
-#endif
   auto stage = [&](int tile, int slot) -> int {
     if (tile >= t_end) return 0;
-#ifdef MM_NO_DMA                      // experiment: the arithmetic side alone (results WRONG)
-    if (tile > t_begin + 3) return 0;
-#endif
     const int origin_rel = a.origin_rel0 + tile * G::TILE;
     const unsigned img = lds0 + (unsigned)(slot * G::IMG_BYTES);
     if (origin_rel >= 0 && origin_rel + G::IMG_PIECES * 128 <= (int)a.n_total) {

@@ -89,7 +89,11 @@ constexpr float kWord2Rad = 1.4629180792671596e-9f;       // 2pi / 2^32
 // arg(x + jy) as a word of 2^32 per revolution: atan of min/max on [0, 1] by an odd polynomial (degree 15, fitted for
 // the maximum error: 1.4e-7 rad in float32 arithmetic = the resolution of a float32 angle near pi) already scaled to
 // words, the octant put back by exact integer arithmetic.  ~25 instructions where atan2f and the scaling took ~75
-// (the kernel below was bound by them: 17 us for 4.2 M samples).  0 for x = y = 0.
+// (the kernel below was bound by them: 17 us for 4.2 M samples).
+// The word's LSB is a FLAG, "this sample has no amplitude" (x = y = 0: zero-filled replay gaps, a muted or silent input longer
+// than the filters): the spec's detector is e = atan2(Im v, Re v) with v = y exp(-j theta) = 0, and atan2(0, 0) = 0 -- the loop
+// COASTS on its integrator (oracle CarrierPLL) -- where wrap(arg y - theta) with arg 0 := 0 would pull theta to 0 and leave
+// another loop state behind the gap.  A live sample's word has the bit cleared: 2^-31 revolutions of resolution.
 __device__ __forceinline__ uint32_t phase_word(float x, float y) {
   const float ax = fabsf(x), ay = fabsf(y);
   const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
@@ -106,7 +110,11 @@ __device__ __forceinline__ uint32_t phase_word(float x, float y) {
   int a = __float2int_rn(p * q);                            // [0, 2^29]
   if (ay > ax) a = (1 << 30) - a;
   if (x < 0.f) a = (int)(0x80000000u - (uint32_t)a);
-  return (uint32_t)(y < 0.f ? -a : a);
+  return ((uint32_t)(y < 0.f ? -a : a) & ~1u) | (mx > 0.f ? 0u : 1u);
+}
+// the detector on phase words: wrap(phi - theta) (the wrap is the integer overflow), 0 for a sample without amplitude
+__device__ __forceinline__ float am_detector(uint32_t phi, uint32_t theta) {
+  return (phi & 1u) ? 0.f : (float)(int)(phi - theta);
 }
 
 // grid (ceil(n / 2048), nrx): the phase word of every new sample, into the .y of the PLL buffer (its .x gets Re v).
@@ -235,7 +243,7 @@ __device__ __forceinline__ void am_pll_walk(const Stage2Args& a, int r, int i_be
     const int g0 = __float2int_rn(w0r);
     uint32_t ph = ph0 + (uint32_t)lane * (uint32_t)g0;     // guess: free running at the integrator's rate ...
     if (a.pll.direct) {                                    // ... corrected by the linear solve of the block around that line
-      const float u = (float)(int)(phi - ph);
+      const float u = am_detector(phi, ph);
       float s0 = kc.kpi * u, s1 = ki * u;
 #define PYSDR_AM_STEP(CTRL, ROWS, BC, M)                                                      \
       {                                                                                       \
@@ -258,7 +266,7 @@ __device__ __forceinline__ void am_pll_walk(const Stage2Args& a, int r, int i_be
     uint32_t tot = 0u;
     float sj = 0.f;
     auto sweep = [&](uint32_t pin) -> uint32_t {
-      const float e = (float)(int)(phi - pin);             // the detector: wrap(phi - theta), the wrap is the overflow
+      const float e = am_detector(phi, pin);               // the detector: wrap(phi - theta), the wrap is the overflow
       sj = wave_scan_add(e);
       const uint32_t corr = (uint32_t)__float2int_rn(__fmaf_rn(kp, e, __fmaf_rn(ki, sj, w0r)));
       tot = wave_scan_add(corr);
@@ -341,12 +349,15 @@ __device__ __forceinline__ bool am_linear_start(const Stage2Args& a, int r, int 
   const int m = (s0 - wb) >> 6;
   double c0 = 0.0, c1 = 0.0;
   int umax = 0;
+  uint32_t dead = 0u;
   uint32_t gl = anchor + (uint32_t)lane * G;                // the line at this lane's sample of row j
   const uint32_t* f = reinterpret_cast<const uint32_t*>(o + wb + lane) + 1;
 #pragma unroll 6
   for (int j = 0; j < m; ++j) {
-    const int u = (int)(f[128 * j] - gl);
+    const uint32_t fj = f[128 * j];
+    const int u = (int)(fj - gl);
     gl += 64u * G;
+    dead |= fj & 1u;                                        // a sample without amplitude: e = 0 there, not u - eps -- not this model's case
     umax = max(umax, u < 0 ? -u : u);                       // (INT_MIN stays negative: it fails the test below as it should)
     const double ud = (double)u;
     const double n0 = fma(A64.a, c0, fma(A64.b, c1, kpi * ud));
@@ -354,7 +365,7 @@ __device__ __forceinline__ bool am_linear_start(const Stage2Args& a, int r, int 
     c0 = n0; c1 = n1;
   }
   double x0 = pl.a * c0 + pl.b * c1, x1 = pl.c * c0 + pl.d * c1;
-  bool lin = umax >= 0 && umax <= kAmLinearMaxU;
+  bool lin = umax >= 0 && umax <= kAmLinearMaxU && !dead;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { x0 += __shfl_xor(x0, d); x1 += __shfl_xor(x1, d); }
   if (__ballot(!lin)) return false;
@@ -1123,8 +1134,10 @@ __global__ __launch_bounds__(256) void wfm_disc_kernel(const WfmArgs a) {
       // (nontemporal loads here measured 36.1-36.6 us against 34.6-35.8: plain)
       const float2 yb = a.y1[r][i], ya = a.y1[r][i - 1];
       // the 1-sample IF history of the NEXT call (this kernel is the buffer's only reader; until round 5 the pilot loop's
-      // patch-up kernel rolled it, which tied the next call's discriminator to this call's pilot loop)
-      if (i == a.n1 - 1) a.y1dst[r][1] = yb;
+      // patch-up kernel rolled it, which tied the next call's discriminator to this call's pilot loop) -- into the OTHER buffer
+      // of the pair only: in the single-stream form the destination is the word thread 0 of workgroup 0 reads as y1[-1] in
+      // this very launch, unordered across workgroups; launch_wfm_disc rolls it behind the kernel then
+      if (i == a.n1 - 1 && a.y1dst[r] != a.y1base[r]) a.y1dst[r][1] = yb;
       const float re = yb.x * ya.x + yb.y * ya.y;
       const float im = yb.y * ya.x - yb.x * ya.y;
       const float mpx = atan2f(im, re) * a.scale;
@@ -1555,6 +1568,9 @@ int launch_wfm_disc(const WfmArgs& a, hipStream_t st) {
   if (a.n1 > 0) {
     hipLaunchKernelGGL(wfm_disc_kernel, dim3((a.n1 + kSeedTile - 1) / kSeedTile, a.nrx), dim3(256), 0, st, a);
     PYSDR_HIP_CHECK(hipGetLastError());
+    for (int r = 0; r < a.nrx; ++r)            // one buffer (every live context): the roll in stream order behind its only reader
+      if (a.y1dst[r] == a.y1base[r])
+        PYSDR_HIP_CHECK(hipMemcpyAsync(a.y1base[r] + 1, a.y1base[r] + 2 + (a.n1 - 1), sizeof(float2), hipMemcpyDeviceToDevice, st));
   }
   return PYSDR_OK;
 }

@@ -37,6 +37,17 @@ def _device_of(P):
     return int(getattr(P, 'GPU_DEVICE', 0) or 0)
 
 
+def _chunk_key(x):
+    """Identity of a chunk for the per-chunk cache of ``Receiver.demod_data``: where it lives, how long it is and 16 of its
+    samples (a buffer reused in place for the next chunk keeps its address; its contents do not stay)."""
+    x = np.asarray(x)
+    n = x.shape[0] if x.ndim else 0
+    if n == 0:
+        return (0, 0, b'')
+    idx = (np.arange(16, dtype=np.int64) * (n - 1)) // 15
+    return (x.__array_interface__['data'][0], n, x[idx].tobytes())
+
+
 # ----------------------------------------------------------------------------------------
 class _StreamContext:
     """One wideband stream on one GPU: owns the ``pysdr_ctx`` and the per-chunk cache
@@ -63,6 +74,8 @@ class _StreamContext:
         self.receivers = []
         self.seq = 0                 # chunks processed
         self.cache = {}              # irx -> (am, iq, peak)
+        self.cache_key = None        # which chunk the cache holds (_chunk_key) ...
+        self.served = set()          # ... and which sub-receivers have taken their share of it
         self.lock = threading.Lock()
         self.cap = int(self.max_chunks * int(P.IN_CHUNK_SIZE) * int(P.UP) // int(P.DOWN)) + 8
 
@@ -391,14 +404,26 @@ class Receiver:
             self._applied = want
 
     def demod_data(self, x):
+        """``rx.demod_data(x)`` (``receiver.py:235``).  The sub-receivers of a stream share ONE launch sequence per chunk: the
+        first of them to be handed a chunk runs it for all, the others take their share from the cache.  WHICH chunk the
+        cache holds is decided by the chunk itself (buffer address, length and a fingerprint of 16 of its samples), not by
+        counting calls: a caller that leaves a sub-receiver out for a chunk (the reference's MP_SCHEME 3 workers each call
+        their own ``rx``, ``receiver.py:726-739``) then neither shifts that receiver onto the previous chunk's results nor
+        the others onto a chunk that was never run.  The same receiver asking twice for the same samples runs them twice
+        (a stream may repeat).  What this cannot tell apart: two different chunks with the same address, length and
+        fingerprint (all-zero chunks) when a receiver skipped the first of them -- it then gets the first one's share."""
         ctx = self._ctx
+        key = _chunk_key(x)
         with ctx.lock:
-            if self._seen >= ctx.seq:
+            if key != ctx.cache_key or self.irx in ctx.served or self.irx not in ctx.cache:
                 # first receiver to see this chunk: run the whole stream once
                 for rx in ctx.receivers:
                     rx._sync_controls()
                 ctx.process_chunk(x)
+                ctx.cache_key = key
+                ctx.served = set()
             am, iq, pk = ctx.cache[self.irx]
+            ctx.served.add(self.irx)
             self._seen = ctx.seq
         self.am, self.iq, self.peak_in = am, iq, pk
         return am

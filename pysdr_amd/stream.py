@@ -25,6 +25,24 @@ class StreamResult:
         return f"ret={self.ret}, flags={self.flags}, timeNs={self.timeNs}"
 
 
+class Range(list):
+    """What ``getGainRange`` / ``getFrequencyRange`` hand back: SoapySDR's range object as the reference reads it
+    (``r.minimum(), r.maximum(), r.step()``, ``receiver.py:328-330``) that is also the plain ``[min, max, step]`` list its own
+    RTL stand-in returns (``utils.py:175-178``)."""
+
+    def __init__(self, lo, hi, step=0.0):
+        super().__init__([lo, hi, step])
+
+    def minimum(self):
+        return self[0]
+
+    def maximum(self):
+        return self[1]
+
+    def step(self):
+        return self[2]
+
+
 class SynthSDR:
     """``data`` is either a synth config dict (``pysdr_amd.synth.CONFIGS[...]``) or a
     complex64 array to replay.  ``read_pattern`` = fractions of the requested count handed
@@ -78,8 +96,23 @@ class SynthSDR:
     def getGain(self, rx, ch, stage=None):
         return self.gain.get(stage, 0)
 
+    def getGainRange(self, rx, ch, stage=None):
+        return Range(0.0, 49.6, 1.0)             # the span the reference's RTL stand-in clamps to (utils.py:204-205)
+
+    def hasGainMode(self, rx, ch):
+        return True
+
     def setGainMode(self, rx, ch, flag):
         self.gain['auto'] = flag
+
+    def getGainMode(self, rx, ch):
+        return bool(self.gain.get('auto', False))
+
+    def getFrequencyRange(self, rx, ch, tag='RF'):
+        return [Range(0.0, 6e9)]
+
+    def listAntennas(self, rx, ch):
+        return ['RX']
 
     def setAntenna(self, rx, ch, ant):
         self.settings['antenna'] = ant
@@ -90,8 +123,11 @@ class SynthSDR:
     def listBandwidths(self, rx, ch):
         return []
 
+    def setBandwidth(self, rx, ch, bw):
+        self.settings['bandwidth'] = float(bw)
+
     def getBandwidth(self, rx, ch):
-        return self.fs
+        return self.settings.get('bandwidth', self.fs)
 
     def writeSetting(self, key, val):
         self.settings[key] = val
@@ -139,6 +175,13 @@ class SynthSDR:
         buffs[0][:k] = self.samples[self.pos:self.pos + k]
         self.pos += k
         return StreamResult(k)
+
+    def readStreamRTL(self, stream, n):
+        """The reference's own RTL stand-in hands out an ARRAY instead of filling a buffer (``utils.py:241-251``,
+        ``receiver.py:598-600`` under ``P.USE_FAKE_RTL``): whatever is ready, possibly nothing."""
+        buf = np.empty(int(n), np.complex64)
+        sr = self.readStream(stream, [buf], int(n))
+        return buf[:max(sr.ret, 0)]
 
     # -- replay surface (fileio.sdr_fileio.read_data, receiver.py:526)
     def read_data(self):

@@ -560,6 +560,36 @@ def test_multi_rx_long_prototype_does_not_depend_on_the_cut(name, nrx, grid, mon
         assert relerr(np.concatenate(iq1[i]), want) <= TOL, (i, o.mode)
 
 
+def test_a_sub_receiver_left_out_for_a_chunk_does_not_shift_anyones_chunks():
+    """The sub-receivers of a stream share one launch sequence per chunk (sig_proc.Receiver.demod_data).  Which chunk the
+    shared results belong to is decided by the chunk (address, length, fingerprint), not by counting calls: chunk 1 is asked
+    for by RX 0 only, chunk 2 by RX 1 FIRST -- it must get chunk 2's audio, not chunk 1's (with call counting it
+    silently did), and RX 0 behind it shares that launch; asking twice for the same samples runs them twice."""
+    cfg = dict(so.CONFIGS['C3'], rx=so.CONFIGS['C3']['rx'][:2])
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    x = so.synth_iq(cfg, 4 * L, 17)
+    P, g = make_gpu_receivers(cfg)
+    o = so.make_receivers(cfg, np.float32)
+    want = [[ro.demod_data(x[k * L:(k + 1) * L]).copy() for k in range(4)] for ro in o]
+    ctx = P._pysdr_stream
+    c0, c1, c2, c3 = (x[k * L:(k + 1) * L] for k in range(4))
+    assert relerr(g[0].demod_data(c0), want[0][0]) <= TOL and relerr(g[1].demod_data(c0), want[1][0]) <= TOL
+    assert ctx.seq == 1
+    assert relerr(g[0].demod_data(c1), want[0][1]) <= TOL              # RX 1 sits this chunk out
+    assert ctx.seq == 2
+    assert relerr(g[1].demod_data(c2), want[1][2]) <= TOL              # ... and comes first on the next one
+    assert relerr(g[0].demod_data(c2), want[0][2]) <= TOL and ctx.seq == 3        # one launch for both
+    # a buffer reused in place: same address, new samples
+    buf = np.array(c3)
+    a = g[0].demod_data(buf).copy()
+    assert relerr(a, want[0][3]) <= TOL and relerr(g[1].demod_data(buf), want[1][3]) <= TOL and ctx.seq == 4
+    buf[:] = c0
+    g[0].demod_data(buf)
+    assert ctx.seq == 5
+    g[0].demod_data(buf)                                               # the same samples again: a stream may repeat
+    assert ctx.seq == 6
+
+
 def test_long_prototype_1001_taps_and_10msps():
     cfg = dict(so.CONFIGS['C2'], fs=10e6, ntaps_dec=1001,
                carriers=[dict(f=455e3, kind='fm', amp=0.3, tone=1000.0, dev=3000.0)])

@@ -269,6 +269,40 @@ def test_am_synch_hard_carriers_equal_the_serial_oracle(f_off, noise, jumps):
     assert relerr(am[1024:], want[1024:]) <= TOL, (stats, relerr(am[1024:], want[1024:]))
 
 
+@pytest.mark.parametrize("batched", [True, False])
+def test_am_synch_coasts_through_samples_without_amplitude(batched):
+    """A run of exact zeros inside an AM-Synch stream (a zero-filled replay gap, a muted input: 3 chunks, longer than every
+    filter, so the decimator's output is exactly 0 for ~2 chunks): the spec's detector atan2(Im v, Re v) is 0 for v = 0 and the
+    loop coasts on its integrator; the phase-domain form must not read "arg 0 = 0" as a carrier at phase 0 (the
+    loop state behind the gap, and with it the re-lock transient, then differs from the serial oracle's).  One call of 24
+    chunks (48 segments; the windows with dead samples take the walked warm-up, not the linear solve) and chunk by chunk
+    (one segment per call)."""
+    cfg = dict(so.CONFIGS['C1'])
+    cfg['ntaps_dec'] = 255
+    cfg['rx'] = [dict(frq=100e3 - 7.0, mode='AM-Synch', video_bw=10e3, af_bw=5e3)]
+    B = 24
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    x = so.synth_iq(cfg, B * L, 8).copy()
+    x[9 * L + 1234:12 * L + 77] = 0
+    P = RunTimeParams(fs=cfg['fs'], fsout=48e3, fc=[7e6], mode='AM-Synch', nfilt=255, max_batch_chunks=B if batched else 1)
+    P.VIDEO_BW = 10e3
+    g = sig_proc.Receiver(P, 100e3 - 7.0, 0, '1')
+    g.mode, g.af_bw = 'AM-Synch', 5e3
+    if batched:
+        ctx = P._pysdr_stream
+        ctx.process_batch(x, B, L, on_device=False)
+        am = ctx.fetch(0, B)[0]
+        assert pll_stats(ctx)[0] >= 40
+    else:
+        am = np.concatenate([g.demod_data(x[k * L:(k + 1) * L]).copy() for k in range(B)])
+    o = so.make_receivers(cfg, np.float32)[0]
+    want = np.concatenate([o.demod_data(x[k * L:(k + 1) * L]) for k in range(B)])
+    assert am.shape == want.shape
+    lo, hi = 10 * 1024 + 512, 11 * 1024 + 512
+    assert np.all(want[lo:hi] == 0) and np.all(am[lo:hi] == 0)          # inside the gap both are silent
+    assert relerr(am[1024:], want[1024:]) <= TOL                        # ... and the re-lock behind it is the oracle's
+
+
 def _linear_starts(ctx, irx=0):
     n = C.c_int(-1)
     _lib.check(_lib.lib().pysdr_pll_linear_starts(ctx.h, irx, C.byref(n)), "pll_linear_starts")
