@@ -158,20 +158,14 @@ bool mixdec_mfma_plan(int shape, unsigned long long s0, unsigned long long m0, u
 int launch_mixdec_mfma(int shape, const MixMfmaArgs& a, int grid, hipStream_t st);
 
 // ---- compile-time experiment switches ----------------------------------------------------
-// Two kinds live in the kernel sources.  A/B switches keep the results right (MM_EPI_PLAIN, MM_*_PRIO, MM_C1_* / MM_C4_*
-// shapes, MM_NTX, FIRX_THREADS, PSDX_WAVE_SCALE, PLLX_PRIO, PYSDR_BLK_STRIDE, ...).  ABLATION switches skip work to time what
-// is left and give WRONG results by design (scripts/diag/*_ablate.sh); they compile only where PYSDR_ABLATE is defined, which
-// `python -m pysdr_amd.build --diag` does for libpysdr_hip_diag.so and nothing does for the shipped libpysdr_hip.so -- a
-// stray -D in an ambient PYSDR_*_FLAGS variable stops the build here instead of silently producing a wrong library
-// (build.py also ignores those variables unless PYSDR_TUNING=1, and pysdr_build_flags_hash() / the bench line show what
-// extra flags a library was built with).
-#if !defined(PYSDR_ABLATE) && (defined(MM_NO_PK) || defined(MM_NO_PART) || defined(MM_NO_MFMA) || defined(MM_NO_HALO) || \
-    defined(MM_NO_DMA) || defined(MM_NO_CONS) || defined(MM_NO_EPI) || defined(MM_EPI_ZERO) || defined(MM_EPI_NO_STORE) || \
-    defined(MM_EPI_WIDE) || defined(MM_EPI_SAMEPLACE) || defined(FIRX_NO_SUM) || defined(FIRX_NO_STAGE) || \
-    defined(FIRX_NO_ATOMICS) || defined(AGCX_NO_ZERO) || defined(AGCX_NO_LOAD) || defined(AGCX_NO_CHAIN) || \
-    defined(PSDX_NO_LO) || defined(PSDX_NO_SCALE))
-#error "work-skipping ablation switch without PYSDR_ABLATE: these give wrong results and belong to the diagnostic build (python -m pysdr_amd.build --diag)"
-#endif
+// The kernel sources carry A/B switches only: every one of them keeps the results right (MM_EPI_PLAIN, MM_*_PRIO, MM_C1_* /
+// MM_C4_* shapes, MM_NTX, MM_PART_PLAIN, MD_* of mixdec.hip, FIRX_THREADS, PSDX_WAVE_SCALE, PLLX_PRIO, PYSDR_BLK_STRIDE, ...);
+// `build.py` reads extra -D flags only under PYSDR_TUNING=1 and `pysdr_build_flags_hash()` / the bench line show what a
+// library was built with.  The work-skipping ABLATION branches that rounds 3-5 timed kernels with (MM_NO_*, MM_EPI_ZERO /
+// NO_STORE / WIDE / SAMEPLACE, FIRX_NO_*, AGCX_NO_*, PSDX_NO_*: results WRONG by design) are no longer in the sources: they are
+// scripts/experiments/ablation_switches.patch.txt (apply with `patch -p1`, build with `python -m pysdr_amd.build --diag`,
+// which defines PYSDR_ABLATE for them).  What remains of that kind are the four RUN-TIME switches of mixdec.hip
+// (PYSDR_DEBUG_FLAGS), compiled only into the diagnostic library (-DPYSDR_DIAG).
 
 // ---- stage 2 at FS_OUT (stage2.hip) --------------------------------------------------
 #ifndef PYSDR_BLK_STRIDE

@@ -322,14 +322,11 @@ __device__ __forceinline__ void cols_unit_pk(const float2* __restrict__ xf, cons
     twiddle_pow0(v, expmpi((float)(16 * bb) * (1.0f / 32768.0f)),
                  expmpi((float)(bb * p1) * (1.0f / 32768.0f)));
     // the block's largest |component|: thread, wave (DPP-free butterflies through shuffles), workgroup.
-    // Measured (scripts/diag/psd_variants.sh, PSD alone, ms per 10666 frames): shipped 2.27; a fixed scale (-DPSDX_NO_SCALE,
-    // results wrong) 2.18; a scale per WAVE (-DPSDX_WAVE_SCALE: no barrier, no LDS round trip in front of the stores; parity
+    // Measured (scripts/diag/psd_variants.sh, PSD alone, ms per 10666 frames): shipped 2.27; a fixed scale (ablation PSDX_NO_SCALE,
+    // results wrong; scripts/experiments/ablation_switches.patch.txt) 2.18; a scale per WAVE (-DPSDX_WAVE_SCALE: no barrier, no LDS round trip in front of the stores; parity
     // green) 2.35-2.41 against 2.35-2.37 on the same box: the barrier is not what the reduction costs.  Without the LO plane
-    // (-DPSDX_NO_LO, results wrong) 2.00, without both 1.85: the pair moves its bytes at ~6 TB/s in every variant.
+    // (ablation PSDX_NO_LO, results wrong) 2.00, without both 1.85: the pair moves its bytes at ~6 TB/s in every variant.
     float m = 0.f;
-#if defined(PSDX_NO_SCALE)
-    m = 64.f;
-#else
 #pragma unroll
     for (int p0 = 0; p0 < 16; ++p0) m = fmaxf(fmaxf(m, fabsf(v[p0].x)), fabsf(v[p0].y));
 #pragma unroll
@@ -338,7 +335,6 @@ __device__ __forceinline__ void cols_unit_pk(const float2* __restrict__ xf, cons
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-#endif
 #endif
     // (a block whose largest component is below 1e-20 contributes powers below 1e-36 * 65536: far under the 1e-30 that is
     //  added before the logarithm -- it is stored as zeros, which also keeps 8388600 / m finite for denormal m)
@@ -353,9 +349,7 @@ __device__ __forceinline__ void cols_unit_pk(const float2* __restrict__ xf, cons
     for (int p0 = 0; p0 < 16; ++p0) {
       const unsigned a = (unsigned)__float2int_rn(v[p0].x * sc), c = (unsigned)__float2int_rn(v[p0].y * sc);
       oh[p0 * 256] = pk_perm(c, a, 0x06050201u);                       // [a.b1, a.b2, c.b1, c.b2]
-#ifndef PSDX_NO_LO                    // experiment (results WRONG): the HI plane alone
       ol[p0 * 256] = (unsigned short)pk_perm(c, a, 0x0c0c0400u);       // [a.b0, c.b0]
-#endif
     }
   }
 }
@@ -380,11 +374,7 @@ __device__ __forceinline__ void rows_unit_pk(const char* __restrict__ wf, float*
     const PYSDR_AS1 float* ss = (const PYSDR_AS1 float*)(wf + kPkScaleOff);
     unsigned h[16], l[16];
 #pragma unroll
-#ifdef PSDX_NO_LO
-    for (int c1 = 0; c1 < 16; ++c1) { h[c1] = sh[4096 * c1]; l[c1] = 0u; }
-#else
     for (int c1 = 0; c1 < 16; ++c1) { h[c1] = sh[4096 * c1]; l[c1] = sl[4096 * c1]; }
-#endif
     float2 u[16];
 #pragma unroll
     for (int c1 = 0; c1 < 16; ++c1) {

@@ -756,9 +756,6 @@ __device__ __forceinline__ void fir_epilogue(const Stage2Args& a, int r, int det
       cnt0 += __shfl_xor(cnt0, o); cnt1 += __shfl_xor(cnt1, o);
     }
   }
-#ifdef FIRX_NO_ATOMICS                // experiment (results WRONG): no block peaks
-  if (m0 + m1 == 1.2345e30f)
-#endif
   if ((tid & 63) == 0 && wb0 != 0xFFFFFFFFu) {
     // (a single-block RX -- broadcast FM -- deals its waves over single_spread accumulators: agc_scan_kernel folds them)
     const uint32_t sp = a.single_block[r] ? (blockIdx.x & (uint32_t)(a.single_spread - 1)) : 0u;
@@ -803,11 +800,7 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   for (int e = tid; e < E; e += kFirThreads) {
     const int i = i0 - H + e - 3;
     // (indices in front of the kept history only ever meet zero-padded taps)
-#ifdef FIRX_NO_STAGE                  // experiment (results WRONG): no loads, no detector
-    const float2 d = make_float2(1.0f + (float)e, 0.5f);
-#else
     const float2 d = (i >= -a.hy + 2) ? detect(a, r, det, y, i) : make_float2(0.f, 0.f);
-#endif
     sre[fir_pad(e)] = d.x;
     sim[fir_pad(e)] = d.y;
   }
@@ -819,10 +812,6 @@ __global__ __launch_bounds__(kFirThreads) void demod_fir_kernel(const Stage2Args
   __syncthreads();
 
   float2 acc[kW];
-#ifdef FIRX_NO_SUM                    // experiment (results WRONG): no inner product
-  for (int j = 0; j < kW; ++j) acc[j] = make_float2(sre[fir_pad(kW * tid + H + 3 + j)], sim[fir_pad(kW * tid + H + 3 + j)]);
-  if (false)
-#endif
   if (CPLX) {
     fir_run<kFirCplx>(sre, sim, tre, tim, tre_s, tim_s, nblk, H, tid, acc);
   } else {
@@ -890,11 +879,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int c = c0 + u * 256 + tid;
-#ifdef AGCX_NO_LOAD                   // experiment (results WRONG)
-      v[u] = (c < nacc) ? 0x3f000000u + c : 0u;
-#else
       v[u] = (c < nacc) ? a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] : 0u;
-#endif
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -920,11 +905,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
   constexpr int kWarm = 176;             // 0.9^176 = 9e-9 < 2^-24: a decaying start value is gone from a float
   const int T = (nch + 255) / 256 < 16 ? 16 : (nch + 255) / 256;
   const int K = (nch + T - 1) / T;
-#ifdef AGCX_NO_CHAIN                  // experiment (results WRONG)
-  if (tid < K && a.n_out < 0) {
-#else
   if (tid < K) {
-#endif
     const int s0 = tid * T, s1 = (s0 + T < nch) ? s0 + T : nch;
     int wb = s0 - kWarm;
     float env = 0.f;
@@ -972,9 +953,7 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
     const float g = st.agc_enable ? fminf(__fdiv_rn(st.ref, fmaxf(pk[px(c)], 1e-12f)), 1.0e4f) : 1.f;
     a.gain[(size_t)r * a.nchunks + c] = g;
     // the raw block peaks are consumed: leave them zeroed for the next call
-#ifndef AGCX_NO_ZERO                  // experiment (results WRONG from the second call on)
     a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] = 0u;
-#endif
   }
   if (a.single_block[r])
     for (int c = 1 + tid; c < nacc; c += 256) a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] = 0u;

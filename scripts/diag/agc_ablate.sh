@@ -1,4 +1,5 @@
 # where agc_scan_kernel's time goes: builds of stage2.hip with parts switched off (results WRONG), kernel averages from rocprofv3
+grep -q "MM_NO_CONS" pysdr_amd/csrc/mixdec_mfma.hip || { echo "the ablation branches are not in the sources: patch -p1 < scripts/experiments/ablation_switches.patch.txt first (and git checkout pysdr_amd/csrc afterwards)"; exit 1; }
 export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so

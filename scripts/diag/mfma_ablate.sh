@@ -1,4 +1,5 @@
 # A/B builds of mixdec_mfma.hip (flag sets as arguments) timed with bench.py c1 and c4 (front-end ms; C4 also per kernel)
+grep -q "MM_NO_CONS" pysdr_amd/csrc/mixdec_mfma.hip || { echo "the ablation branches are not in the sources: patch -p1 < scripts/experiments/ablation_switches.patch.txt first (and git checkout pysdr_amd/csrc afterwards)"; exit 1; }
 export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 cp pysdr_amd/libpysdr_hip.so /tmp/keep.so
 for fl in "$@"; do

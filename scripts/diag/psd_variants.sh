@@ -1,4 +1,5 @@
 # A/B of compile-time variants of psdfft.hip ON the GPU box: for every flag set given as an argument ("" = shipped) rebuild
+grep -q "MM_NO_CONS" pysdr_amd/csrc/mixdec_mfma.hip || { echo "the ablation branches are not in the sources: patch -p1 < scripts/experiments/ablation_switches.patch.txt first (and git checkout pysdr_amd/csrc afterwards)"; exit 1; }
 export PYSDR_TUNING=1   # build.py reads PYSDR_*_FLAGS only under the tuning master switch (round 5)
 # the library and time the PSD alone (bench.py --no-demod) and inside C3.
 #   bash scripts/diag/psd_variants.sh "" "-DPSDX_NO_SCALE" "-DPSDX_NO_LO"
