@@ -530,19 +530,51 @@ def verify_rank(cfg, ctx, rxs, rx_idx, xu, nloop, seam, nsamp, L, B, steps_done,
     return dict(ok=bool(ok), worst_rel=worst, checks=checks)
 
 
+def pick_device(local_rank, ndev):
+    """Rank r of a node binds device r (one process per GPU); with fewer devices than ranks -- the single-GPU boxes of the
+    tests, where every rank of a world of 8 shares device 0 -- the ranks wrap round."""
+    return int(local_rank) % max(1, int(ndev))
+
+
+def split_rx_refusal(split_rx, world, ndev):
+    """--split rx broadcasts over RCCL, which refuses two ranks of one communicator on one device: the reason to refuse
+    the run, or None."""
+    if split_rx and world > ndev:
+        return f"--split rx needs one GPU per rank (RCCL): {world} ranks, {ndev} device(s)"
+    return None
+
+
+def checksum_words(words, s=0, x=0):
+    """(wrapping sum, xor) of uint64 words, continued from (s, x)."""
+    with np.errstate(over='ignore'):
+        s = np.uint64(s) + np.add.reduce(words, dtype=np.uint64)
+        x = np.uint64(x) ^ (np.bitwise_xor.reduce(words) if len(words) else np.uint64(0))
+    return int(s), int(x)
+
+
+def aggregate_verify(allv, split_rx):
+    """Every rank's verification record -> the line's stamp.  --split rx: a rank is only good if its copy of the broadcast
+    batch has the root's checksum -- ranks WITHOUT a sub-receiver (4 RX over 8 GPUs: ranks 4-7) have nothing else to show,
+    and a rank whose receivers pass on a batch that is not the root's would be passing on the wrong data."""
+    if split_rx:
+        for v in allv:
+            v["bcast_equals_root"] = (v["bcast_checksum"] == allv[0]["bcast_checksum"])
+            v["ok"] = bool(v["ok"] and v["bcast_equals_root"])
+    return dict(verified_ranks=sum(1 for v in allv if v["ok"]),
+                worst_rel=max(v["worst_rel"] for v in allv), tol=VERIFY_TOL, ranks=allv)
+
+
 def device_checksum(lib, device, d_ptr, nbytes, piece=256 << 20):
     """64-bit checksum (wrapping sum and xor of the 8-byte words) of a DEVICE buffer, downloaded in
     pieces: what --split rx compares between the root's batch and every other rank's copy."""
     from pysdr_amd import _lib
     host = np.empty(min(piece, nbytes) // 8, np.uint64)
-    s, x = np.uint64(0), np.uint64(0)
-    with np.errstate(over='ignore'):
-        for off in range(0, nbytes, piece):
-            n = min(piece, nbytes - off) // 8
-            _lib.check(lib.pysdr_dev_download(device, C.c_void_p(host.ctypes.data), C.c_void_p(d_ptr + off), n * 8), "download")
-            s = s + np.add.reduce(host[:n], dtype=np.uint64)
-            x = x ^ np.bitwise_xor.reduce(host[:n])
-    return int(s), int(x)
+    s, x = 0, 0
+    for off in range(0, nbytes, piece):
+        n = min(piece, nbytes - off) // 8
+        _lib.check(lib.pysdr_dev_download(device, C.c_void_p(host.ctypes.data), C.c_void_p(d_ptr + off), n * 8), "download")
+        s, x = checksum_words(host[:n], s, x)
+    return s, x
 
 
 def source_sha(name):
@@ -741,7 +773,7 @@ def main():
     lib = _lib.lib()
     _lib.require_gpu()
     ndev = _lib.device_count()
-    device = local_rank % ndev
+    device = pick_device(local_rank, ndev)
 
     dist = None
     if world > 1:
@@ -751,8 +783,9 @@ def main():
 
     split_rx = args.split == "rx"
     do_verify = True if args.verify is None else bool(args.verify)
-    if split_rx and world > ndev:
-        raise SystemExit(f"--split rx needs one GPU per rank (RCCL): {world} ranks, {ndev} device(s)")
+    refuse = split_rx_refusal(split_rx, world, ndev)
+    if refuse:
+        raise SystemExit(refuse)
     with_psd = (args.workload == "c3") and not args.no_psd and (not split_rx or rank == 0)
     B = args.chunks or DEFAULT_CHUNKS[args.workload]
     nrx_total = len(cfg['rx'])
@@ -919,12 +952,7 @@ def main():
         if dist is not None:
             allv = [None] * world
             dist.all_gather_object(allv, mine)
-        if split_rx:
-            for v in allv:
-                v["bcast_equals_root"] = (v["bcast_checksum"] == allv[0]["bcast_checksum"])
-                v["ok"] = bool(v["ok"] and v["bcast_equals_root"])
-        verify = dict(verified_ranks=sum(1 for v in allv if v["ok"]),
-                      worst_rel=max(v["worst_rel"] for v in allv), tol=VERIFY_TOL, ranks=allv)
+        verify = aggregate_verify(allv, split_rx)
 
     # ---- the reference's real PSD duty next to the headline (never `value`): the GUI's 20 Hz timer
     # takes one 32768-sample chunk per tick and flushes the backlog (pySDR.py:252-256, gui.py:1264-1267),
