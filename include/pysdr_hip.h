@@ -245,6 +245,15 @@ int  pysdr_waterfall_image(pysdr_waterfall* wf, float pan_dr, float* image_out, 
 int  pysdr_waterfall_image_rows(pysdr_waterfall* wf, float pan_dr, int npsd, float* image_out,
                                 float* mean_out, float* bkgnd_out);
 
+/* The peak pick of the display, `peaks, _ = signal.find_peaks(PSD2, distance=dist, height=bkgnd+10)` (Plotting.py:594-602), on
+ * the device: local maxima with flat tops (midpoint of a plateau, none at the ends of the line), height >= `height` (double),
+ * then SciPy's priority-by-height distance rule with distance = ceil(PEAK_DIST / df) >= 1 (a kept peak removes every peak
+ * closer than that).  line == NULL: over the first n values of the averaged line the last pysdr_waterfall_image left on the
+ * device (PSD2); otherwise over the n host values given.  idx_out[min(*n_out, cap)] ascending; *n_out = how many there are.
+ * Equal heights closer than `distance`: SciPy's choice rests on an unstable argsort; here the higher index outranks. */
+int  pysdr_waterfall_peaks(pysdr_waterfall* wf, const float* line, int n, double height, int distance, int* idx_out, int cap,
+                           int* n_out);
+
 /* ---- device memory for resident streams --------------------------------------- */
 int pysdr_dev_alloc(int device, size_t bytes, void** out);
 int pysdr_dev_free(int device, void* p);

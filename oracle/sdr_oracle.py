@@ -614,6 +614,43 @@ def find_peaks_db(psd2, bkgnd, peak_dist_bins):
     return peaks
 
 
+def find_peaks_greedy(x, height, distance):
+    """``scipy.signal.find_peaks(x, height=height, distance=distance)`` (what ``Plotting.py:596`` calls) written out as its
+    sequential walk: local maxima with flat tops (the midpoint of a plateau, ``(left + right) // 2``; a flat stretch that
+    touches either end of the line is no peak), ``x[peak] >= height``, then greedily by height -- every kept peak removes all
+    peaks closer than ``ceil(distance)``.  The ONE choice SciPy leaves to an unstable ``np.argsort`` is made explicit: of
+    equal heights the higher index ranks first (what a stable sort gives).  Pinned to SciPy's own output on the tie-free
+    lines of ``tests/golden/peaks_ref.npz`` (``tests/test_oracle_pins.py``); the checker of the device kernel where ties
+    closer than ``distance`` make SciPy's answer depend on NumPy's sort."""
+    x = np.asarray(x)
+    n = len(x)
+    pk, i = [], 1
+    while i < n - 1:
+        if x[i - 1] < x[i]:
+            j = i + 1
+            while j < n - 1 and x[j] == x[i]:
+                j += 1
+            if x[j] < x[i]:
+                pk.append((i + j - 1) // 2)
+                i = j
+        i += 1
+    pk = np.array([p for p in pk if float(x[p]) >= height], np.int64)
+    d = math.ceil(distance)
+    keep = np.ones(len(pk), bool)
+    for j in sorted(range(len(pk)), key=lambda q: (x[pk[q]], pk[q]), reverse=True):
+        if not keep[j]:
+            continue
+        k = j - 1
+        while k >= 0 and pk[j] - pk[k] < d:
+            keep[k] = False
+            k -= 1
+        k = j + 1
+        while k < len(pk) and pk[k] - pk[j] < d:
+            keep[k] = False
+            k += 1
+    return pk[keep]
+
+
 # ------------------------------------------------------------------ test signals
 # The synthetic wideband IQ source and the benchmark configurations are not part of
 # the algorithm under test; they live with the synthetic SDR device.

@@ -102,6 +102,7 @@ PROTOTYPES = {
     "pysdr_waterfall_roll": (_i, [_vp, _i]),
     "pysdr_waterfall_image": (_i, [_vp, _f, _pf, _pf, _pf]),
     "pysdr_waterfall_image_rows": (_i, [_vp, _f, _i, _pf, _pf, _pf]),
+    "pysdr_waterfall_peaks": (_i, [_vp, _pf, _i, C.c_double, _i, C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32)]),
     "pysdr_dev_alloc": (_i, [_i, _sz, C.POINTER(_vp)]),
     "pysdr_dev_free": (_i, [_i, _vp]),
     "pysdr_dev_upload": (_i, [_i, _vp, _vp, _sz]),

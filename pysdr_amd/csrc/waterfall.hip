@@ -19,6 +19,7 @@ struct pysdr_waterfall {
   float* d_mean = nullptr;   // [nfft]
   float* d_stat = nullptr;   // [0] bkgnd, [1] max(wf)
   float* d_image = nullptr;  // [ncols][nfft]
+  int* d_pk = nullptr;       // peak pick scratch: [3][nfft / 2 + 2] positions, states, kept indices; + [1] the count
   hipStream_t stream = nullptr;
 };
 
@@ -135,6 +136,131 @@ __global__ __launch_bounds__(256) void wf_image_kernel(const float* __restrict__
   img[(size_t)c * nfft + i] = fmaxf(wf[(size_t)s * nfft + p] - bk, zmax - pan_dr);
 }
 
+// ---- scipy.signal.find_peaks(x, height = h, distance = d) on the device (Plotting.py:594-602: the peak pick on the averaged
+// PSD), ONE workgroup.  The three steps of SciPy's implementation, each in its parallel form:
+//  (1) local maxima with flat tops (_local_maxima_1d): a peak is a FALL x[i] < x[i-1] whose previous change point p (largest
+//      p < i with x[p] != x[p-1]) was a RISE; the plateau is [p, i-1], the peak its midpoint (p + i - 1) / 2 (integer
+//      division).  Flat stretches touching either end of the line have no rise / no fall and are no peaks, as there.  The
+//      previous change point is an exclusive prefix maximum: per-thread chunks, a scan of the 1024 chunk results in LDS.
+//  (2) height: x[peak] >= h, compared in double (h = bkgnd + 10 is a double there).
+//  (3) distance (_select_by_peak_distance): greedily by priority = height, every kept peak removes all peaks closer than
+//      ceil(d).  Rounds: an undecided peak that outranks every not-yet-removed peak closer than d is KEPT (the greedy order
+//      would reach it before anything could remove it); then every undecided peak closer than d to a kept one is REMOVED;
+//      until nothing is undecided.  Same result as the sequential greedy walk whenever the heights differ.  TIES: SciPy
+//      ranks equal heights by an UNSTABLE np.argsort, i.e. which of two equal peaks closer than d survives there depends
+//      on NumPy's sort of the day; here the one with the higher index outranks (what a stable sort would give).
+__global__ __launch_bounds__(1024) void wf_peaks_kernel(const float* __restrict__ x, int n, double height, int dist,
+                                                        int* __restrict__ pos, int* __restrict__ state,
+                                                        int* __restrict__ kept, int* __restrict__ count) {
+  __shared__ int sh[1024];
+  __shared__ int sh2[1024];
+  __shared__ int flag;
+  const int t = threadIdx.x;
+  const int C = (n + 1023) / 1024;
+  const int lo = t * C, hi = (lo + C < n) ? lo + C : n;
+  // (1a) last change point of every chunk, exclusive prefix maximum over the chunks
+  int last = -1;
+  for (int i = (lo > 1 ? lo : 1); i < hi; ++i)
+    if (x[i] != x[i - 1]) last = i;
+  sh[t] = last;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (t >= o) ? sh[t - o] : -1;
+    __syncthreads();
+    sh[t] = max(sh[t], v);
+    __syncthreads();
+  }
+  const int carry = (t > 0) ? sh[t - 1] : -1;
+  __syncthreads();
+  // (1b + 2) this chunk's peaks: counted, then (with the chunks' prefix sum) written in order of position
+  auto walk = [&](int* out) {
+    int prev = carry, cnt = 0;
+    for (int i = (lo > 1 ? lo : 1); i < hi; ++i) {
+      const float a = x[i - 1], b = x[i];
+      if (a == b) continue;
+      if (b < a && prev >= 1 && x[prev] > x[prev - 1]) {
+        const int mid = (prev + i - 1) >> 1;
+        if ((double)x[mid] >= height) {
+          if (out) out[cnt] = mid;
+          ++cnt;
+        }
+      }
+      prev = i;
+    }
+    return cnt;
+  };
+  const int mine = walk(nullptr);
+  sh2[t] = mine;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (t >= o) ? sh2[t - o] : 0;
+    __syncthreads();
+    sh2[t] += v;
+    __syncthreads();
+  }
+  const int P = sh2[1023];
+  (void)walk(pos + (sh2[t] - mine));
+  for (int j = t; j < P; j += 1024) state[j] = 0;
+  __threadfence_block();
+  __syncthreads();
+  // (3) the distance rule in rounds; 0 undecided, 1 kept, 2 removed
+  auto outranks = [&](int k, int j) {             // peak k before peak j in the greedy order
+    const float a = x[pos[k]], b = x[pos[j]];
+    return a > b || (a == b && k > j);
+  };
+  if (dist > 1) {
+    for (;;) {
+      if (t == 0) flag = 0;
+      __syncthreads();
+      for (int j = t; j < P; j += 1024) {
+        if (state[j] != 0) continue;
+        bool best = true;
+        for (int k = j - 1; best && k >= 0 && pos[j] - pos[k] < dist; --k)
+          if (((volatile int*)state)[k] != 2 && outranks(k, j)) best = false;
+        for (int k = j + 1; best && k < P && pos[k] - pos[j] < dist; ++k)
+          if (((volatile int*)state)[k] != 2 && outranks(k, j)) best = false;
+        if (best) ((volatile int*)state)[j] = 1;
+      }
+      __threadfence_block();
+      __syncthreads();
+      for (int j = t; j < P; j += 1024) {
+        if (state[j] != 0) continue;
+        bool gone = false;
+        for (int k = j - 1; !gone && k >= 0 && pos[j] - pos[k] < dist; --k) gone = (state[k] == 1);
+        for (int k = j + 1; !gone && k < P && pos[k] - pos[j] < dist; ++k) gone = (state[k] == 1);
+        if (gone) state[j] = 2;
+        else flag = 1;                             // still undecided: another round
+      }
+      __threadfence_block();
+      __syncthreads();
+      const int again = flag;
+      __syncthreads();
+      if (!again) break;
+    }
+  } else {
+    for (int j = t; j < P; j += 1024) state[j] = 1;
+    __threadfence_block();
+    __syncthreads();
+  }
+  // kept peaks, in order of position
+  const int PC = (P + 1023) / 1024;
+  const int plo = t * PC, phi = (plo + PC < P) ? plo + PC : P;
+  int kc = 0;
+  for (int j = plo; j < phi; ++j) kc += (state[j] == 1);
+  sh[t] = kc;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (t >= o) ? sh[t - o] : 0;
+    __syncthreads();
+    sh[t] += v;
+    __syncthreads();
+  }
+  int w = sh[t] - kc;
+  for (int j = plo; j < phi; ++j)
+    if (state[j] == 1) kept[w++] = pos[j];
+  if (t == 0) *count = sh[1023];
+}
+
 }  // namespace
 }  // namespace pysdr
 
@@ -156,6 +282,7 @@ int pysdr_waterfall_create(int device, int nfft, int ncols, pysdr_waterfall** ou
   CK(hipMalloc(&w->d_line, (size_t)nfft * sizeof(float)));
   CK(hipMalloc(&w->d_mean, (size_t)nfft * sizeof(float)));
   CK(hipMalloc(&w->d_stat, 4 * sizeof(float)));
+  CK(hipMalloc(&w->d_pk, (3 * ((size_t)nfft / 2 + 2) + 1) * sizeof(int)));
 #undef CK
   hipLaunchKernelGGL(wf_fill_kernel, dim3(1024), dim3(256), 0, w->stream, w->d_wf, n, kFill);
   if (hipStreamSynchronize(w->stream) != hipSuccess) { pysdr_waterfall_destroy(w); return PYSDR_ERR_HIP; }
@@ -172,6 +299,7 @@ void pysdr_waterfall_destroy(pysdr_waterfall* w) {
   if (w->d_line) (void)hipFree(w->d_line);
   if (w->d_mean) (void)hipFree(w->d_mean);
   if (w->d_stat) (void)hipFree(w->d_stat);
+  if (w->d_pk) (void)hipFree(w->d_pk);
   if (w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
 }
@@ -221,6 +349,34 @@ int pysdr_waterfall_image_rows(pysdr_waterfall* w, float pan_dr, int npsd, float
   if (mean_out) PYSDR_HIP_CHECK(hipMemcpyAsync(mean_out, w->d_mean, (size_t)w->nfft * sizeof(float), hipMemcpyDeviceToHost, w->stream));
   if (bkgnd_out) PYSDR_HIP_CHECK(hipMemcpyAsync(bkgnd_out, w->d_stat, sizeof(float), hipMemcpyDeviceToHost, w->stream));
   PYSDR_HIP_CHECK(hipStreamSynchronize(w->stream));
+  return PYSDR_OK;
+}
+
+int pysdr_waterfall_peaks(pysdr_waterfall* w, const float* line, int n, double height, int distance, int* idx_out, int cap,
+                          int* n_out) {
+  if (!w || !n_out || n < 0 || n > w->nfft || distance < 1 || cap < 0 || (cap > 0 && !idx_out)) return PYSDR_ERR_ARG;
+  PYSDR_HIP_CHECK(hipSetDevice(w->device));
+  const float* x = w->d_mean;
+  if (line) {
+    PYSDR_HIP_CHECK(hipMemcpyAsync(w->d_line, line, (size_t)n * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    x = w->d_line;
+  } else if (w->cnt < 1) {
+    set_last_error("pysdr_waterfall_peaks: no averaged line yet (pysdr_waterfall_image first, or pass a line)");
+    return PYSDR_ERR_STATE;
+  }
+  const size_t half = (size_t)w->nfft / 2 + 2;
+  int* pos = w->d_pk, *state = w->d_pk + half, *kept = w->d_pk + 2 * half, *count = w->d_pk + 3 * half;
+  hipLaunchKernelGGL(wf_peaks_kernel, dim3(1), dim3(1024), 0, w->stream, x, n, height, distance, pos, state, kept, count);
+  PYSDR_HIP_CHECK(hipGetLastError());
+  int np_ = 0;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&np_, count, sizeof(int), hipMemcpyDeviceToHost, w->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(w->stream));
+  *n_out = np_;
+  const int m = np_ < cap ? np_ : cap;
+  if (m > 0) {
+    PYSDR_HIP_CHECK(hipMemcpyAsync(idx_out, kept, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, w->stream));
+    PYSDR_HIP_CHECK(hipStreamSynchronize(w->stream));
+  }
   return PYSDR_OK;
 }
 

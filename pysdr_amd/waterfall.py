@@ -6,8 +6,9 @@ from __future__ import annotations
 import ctypes as C
 import sys
 
+import math
+
 import numpy as np
-from scipy import signal
 
 from . import _lib
 from ._lib import check
@@ -66,8 +67,23 @@ class Waterfall:
                                                     C.byref(bk)), "pysdr_waterfall_image_rows")
         return img.T[:npsd], bk.value, mean
 
-    @staticmethod
-    def peaks(psd2, bkgnd, peak_dist, df):
-        """``Plotting.py:594-602``: peak pick on the averaged PSD (host, SciPy)."""
-        pk, _ = signal.find_peaks(psd2, distance=peak_dist / df, height=bkgnd + 10)
-        return pk
+    def peaks(self, bkgnd, peak_dist, df, psd2=None):
+        """``Plotting.py:594-602``: ``peaks, _ = signal.find_peaks(PSD2, distance=PEAK_DIST/df, height=bkgnd+10)`` on the
+        device (``pysdr_waterfall_peaks``: flat tops, height, SciPy's priority-by-height distance rule) -> ascending bin
+        indices.  Over the averaged line the last ``image()`` left on the device, or over ``psd2`` if one is given."""
+        n = int(getattr(self, 'npsd', self.nfft)) if psd2 is None else len(psd2)
+        dist = max(1, int(math.ceil(float(peak_dist) / float(df))))
+        line = None
+        if psd2 is not None:
+            line = np.ascontiguousarray(psd2, np.float32)
+            if n > self.nfft:
+                raise ValueError(f"peaks: a line of {n} bins on a waterfall of {self.nfft}")
+        else:
+            n = self.nfft                      # the reference picks over all of PSD2 (Plotting.py:583,595)
+        cap = self.nfft // 2 + 1
+        idx = np.empty(cap, np.int32)
+        cnt = C.c_int32(0)
+        check(_lib.lib().pysdr_waterfall_peaks(self._h, None if line is None else _lib.as_pf(line), n, float(bkgnd) + 10.0, dist,
+                                               idx.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(cnt)),
+              "pysdr_waterfall_peaks")
+        return idx[:cnt.value].astype(np.int64)

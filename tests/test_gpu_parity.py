@@ -948,8 +948,7 @@ def test_waterfall_backend_matches_plotting_py_numerics():
             assert abs(bk - rbk) <= 1e-5 * abs(rbk)
             assert np.allclose(psd2, rpsd2, rtol=1e-5)
             assert np.allclose(img, rimg, rtol=1e-5, atol=1e-3)
-            assert np.array_equal(Waterfall.peaks(psd2.astype(np.float64), bk, 10.0, df),
-                                  so.find_peaks_db(rpsd2, rbk, 10.0 / df)) or k != 129
+            assert np.array_equal(w.peaks(bk, 10.0, df), so.find_peaks_db(rpsd2, rbk, 10.0 / df)) or k != 129
 
 
 def test_waterfall_backend_equals_the_executed_reference_text():
@@ -968,10 +967,43 @@ def test_waterfall_backend_equals_the_executed_reference_text():
         assert abs(bk - float(g[f"bk{k}"])) <= 1e-5 * abs(float(g[f"bk{k}"]))
         assert np.allclose(psd2, g[f"psd2_{k}"], rtol=1e-5)
         assert np.allclose(img, ref, rtol=1e-5, atol=1e-3)
-        pk = Waterfall.peaks(psd2.astype(np.float64), bk, float(g["peak_dist"]), float(g["df"]))
+        pk = w.peaks(bk, float(g["peak_dist"]), float(g["df"]))               # on the device, over the line image() left there
         assert np.array_equal(pk, g[f"peaks{k}"])
         seen += 1
     assert seen == 4
+
+
+def test_peak_pick_on_the_device_equals_the_executed_reference_statement():
+    """N1's last host step: `signal.find_peaks(PSD2, distance=dist, height=bkgnd+10)` (Plotting.py:594-602) as
+    a kernel (waterfall.hip wf_peaks_kernel), index for index against tests/golden/peaks_ref.npz -- the reference's own
+    statements executed on lines with carriers, flat tops, flat stretches at both ends, peaks in the first / last interior
+    bin, equal heights further apart than the distance, a dense comb and a staircase (the distance rule's rounds), a 64k
+    line.  Equal heights CLOSER than the distance are where SciPy's own answer hangs on an unstable argsort: there (and on
+    random lines full of ties and plateaus) the kernel is held to the written-out greedy walk with its tie rule."""
+    from pysdr_amd.waterfall import Waterfall
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "peaks_ref.npz"))
+    w = Waterfall(65536, 2)
+    for k in range(int(g["ncases"])):
+        x, pd, df, bk = g[f"line{k}"], float(g[f"peak_dist{k}"]), float(g[f"df{k}"]), float(g[f"bk{k}"])
+        got = w.peaks(bk, pd, df, psd2=x)
+        want = g[f"peaks{k}"] if not int(g[f"tie{k}"]) else so.find_peaks_greedy(x.astype(np.float64), bk + 10.0, pd / df)
+        assert np.array_equal(got, want), (k, len(got), len(want))
+        assert np.array_equal(so.find_peaks_greedy(x.astype(np.float64), bk + 10.0, pd / df), want), k
+    rng = np.random.default_rng(30)
+    for trial in range(40):
+        n = int(rng.choice([3, 8, 17, 100, 1000, 8192, 65536]))
+        kind = trial % 4
+        x = rng.standard_normal(n) * 3
+        if kind == 1:
+            x = np.round(x)                                                     # ties and plateaus everywhere
+        elif kind == 2:
+            x = np.repeat(np.round(rng.standard_normal(n // 4 + 1) * 3), 4)[:n]
+        x = x.astype(np.float32)
+        bk = float(np.median(x)) - (9.0 if kind else 8.5)                       # height = median + 1 / + 1.5
+        dist = float(rng.choice([1.0, 2.5, 7.0, 33.3, 82.0]))
+        got = w.peaks(bk, dist, 1.0, psd2=x)
+        assert np.array_equal(got, so.find_peaks_greedy(x.astype(np.float64), bk + 10.0, dist)), (trial, n, kind, dist)
+    assert "scipy" not in open(os.path.join(os.path.dirname(__file__), "..", "pysdr_amd", "waterfall.py")).read()
 
 
 @pytest.mark.parametrize("name,B", [("C3", 2048), ("C2", 2048), ("C1", 4096), ("FT8TRI", 2048), ("TEST2RX", 4096)])

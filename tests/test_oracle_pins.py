@@ -230,3 +230,32 @@ def test_oracle_waterfall_equals_the_executed_reference_text():
         assert np.array_equal(so.find_peaks_db(psd2, bk, float(g["peak_dist"]) / float(g["df"])), g[f"peaks{k}"])
         seen += 1
     assert seen == 4
+
+
+def test_written_out_find_peaks_equals_the_executed_reference_statement():
+    """`oracle.find_peaks_greedy` (the checker of the device peak pick) against tests/golden/peaks_ref.npz: the reference's
+    `signal.find_peaks(PSD2, distance=dist, height=bkgnd+10)` (Plotting.py:587,594,596 executed as they stand,
+    tests/golden/make_peaks_ref_golden.py) on every tie-free line, index for index; and against SciPy itself here on random
+    lines whose heights are all distinct (flat tops of every width included)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "peaks_ref.npz"))
+    seen = 0
+    for k in range(int(g["ncases"])):
+        if int(g[f"tie{k}"]):
+            continue
+        x, bk = g[f"line{k}"].astype(np.float64), float(g[f"bk{k}"])
+        assert abs(bk - float(np.median(x))) == 0.0
+        got = so.find_peaks_greedy(x, bk + 10.0, float(g[f"peak_dist{k}"]) / float(g[f"df{k}"]))
+        assert np.array_equal(got, g[f"peaks{k}"]), k
+        seen += 1
+    assert seen >= 7
+    rng = np.random.default_rng(31)
+    for trial in range(60):
+        n = int(rng.choice([3, 8, 17, 100, 1000, 8192]))
+        m = max(1, n // int(rng.choice([1, 2, 5])))
+        x = np.repeat(rng.permutation(m).astype(np.float32) * 0.25 - 3.0, rng.integers(1, 6, m))[:n]
+        if len(x) < n:
+            x = np.r_[x, rng.permutation(n - len(x)).astype(np.float32) + 1e4]
+        h, dist = float(np.median(x)), float(rng.choice([1.0, 2.5, 7.0, 33.3]))
+        want, _ = signal.find_peaks(x, distance=dist, height=h)
+        assert np.array_equal(so.find_peaks_greedy(x, h, dist), want), (trial, n, dist)
