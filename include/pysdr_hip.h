@@ -132,6 +132,15 @@ int pysdr_pll_linear_starts(pysdr_ctx* ctx, int irx, int* n);
  * muted while it exceeds `thresh`; thresh <= 0 disables (default). */
 int pysdr_set_squelch(pysdr_ctx* ctx, int irx, float thresh);
 int pysdr_squelch_get(pysdr_ctx* ctx, int irx, float* level, int* open);
+/* The RATIO squelch, as the only design the reference holds sketches it (sigs/squelch.m:92-145; no run-time call site): z1 =
+ * low-pass < 3 kHz and z2 = high-pass > 4 kHz of the discriminator output (`lp`, `hp`: FIR taps, ntaps <= 64, for the
+ * context's FS_OUT; there: elliptic IIRs of order 5, :103-105), sq1 / sq2 = one-pole envelopes of |z1| / |z2| per SAMPLE with
+ * alpha = 0.001 (:131-134), and the gate open while sq1 / sq2 >= min_ratio (:145) -- independent of the signal's level.  One
+ * decision per chunk (the AGC block), on the envelopes behind its last sample.  min_ratio > 0 arms it for that sub-receiver
+ * (NFM) and takes precedence over pysdr_set_squelch; 0 disarms.  pysdr_squelch_ratio_get: the two envelopes and the gate
+ * behind the last call. */
+int pysdr_set_squelch_ratio(pysdr_ctx* ctx, int irx, float min_ratio, const float* lp, const float* hp, int ntaps);
+int pysdr_squelch_ratio_get(pysdr_ctx* ctx, int irx, float* sq_lp, float* sq_hp, int* open);
 /* AGC on/off and reference level */
 int pysdr_set_agc(pysdr_ctx* ctx, int irx, int enable, float ref);
 

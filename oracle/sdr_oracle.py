@@ -41,6 +41,22 @@ AUTO_MUTE_THRESH = 0.7         # |x| peak of the raw chunk that trips auto-mute
 PLL_ZETA = 0.7071
 PLL_BW_HZ = 50.0
 SQUELCH_ALPHA = 0.64           # per-block smoothing = 1-(1-0.001)^1024 (sigs/squelch.m alpha=0.001/sample)
+# The RATIO squelch, as sigs/squelch.m:92-145 sketches it: z1 = low-pass < 3 kHz and z2 = high-pass > 4 kHz of the
+# discriminator output (there elliptic IIRs of order 5, :103-105; here their FIR equivalents -- the path has no IIR machinery and a
+# linear-phase pair keeps the two envelopes aligned), sq1 / sq2 = one-pole envelopes of |z1| / |z2| PER SAMPLE with
+# alpha = 0.001 (:131-134), the decision on sq1 / sq2 (:145) -- amplitude independent.  "parity unpinned": the reference has
+# the sketch, no run-time call.
+SQ_RATIO_ALPHA = 0.001
+SQ_RATIO_TAPS = 63
+SQ_RATIO_LP_HZ = 3000.0
+SQ_RATIO_HP_HZ = 4000.0
+
+
+def squelch_ratio_taps(fs_out, dtype=np.float32):
+    """(low-pass < 3 kHz, high-pass > 4 kHz), 63 taps each, Hamming (``sigs/squelch.m:103-105``: the bands)."""
+    lp = signal.firwin(SQ_RATIO_TAPS, SQ_RATIO_LP_HZ, window='hamming', fs=fs_out)
+    hp = signal.firwin(SQ_RATIO_TAPS, SQ_RATIO_HP_HZ, window='hamming', pass_zero=False, fs=fs_out)
+    return lp.astype(dtype), hp.astype(dtype)
 
 
 # ------------------------------------------------------------------ rates / sizes
@@ -409,6 +425,8 @@ class Demodulator:
         # the NFM noise squelch (sigs/squelch.m:92-145: HP envelope, one-pole smoothing)
         dr = d.real.astype(self.rd)
         self.last_hp = np.abs(dr[hl:] - self.rd(2) * dr[hl - 1:-1] + dr[hl - 2:-2]).astype(self.rd) if n else dr[:0]
+        # ... and for the ratio squelch the detector output itself, with the history its two FIRs reach back over
+        self.last_det = dr[hl - (SQ_RATIO_TAPS - 1):] if n else dr[:0]
         self.yhist = ybuf[len(ybuf) - (hl + 2):]
         self.m_abs += n
         return a.astype(self.cd)
@@ -448,6 +466,10 @@ class Receiver:
         self.squelch = dtype(0)        # NFM noise-squelch threshold, 0 = off
         self.sq_level = dtype(0)
         self.sq_open = True
+        self.squelch_ratio = dtype(0)  # the ratio squelch: open while sq1 / sq2 >= this; 0 = off (takes precedence when armed)
+        self.sq_lp = dtype(0)          # sq1: envelope of the < 3 kHz part of the discriminator output
+        self.sq_hp = dtype(0)          # sq2: envelope of the > 4 kHz part
+        self._sq_taps = squelch_ratio_taps(self.fs_out, dtype)
         self.xhist = np.zeros(0, self.cd)
 
     @staticmethod
@@ -502,7 +524,20 @@ class Receiver:
             a = a.real.astype(self.rd)
             peak = np.max(np.abs(a)) if len(a) else 0.0
         g = self.agc.update(peak, self.mode in AGC_MODES)
-        if self.mode == 'NFM' and self.squelch > 0 and len(a):
+        if self.mode == 'NFM' and self.squelch_ratio > 0 and len(a):
+            # sigs/squelch.m:127-145: z1, z2 -> |.| -> filter(alpha, [1 alpha-1], .) per sample -> ratio; the gate follows
+            # the ratio behind the chunk's last sample (a chunk is the AGC block: one gain per chunk)
+            al = self.rd(SQ_RATIO_ALPHA)
+            b, aa = np.array([al], self.rd), np.array([1, al - 1], self.rd)
+            det = self.demod.last_det
+            for name, taps in (("sq_lp", self._sq_taps[0]), ("sq_hp", self._sq_taps[1])):
+                z = np.abs(np.convolve(det, taps, mode='valid').astype(self.rd))
+                env, _ = signal.lfilter(b, aa, z, zi=np.array([(self.rd(1) - al) * getattr(self, name)], self.rd))
+                setattr(self, name, self.rd(env[-1]))
+            self.sq_open = bool(self.sq_lp >= self.rd(self.squelch_ratio) * self.sq_hp)
+            if not self.sq_open:
+                g = self.rd(0)
+        elif self.mode == 'NFM' and self.squelch > 0 and len(a):
             noise = self.rd(np.sum(self.demod.last_hp.astype(np.float64)) / len(a))
             self.sq_level = self.rd(self.sq_level + self.rd(SQUELCH_ALPHA) * self.rd(noise - self.sq_level))
             self.sq_open = bool(self.sq_level <= self.rd(self.squelch))

@@ -70,6 +70,8 @@ PROTOTYPES = {
     "pysdr_set_agc": (_i, [_vp, _i, _i, _f]),
     "pysdr_set_squelch": (_i, [_vp, _i, _f]),
     "pysdr_squelch_get": (_i, [_vp, _i, _pf, _pi]),
+    "pysdr_set_squelch_ratio": (_i, [_vp, _i, _f, _pf, _pf, _i]),
+    "pysdr_squelch_ratio_get": (_i, [_vp, _i, _pf, _pf, _pi]),
     "pysdr_process": (_i, [_vp, _pf, _sz, C.POINTER(Out)]),
     "pysdr_process_batch": (_i, [_vp, _vp, _i, _sz, _i]),
     "pysdr_fetch": (_i, [_vp, _i, _pf, _pf, _i, _pi, _pi, _pi, _pf]),

@@ -104,6 +104,7 @@ struct RxHost {
   int agc_enable = 1;
   float agc_ref = 0.5f;
   float sq_thresh = 0.f;
+  float sq_ratio = 0.f;         // ratio squelch armed (> 0: the least sq1 / sq2 that keeps the gate open); takes precedence
   float2* d_y = nullptr;        // [hy + mmax]
   float2* d_y_alt = nullptr;    // the second buffer of the pair, allocated when the context overlaps its calls (pysdr_set_overlap)
   float2* d_ypll = nullptr;     // [hy + mmax], allocated on first AM-Synch use
@@ -132,7 +133,7 @@ struct RxHost {
 struct RxSnap {
   int mode = PYSDR_AM;
   uint32_t fword = 0, phase = 0, bfo_fword = 0;
-  float sq_thresh = 0.f;
+  float sq_thresh = 0.f, sq_ratio = 0.f;
   int taps_real = 0;
   float2 *d_y = nullptr, *d_ypll = nullptr, *d_a = nullptr, *d_y1 = nullptr, *d_w = nullptr;   // d_y / d_ypll / d_y1 / d_w: THIS call's buffer of each pair
   float2 *d_y_next = nullptr, *d_ypll_next = nullptr, *d_y1_next = nullptr;   // the next call's (the same one unless the calls overlap): gets the history prefix
@@ -224,6 +225,9 @@ struct pysdr_ctx {
   unsigned* d_blkpeak = nullptr; // [MAX_RX][max_chunks]
   float* d_gain = nullptr;       // [MAX_RX][max_chunks]
   float* d_blknoise = nullptr;   // [MAX_RX][max_chunks]
+  float* d_blknoise2 = nullptr;  // [MAX_RX][max_chunks] ratio squelch: the low-pass envelope's block sums (allocated when first armed)
+  float* d_sqtaps = nullptr;     // [2][kSqTapsMax] its two FIRs
+  int sq_ntaps = 0;
   unsigned* d_blkcnt = nullptr;  // [MAX_RX][max_chunks]
   RxDevState* d_state = nullptr; // [MAX_RX]
   uint32_t* d_pllseg = nullptr;  // [MAX_RX][kPllSegMax][4] start/end states of the time-parallel PLLs + [MAX_RX][kPllSegMax] flags (PllPlan::lin)
@@ -693,7 +697,7 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
       RxDevState st;
       PYSDR_HIP_CHECK(hipMemcpyAsync(&st, c->d_state + r, sizeof(st), hipMemcpyDeviceToHost, c->stream));
       PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
-      if (x.reset_pending & 1u) { st.env = 0.f; st.gain = 1.f; st.maxbuf = 0.f; st.err = 0.f; st.sq_level = 0.f; st.sq_open = 1; }
+      if (x.reset_pending & 1u) { st.env = 0.f; st.gain = 1.f; st.maxbuf = 0.f; st.err = 0.f; st.sq_level = 0.f; st.sq_open = 1; st.sq_lp = 0.f; st.sq_hp = 0.f; }
       if (x.reset_pending & 2u) { st.pll_phase = 0u; st.pll_w = 0.f; st.wfm_phase = 0u; st.wfm_w = 0.f; st.wfm_slope_ok = 0; }
       st.ref = x.agc_ref; st.agc_enable = x.agc_enable;
       PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_state + r, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
@@ -740,7 +744,7 @@ int apply_pending(pysdr_ctx* c, CallSnap* snap) {
     }
     RxSnap& q = snap->rx[r];
     q.mode = x.mode; q.fword = x.fword; q.phase = x.phase; q.bfo_fword = x.bfo_fword;
-    q.sq_thresh = x.sq_thresh; q.taps_real = x.taps_real;
+    q.sq_thresh = x.sq_thresh; q.sq_ratio = x.sq_ratio; q.taps_real = x.taps_real;
     q.d_a = x.d_a; q.d_am = x.d_am; q.d_aftaps = x.d_aftaps;
     q.d_seed = x.d_seed;
     q.d_mnt = x.d_mnt[c->par];
@@ -790,10 +794,12 @@ void fill_stage2(pysdr_ctx* c, const CallSnap& snap, bool wfm, int nchunks, size
     while (s.single_spread * 2 <= std::min(nchunks, 32)) s.single_spread *= 2;
     s.matrix[r] = (x.mode == PYSDR_WFM2) ? 1 : 0;
     s.bfo_fword[r] = x.bfo_fword;
-    s.sq_thresh[r] = x.sq_thresh;
+    s.sq_ratio[r] = (x.sq_ratio > 0.f && c->d_sqtaps != nullptr) ? 1 : 0;
+    s.sq_thresh[r] = s.sq_ratio[r] ? x.sq_ratio : x.sq_thresh;
   }
   s.blkpeak = c->d_blkpeak; s.gain = c->d_gain; s.state = c->d_state;
   s.blknoise = c->d_blknoise; s.blkcnt = c->d_blkcnt;
+  s.blknoise2 = c->d_blknoise2; s.sqtaps = c->d_sqtaps; s.sq_ntaps = c->sq_ntaps;
 }
 
 // T: the tail of a call on `stream` -- for broadcast FM the audio resamplers first, then detector + AF FIR, the block
@@ -1029,6 +1035,8 @@ void pysdr_destroy(pysdr_ctx* c) {
   if (c->d_blkpeak) (void)hipFree(c->d_blkpeak);
   if (c->d_gain) (void)hipFree(c->d_gain);
   if (c->d_blknoise) (void)hipFree(c->d_blknoise);
+  if (c->d_blknoise2) (void)hipFree(c->d_blknoise2);
+  if (c->d_sqtaps) (void)hipFree(c->d_sqtaps);
   if (c->d_blkcnt) (void)hipFree(c->d_blkcnt);
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->d_pllseg) (void)hipFree(c->d_pllseg);
@@ -1137,6 +1145,46 @@ int pysdr_set_squelch(pysdr_ctx* c, int irx, float thresh) {
   if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
   std::lock_guard<std::mutex> lk(c->mu);
   c->rx[irx].sq_thresh = thresh > 0.f ? thresh : 0.f;
+  return PYSDR_OK;
+}
+
+int pysdr_set_squelch_ratio(pysdr_ctx* c, int irx, float min_ratio, const float* lp, const float* hp, int ntaps) {
+  if (!c || irx < 0 || irx >= c->nrx || (min_ratio > 0.f && (!lp || !hp || ntaps < 1 || ntaps > kSqTapsMax))) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);     // allocates and uploads on the context's stream
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  if (min_ratio > 0.f) {
+    const size_t nb = (size_t)PYSDR_MAX_RX * c->cfg.max_chunks * kBlkStride * sizeof(float);
+    if (!c->d_blknoise2) {
+      PYSDR_HIP_CHECK(hipMalloc(&c->d_blknoise2, nb));
+      PYSDR_HIP_CHECK(hipMemsetAsync(c->d_blknoise2, 0, nb, c->stream));
+    }
+    if (!c->d_sqtaps) PYSDR_HIP_CHECK(hipMalloc(&c->d_sqtaps, 2 * kSqTapsMax * sizeof(float)));
+    float h[2 * kSqTapsMax] = {0.f};
+    for (int q = 0; q < ntaps; ++q) { h[q] = lp[q]; h[kSqTapsMax + q] = hp[q]; }
+    // (the two FIRs belong to the context -- they depend on FS_OUT only; pageable source: the copy is staged before the call returns)
+    PYSDR_HIP_CHECK(hipMemcpyAsync(c->d_sqtaps, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->sq_ntaps = ntaps;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->rx[irx].sq_ratio = min_ratio > 0.f ? min_ratio : 0.f;
+  return PYSDR_OK;
+}
+
+int pysdr_squelch_ratio_get(pysdr_ctx* c, int irx, float* sq_lp, float* sq_hp, int* open) {
+  if (!c || irx < 0 || irx >= c->nrx) return PYSDR_ERR_ARG;
+  std::lock_guard<std::recursive_mutex> run_lk(c->run_mu);
+  int rc = use_device(c->cfg.device);
+  if (rc) return rc;
+  RxDevState d;
+  rc = flush_tail(c);
+  if (rc) return rc;
+  PYSDR_HIP_CHECK(hipMemcpyAsync(&d, c->d_state + irx, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+  PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (sq_lp) *sq_lp = d.sq_lp;
+  if (sq_hp) *sq_hp = d.sq_hp;
+  if (open) *open = d.sq_open;
   return PYSDR_OK;
 }
 

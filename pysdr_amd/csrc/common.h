@@ -197,7 +197,13 @@ struct RxDevState {       // one per RX, lives in device memory
   int wfm_slope_ok;         // the last call ran in segments and none had to be patched: wfm_slope is usable
   int wfm_redo;             // this call's short warm-ups did not meet (stream discontinuity): run the long ones
   double wfm_slope;         // its mean pilot-phase increment per sample beyond fword0 (words of 2^32)
+  float sq_lp, sq_hp;       // ratio squelch (sigs/squelch.m:127-145): per-sample one-pole envelopes of the < 3 kHz / > 4 kHz parts of the
+                            // discriminator output, as they stand behind the last sample of the last call
 };
+// ratio squelch: taps per filter (device layout [2][kSqTapsMax]: low-pass, high-pass, zero padded), the envelopes' pole
+constexpr int kSqTapsMax = 64;
+constexpr float kSqAlpha = 0.001f;                 // sigs/squelch.m:131
+constexpr float kSqLog2Decay = -0.00144341686f;    // log2(1 - 0.001)
 
 // Time-parallel form of the serial PLLs (WFM2 pilot, AM-Synch carrier), DESIGN.md 4.2: the call's
 // samples are cut into K segments of T; segment k > 0 first runs the SAME recursion over the W
@@ -248,7 +254,11 @@ struct Stage2Args {
   int single_spread;                  // power of two <= min(nchunks, 32): a single-block RX spreads its peak atomics over that many
                                       // accumulators (one address for every wave of the call serialised: 14 of C4's 73 us AF FIR)
   int matrix[PYSDR_MAX_RX];           // WFM2: (S, D) -> (S+D) + j(S-D) = L + jR
-  float sq_thresh[PYSDR_MAX_RX];      // NFM noise squelch threshold, <= 0 disabled
+  float sq_thresh[PYSDR_MAX_RX];      // NFM noise squelch threshold, <= 0 disabled; with sq_ratio: the least sq1 / sq2 that keeps the gate open
+  int sq_ratio[PYSDR_MAX_RX];         // 1: the ratio squelch of sigs/squelch.m:92-145 instead of the block-noise one
+  int sq_ntaps;                       // taps of its two FIRs (<= kSqTapsMax)
+  const float* sqtaps;                // [2][kSqTapsMax] low-pass < 3 kHz, high-pass > 4 kHz
+  float* blknoise2;                   // [nrx][nchunks] ratio squelch: the block's weighted sum of |z1| (blknoise: of |z2|)
   float* blknoise;                    // [nrx][nchunks] sum |2nd difference of the detector output|
   unsigned* blkcnt;                   // [nrx][nchunks] outputs per block
   unsigned* blkpeak;                  // [nrx][nchunks] float bits

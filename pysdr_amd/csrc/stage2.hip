@@ -21,6 +21,15 @@ __device__ __forceinline__ uint32_t block_of(const Stage2Args& a, int r, int i) 
   return (t / (uint32_t)a.up) / a.chunk_len;
 }
 
+// first output index behind block b (the outputs of a block are contiguous; every block of a call is whole)
+__device__ __forceinline__ int block_end(const Stage2Args& a, int r, uint32_t b) {
+  if (a.single_block[r] || b + 1u >= (uint32_t)a.nchunks) return a.n_out;
+  const unsigned long long need = (unsigned long long)(b + 1u) * a.chunk_len * (unsigned)a.up;
+  if (need <= a.t0) return 0;
+  const unsigned long long i = (need - a.t0 + (unsigned)a.down - 1ull) / (unsigned)a.down;
+  return i < (unsigned long long)a.n_out ? (int)i : a.n_out;
+}
+
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -718,8 +727,31 @@ __device__ __forceinline__ void fir_epilogue(const Stage2Args& a, int r, int det
     }
   }
   const uint32_t wb0 = __shfl(blk_lo, 0);                 // lanes ascend: lane 0 invalid = wave invalid
-  float m0 = 0.f, m1 = 0.f, nz0 = 0.f, nz1 = 0.f;
+  float m0 = 0.f, m1 = 0.f, nz0 = 0.f, nz1 = 0.f, lz0 = 0.f, lz1 = 0.f;
   unsigned cnt0 = 0u, cnt1 = 0u;
+  // The RATIO squelch (sigs/squelch.m:92-145): z1 = low-pass < 3 kHz, z2 = high-pass > 4 kHz of the discriminator output
+  // (FIRs of sq_ntaps taps over the staged detector values), per-sample one-pole envelopes of |z1|, |z2| with alpha = 0.001.
+  // A one-pole is linear: behind a block of N samples it is (1 - alpha)^N s + sum_k alpha (1 - alpha)^(N-1-k) |z_k| -- this
+  // kernel leaves the block's weighted sums (blknoise2 / blknoise) and count, agc_scan_kernel runs the block recursion.
+  const bool ratio = squelch && a.sq_ratio[r] != 0;
+  float z1[kW], z2[kW];
+  int bend_lo = 0, bend_hi = 0;
+  if (ratio && valid) {
+    const int e0 = kW * tid + H + 3;                      // S element of output ib
+    float win[kW];
+#pragma unroll
+    for (int j = 0; j < kW; ++j) { z1[j] = 0.f; z2[j] = 0.f; win[j] = sre[fir_pad(e0 + j)]; }
+    for (int q = 0; q < a.sq_ntaps; ++q) {                // an output's sum runs over its taps in order: the same in any call
+      const float tl = a.sqtaps[q], th = a.sqtaps[kSqTapsMax + q];
+#pragma unroll
+      for (int j = 0; j < kW; ++j) { z1[j] = __fmaf_rn(tl, win[j], z1[j]); z2[j] = __fmaf_rn(th, win[j], z2[j]); }
+#pragma unroll
+      for (int j = kW - 1; j > 0; --j) win[j] = win[j - 1];
+      win[0] = sre[fir_pad(e0 - q - 1)];
+    }
+    bend_lo = block_end(a, r, blk_lo);
+    bend_hi = (blk_hi == blk_lo) ? bend_lo : block_end(a, r, blk_hi);
+  }
   if (valid) {
 #pragma unroll
     for (int j = 0; j < kW; ++j)
@@ -731,19 +763,25 @@ __device__ __forceinline__ void fir_epilogue(const Stage2Args& a, int r, int det
         const float m = CPLX ? sqrtf(acc[j].x * acc[j].x + acc[j].y * acc[j].y) : fabsf(acc[j].x);
         const uint32_t bj = (blk_lo == blk_hi) ? blk_lo : block_of(a, r, ib + j);
         const uint32_t slot = bj - wb0;
-        float hp = 0.f;
-        if (squelch) {
+        float hp = 0.f, lp = 0.f;
+        if (ratio) {
+          const int bend = (bj == blk_lo) ? bend_lo : ((bj == blk_hi) ? bend_hi : block_end(a, r, bj));
+          const float w = kSqAlpha * __builtin_amdgcn_exp2f(kSqLog2Decay * (float)(bend - 1 - (ib + j)));
+          hp = w * fabsf(z2[j]);
+          lp = w * fabsf(z1[j]);
+        } else if (squelch) {
           // NFM noise squelch (sigs/squelch.m:92-145): block sum of |2nd difference| of the
           // detector output -- out-of-band noise rises when the carrier goes away
           const int e = kW * tid + H + 3 + j;             // S element of output ib+j
           hp = fabsf(sre[fir_pad(e)] - 2.f * sre[fir_pad(e - 1)] + sre[fir_pad(e - 2)]);
         }
-        if (slot == 0u) { m0 = fmaxf(m0, m); nz0 += hp; cnt0 += 1u; }
-        else if (slot == 1u) { m1 = fmaxf(m1, m); nz1 += hp; cnt1 += 1u; }
+        if (slot == 0u) { m0 = fmaxf(m0, m); nz0 += hp; lz0 += lp; cnt0 += 1u; }
+        else if (slot == 1u) { m1 = fmaxf(m1, m); nz1 += hp; lz1 += lp; cnt1 += 1u; }
         else {
           const size_t k = ((size_t)r * a.nchunks + bj) * kBlkStride;
           atomicMax(a.blkpeak + k, __float_as_uint(m));
           if (squelch) { atomicAdd(a.blknoise + k, hp); atomicAdd(a.blkcnt + k, 1u); }
+          if (ratio) atomicAdd(a.blknoise2 + k, lp);
         }
       }
   }
@@ -755,6 +793,10 @@ __device__ __forceinline__ void fir_epilogue(const Stage2Args& a, int r, int det
       nz0 += __shfl_xor(nz0, o); nz1 += __shfl_xor(nz1, o);
       cnt0 += __shfl_xor(cnt0, o); cnt1 += __shfl_xor(cnt1, o);
     }
+    if (ratio) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { lz0 += __shfl_xor(lz0, o); lz1 += __shfl_xor(lz1, o); }
+    }
   }
   if ((tid & 63) == 0 && wb0 != 0xFFFFFFFFu) {
     // (a single-block RX -- broadcast FM -- deals its waves over single_spread accumulators: agc_scan_kernel folds them)
@@ -765,6 +807,8 @@ __device__ __forceinline__ void fir_epilogue(const Stage2Args& a, int r, int det
     if (squelch) {
       if (cnt0) { atomicAdd(a.blknoise + k0, nz0); atomicAdd(a.blkcnt + k0, cnt0); }
       if (cnt1) { atomicAdd(a.blknoise + k1, nz1); atomicAdd(a.blkcnt + k1, cnt1); }
+      if (ratio && cnt0) atomicAdd(a.blknoise2 + k0, lz0);
+      if (ratio && cnt1) atomicAdd(a.blknoise2 + k1, lz1);
     }
   }
 }
@@ -958,7 +1002,74 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
   if (a.single_block[r])
     for (int c = 1 + tid; c < nacc; c += 256) a.blkpeak[((size_t)r * a.nchunks + c) * kBlkStride] = 0u;
   const float env_last = nch > 0 ? pk[px(nch - 1)] : 0.f;       // (the squelch section reuses pk[])
-  if (a.sq_thresh[r] > 0.f) {
+  if (a.sq_thresh[r] > 0.f && a.sq_ratio[r]) {
+    // The ratio squelch's block recursion: behind a block of n samples each envelope is D s + W with D = (1 - alpha)^n and W the
+    // weighted sum the AF FIR kernel left (sq2 from blknoise, sq1 from blknoise2); the gate is open while sq1 >= thresh * sq2
+    // (sigs/squelch.m:145: the ratio).  D^17 < 2^-24 at 1024 samples per block, so it runs like the envelope above: segments
+    // warmed up over the kSqWarm blocks in front of them, joins compared bit for bit, lane 0 redoes what does not meet.
+    constexpr int kSqWarm = 32;
+    __syncthreads();
+    float* wH = ev;                                  // [px(nch)] W of sq2 (> 4 kHz)
+    float* wL = pk;                                  // [px(nch)] W of sq1 (< 3 kHz)
+    float* dk = sE + 256;                            // [px(nch)] D, < 0: a block without samples
+    float* lvH = dk + nlds;                          // [px(nch)] sq2 behind each block
+    float* lvL = lvH + nlds;                         // [px(nch)] sq1 behind each block
+    float* sS2 = lvL + nlds;                         // [256] + [256]: the second envelope's segment states
+    float* sE2 = sS2 + 256;
+    for (int c = tid; c < nch; c += 256) {
+      const size_t k = ((size_t)r * a.nchunks + c) * kBlkStride;
+      const unsigned n = a.blkcnt[k];
+      wH[px(c)] = a.blknoise[k];
+      wL[px(c)] = a.blknoise2[k];
+      dk[px(c)] = n > 0u ? __builtin_amdgcn_exp2f(kSqLog2Decay * (float)n) : -1.f;
+      a.blknoise[k] = 0.f;
+      a.blknoise2[k] = 0.f;
+      a.blkcnt[k] = 0u;
+    }
+    __syncthreads();
+    auto walk = [&](int c0, int c1, float& h, float& l, bool store) {
+      for (int c = c0; c < c1; ++c) {
+        const float d = dk[px(c)];
+        if (d >= 0.f) { h = __fmaf_rn(d, h, wH[px(c)]); l = __fmaf_rn(d, l, wL[px(c)]); }
+        if (store) { lvH[px(c)] = h; lvL[px(c)] = l; }
+      }
+    };
+    if (tid < K) {
+      const int s0 = tid * T, s1 = (s0 + T < nch) ? s0 + T : nch;
+      int wb = s0 - kSqWarm;
+      float h = 0.f, l = 0.f;
+      if (tid == 0 || wb <= 0) { wb = 0; h = st.sq_hp; l = st.sq_lp; }
+      walk(wb, s0, h, l, false);
+      sS[tid] = h; sS2[tid] = l;
+      walk(s0, s1, h, l, true);
+      sE[tid] = h; sE2[tid] = l;
+    }
+    __syncthreads();
+    const bool sq_miss = tid > 0 && tid < K && (__float_as_uint(sE[tid - 1]) != __float_as_uint(sS[tid]) ||
+                                                __float_as_uint(sE2[tid - 1]) != __float_as_uint(sS2[tid]));
+    if (__syncthreads_or(sq_miss) && tid == 0) {
+      for (int k = 1; k < K; ++k) {
+        if (__float_as_uint(sE[k - 1]) == __float_as_uint(sS[k]) && __float_as_uint(sE2[k - 1]) == __float_as_uint(sS2[k])) continue;
+        const int s0 = k * T, s1 = (s0 + T < nch) ? s0 + T : nch;
+        float h = sE[k - 1], l = sE2[k - 1];
+        walk(s0, s1, h, l, true);
+        sS[k] = sE[k - 1]; sS2[k] = sE2[k - 1];
+        sE[k] = h; sE2[k] = l;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < nch; c += 256)
+      if (dk[px(c)] >= 0.f && !(lvL[px(c)] >= a.sq_thresh[r] * lvH[px(c)])) a.gain[(size_t)r * a.nchunks + c] = 0.f;
+    if (tid == 0 && nch > 0) {
+      int open = st.sq_open;
+      for (int c = nch - 1; c >= 0; --c)
+        if (dk[px(c)] >= 0.f) { open = (lvL[px(c)] >= a.sq_thresh[r] * lvH[px(c)]) ? 1 : 0; break; }
+      a.state[r].sq_hp = lvH[px(nch - 1)];
+      a.state[r].sq_lp = lvL[px(nch - 1)];
+      a.state[r].sq_open = open;
+    }
+    __syncthreads();
+  } else if (a.sq_thresh[r] > 0.f) {
     // One-pole smoothing of the block noise, lvl += 0.64 (noise - lvl) over the blocks that hold samples, and the gate
     // (gain 0 = squelched).  The recursion forgets its start by 0.36 per block -- 0.36^17 < 2^-24 -- so it runs like the
     // envelope above: segments of T blocks, each warmed up over the kSqWarm blocks in front of it from lvl = 0, all joins
@@ -1507,7 +1618,10 @@ int launch_agc_scan(const Stage2Args& a, const EpilogueArgs& e, hipStream_t st) 
     return PYSDR_ERR_ARG;
   }
   const size_t nlds = (size_t)a.nchunks + (a.nchunks >> 4) + 1;      // padded: one word per 16 blocks (agc_scan_kernel: px)
-  const size_t lds = std::max((2 * nlds + 512) * sizeof(float), (size_t)e.hy * sizeof(float2));
+  bool any_ratio = false;
+  for (int r = 0; r < a.nrx; ++r) any_ratio |= (a.sq_ratio[r] != 0 && a.sq_thresh[r] > 0.f);
+  // (the ratio squelch's block recursion keeps three more arrays and a second pair of segment states)
+  const size_t lds = std::max(((any_ratio ? 5 : 2) * nlds + (any_ratio ? 1024 : 512)) * sizeof(float), (size_t)e.hy * sizeof(float2));
   // from ~7.6k blocks per call on this passes the 64 KB a kernel gets without asking (pysdr_create bounds max_chunks so
   // that it stays inside the 160 KB a workgroup can have); the attribute is per (function, device)
   if (lds > 48 * 1024) {

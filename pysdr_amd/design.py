@@ -112,3 +112,11 @@ def wfm_af_taps(fs_out, ntaps, af_bw=0.0):
     de = (1.0 - b) * b ** np.arange(WFM_DEEMPH_TAPS)
     lp = firwin(ntaps - WFM_DEEMPH_TAPS + 1, cut, window='hamming', fs=float(fs_out))
     return np.convolve(lp, de)
+
+
+def squelch_ratio_taps(fs_out, ntaps=63):
+    """The two FIRs of the ratio squelch (``sigs/squelch.m:103-105``: low-pass 3 kHz, high-pass 4 kHz; there elliptic IIRs of
+    order 5, here their linear-phase FIR equivalents) -> (lp, hp) float32."""
+    lp = firwin(ntaps, 3000.0, window='hamming', fs=fs_out)
+    hp = firwin(ntaps, 4000.0, window='hamming', pass_zero=False, fs=fs_out)
+    return np.ascontiguousarray(lp, np.float32), np.ascontiguousarray(hp, np.float32)

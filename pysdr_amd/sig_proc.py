@@ -439,6 +439,29 @@ class Receiver:
         self._squelch = float(thresh)
         check(self._ctx.L.pysdr_set_squelch(self._ctx.h, self.irx, self._squelch), "pysdr_set_squelch")
 
+    # -- the ratio squelch as sigs/squelch.m:92-145 sketches it: envelopes of the < 3 kHz and > 4 kHz parts of the discriminator
+    # output (one-pole per sample, alpha = 0.001), gate open while sq1 / sq2 >= ``rx.squelch_ratio`` -- independent of the signal's
+    # level.  0 disables; armed, it takes precedence over ``rx.squelch``.
+    @property
+    def squelch_ratio(self):
+        return getattr(self, '_squelch_ratio', 0.0)
+
+    @squelch_ratio.setter
+    def squelch_ratio(self, min_ratio):
+        from . import design
+        self._squelch_ratio = float(min_ratio)
+        lp, hp = design.squelch_ratio_taps(float(self._ctx.fs_out))
+        check(self._ctx.L.pysdr_set_squelch_ratio(self._ctx.h, self.irx, self._squelch_ratio, _lib.as_pf(lp), _lib.as_pf(hp), len(lp)),
+              "pysdr_set_squelch_ratio")
+
+    @property
+    def squelch_ratio_state(self):
+        """(sq1, sq2, gate open) behind the last chunk."""
+        lo, hi, op = C.c_float(0), C.c_float(0), C.c_int(1)
+        check(self._ctx.L.pysdr_squelch_ratio_get(self._ctx.h, self.irx, C.byref(lo), C.byref(hi), C.byref(op)),
+              "pysdr_squelch_ratio_get")
+        return lo.value, hi.value, bool(op.value)
+
     @property
     def squelch_state(self):
         lvl, op = C.c_float(0), C.c_int(1)

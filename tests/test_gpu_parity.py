@@ -840,6 +840,68 @@ def test_nfm_noise_squelch_mutes_when_the_carrier_drops():
     assert opened[2] and opened[3] and not opened[5] and not opened[6] and opened[14]
 
 
+@pytest.mark.parametrize("amp", [0.3, 0.03])
+def test_ratio_squelch_follows_the_carrier_at_two_levels_20_db_apart(amp):
+    """The squelch as the one design the reference holds sketches it (sigs/squelch.m:92-145): envelopes of the
+    < 3 kHz and > 4 kHz parts of the discriminator output, one-pole per SAMPLE with alpha = 0.001, the decision on their
+    RATIO.  A station at two levels 20 dB apart over the same noise floor goes off the air for 4 chunks: ONE ratio
+    threshold follows it at both levels; envelopes, gate and audio against the oracle's per-sample recursion."""
+    cfg = dict(so.CONFIGS['C2'], carriers=[dict(so.CONFIGS['C2']['carriers'][0], amp=amp)])
+    L, n = 170666, 14
+    x = so.synth_iq(cfg, n * L, 14)
+    noise_only = so.synth_iq(dict(cfg, carriers=[]), n * L, 15)
+    x[4 * L:8 * L] = noise_only[4 * L:8 * L]
+    P, g = make_gpu_receivers(cfg)
+    o = so.make_receivers(cfg, np.float32)
+    g[0].squelch_ratio = 2.0
+    o[0].squelch_ratio = np.float32(2.0)
+    opened = []
+    for k in range(n):
+        xc = x[k * L:(k + 1) * L]
+        ag, ao = g[0].demod_data(xc), o[0].demod_data(xc)
+        lo, hi, op = g[0].squelch_ratio_state
+        opened.append(op)
+        assert op == o[0].sq_open, k
+        assert abs(lo - float(o[0].sq_lp)) <= 1e-4 * float(o[0].sq_lp) and abs(hi - float(o[0].sq_hp)) <= 1e-4 * float(o[0].sq_hp), (k, lo, hi)
+        if k > 0:
+            assert relerr(ag, ao) <= TOL or (not op and not np.any(ag)), k
+    assert opened[2] and opened[3] and not any(opened[4:8]) and opened[10] and opened[13], opened
+    # with the carrier the ratio is far above the threshold at either level, without it far below
+    assert lo / hi > 20.0
+
+
+@pytest.mark.parametrize("L,B", [(170666, 60), (3000, 400)])
+def test_ratio_squelch_in_a_batch_equals_chunk_by_chunk(L, B):
+    """The block recursion of the two envelopes runs time-parallel inside a batch (agc_scan_kernel: segments warmed up over
+    the 32 blocks in front of them, joins compared bit for bit): gate and audio of a batch = the chunk-by-chunk loop's, bit
+    for bit, with the station going off the air and coming back inside the batch."""
+    cfg = so.CONFIGS['C2']
+    x = so.synth_iq(cfg, B * L, 14)
+    noise_only = so.synth_iq(dict(cfg, carriers=[]), B * L, 15)
+    a, b = (B // 3) * L, (B // 3 + B // 4) * L
+    x[a:b] = noise_only[a:b]
+    P1, g1 = make_gpu_receivers(cfg)
+    g1[0].squelch_ratio = 2.0
+    am1, gate1 = [], []
+    for k in range(B):
+        am1.append(g1[0].demod_data(x[k * L:(k + 1) * L]).copy())
+        gate1.append(g1[0].squelch_ratio_state[2])
+    P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    g2[0].squelch_ratio = 2.0
+    ctx = P2._pysdr_stream
+    ctx.process_batch(x, B, L, on_device=False)
+    am, iq, cn, pk = ctx.fetch(0, B)
+    assert list(cn) == [len(v) for v in am1]
+    assert any(gate1) and not all(gate1)
+    zero1 = [not np.any(v) for v in am1]
+    pos = np.r_[0, np.cumsum(cn)]
+    zero2 = [not np.any(am[pos[k]:pos[k + 1]]) for k in range(B)]
+    assert zero1 == zero2                                    # the same chunks are gated
+    assert np.array_equal(am.view(np.uint32), np.concatenate(am1).view(np.uint32))
+    s1, s2 = g1[0].squelch_ratio_state, g2[0].squelch_ratio_state
+    assert s1[2] == s2[2] and abs(s1[0] - s2[0]) <= 1e-5 * s1[0] and abs(s1[1] - s2[1]) <= 1e-5 * s1[1]
+
+
 @pytest.mark.parametrize("L", [1500, 700, 43690 // 4])
 def test_batch_of_chunks_with_odd_output_counts_equals_chunked_bit_exact(L):
     """Chunks of 1500 samples at 3/500 are 9 outputs, of 700 samples 4 or 5, of 10922 samples 65 or 66: inside a batch
