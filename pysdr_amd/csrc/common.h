@@ -107,6 +107,11 @@ struct MixMfmaArgs {
   uint32_t chunk_len, magic_chunk;
   // the history roll rides in this launch (hist_roll.h): new history, the next call's raw-peak buffer to zero; null = not here
   float2* hist_new; unsigned* zero; int zero_n;
+#ifdef PYSDR_DIAG
+  // [grid][6]: HW_REG_XCC_ID, HW_REG_HW_ID, s_memtime at the workgroup's start / end, s_memrealtime (constant 100 MHz) at its
+  // start / end -- where each workgroup ran and at what clock (scripts/diag/mfma_bimodal.py); null: not recorded
+  unsigned long long* wg_stamps;
+#endif
 };
 // instantiations: X(id, UP, DOWN, S shifts, taps per branch, NB row blocks per tile, WK window slices, producer waves, LDS images, operand ring carried across tiles)
 //   0: 2.048 MS/s -> 48 kHz with the reference's default 1001-tap prototype (params.py:134; am.py path, BASELINE C1)

@@ -544,6 +544,15 @@ __global__ __launch_bounds__(G::NTHREADS) void mixdec_mfma_kernel(const MixMfmaA
   const int t_begin = wb * per + (wb < rem ? wb : rem);
   const int t_end = t_begin + per + (wb < rem ? 1 : 0);
   if (t_begin >= t_end) return;
+#ifdef PYSDR_DIAG
+  if (a.wg_stamps && tid == 0) {
+    unsigned long long* w = a.wg_stamps + (size_t)blockIdx.x * 6;
+    w[0] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20);      // HW_REG_XCC_ID[3:0]
+    w[1] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+    w[2] = __builtin_amdgcn_s_memtime();
+    w[4] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 
   // the images must hold finite numbers wherever a window can reach (0 * NaN is not 0)
   {
@@ -562,6 +571,13 @@ __global__ __launch_bounds__(G::NTHREADS) void mixdec_mfma_kernel(const MixMfmaA
   if (wave < G::NCONS) {
     const int b_blk = wave / G::WK;
     mm_consumer_switch<G, 0>(wave - b_blk * G::WK, a, lds0, part0, b_blk, lane, t_begin, t_end);
+#ifdef PYSDR_DIAG
+    if (a.wg_stamps && tid == 0) {
+      unsigned long long* w = a.wg_stamps + (size_t)blockIdx.x * 6;
+      w[3] = __builtin_amdgcn_s_memtime();
+      w[5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
   } else if (wave < G::NCONS + G::NDMA) {
     mm_dma<G>(a, lds0, wave - G::NCONS, lane, tid - 64 * G::NCONS, t_begin, t_end);
   } else {
