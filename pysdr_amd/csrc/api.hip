@@ -220,7 +220,7 @@ struct pysdr_ctx {
   bool peak_clean[2] = {true, true};   // that buffer is all zero (a call that failed before its history roll leaves the other dirty)
 #ifdef PYSDR_DIAG
   unsigned long long* d_stamps = nullptr;   // mixdec phase stamps (PYSDR_DEBUG_FLAGS & 256)
-  unsigned long long* d_mm_stamps = nullptr;   // mixdec_mfma: per-workgroup placement and clocks (PYSDR_DEBUG_FLAGS & 512), [1024][6]
+  unsigned long long* d_mm_stamps = nullptr;   // mixdec_mfma: per-workgroup placement and clocks (PYSDR_DEBUG_FLAGS & 512), [1024][24]
 #endif
   unsigned* d_peak_scratch = nullptr;  // [1] sink for decimators whose raw peak is not wanted
   unsigned* d_blkpeak = nullptr; // [MAX_RX][max_chunks]
@@ -470,8 +470,8 @@ int decim_run(pysdr_ctx* c, Decim& d, const float2* d_x, size_t n, int nrx, floa
     b.zero_n = peak ? c->cfg.max_chunks : 0;
 #ifdef PYSDR_DIAG
     if ((c->dbg_flags & 512) && !c->d_mm_stamps) {
-      PYSDR_HIP_CHECK(hipMalloc(&c->d_mm_stamps, 1024 * 6 * sizeof(unsigned long long)));
-      PYSDR_HIP_CHECK(hipMemset(c->d_mm_stamps, 0, 1024 * 6 * sizeof(unsigned long long)));
+      PYSDR_HIP_CHECK(hipMalloc(&c->d_mm_stamps, 1024 * 24 * sizeof(unsigned long long)));
+      PYSDR_HIP_CHECK(hipMemset(c->d_mm_stamps, 0, 1024 * 24 * sizeof(unsigned long long)));
     }
     b.wg_stamps = (c->dbg_flags & 512) ? c->d_mm_stamps : nullptr;
 #endif
@@ -1276,11 +1276,11 @@ int pysdr_agc_get(pysdr_ctx* c, int irx, pysdr_agc_state* st) {
 }
 
 #ifdef PYSDR_DIAG
-// diagnostic build only: where every workgroup of the last mixdec_mfma launch ran and at what clock, [1024][6] uint64
+// diagnostic build only: where every workgroup of the last mixdec_mfma launch ran and at what clock, [1024][24] uint64
 extern "C" int pysdr_diag_mfma_stamps(pysdr_ctx* c, unsigned long long* host) {
   if (!c || !host || !c->d_mm_stamps) return PYSDR_ERR_ARG;
   PYSDR_HIP_CHECK(hipStreamSynchronize(c->stream));
-  PYSDR_HIP_CHECK(hipMemcpy(host, c->d_mm_stamps, 1024 * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  PYSDR_HIP_CHECK(hipMemcpy(host, c->d_mm_stamps, 1024 * 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return PYSDR_OK;
 }
 // diagnostic build only: the last launch's mixdec phase stamps, [2][16][24][8] uint64

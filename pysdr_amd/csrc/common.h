@@ -108,8 +108,9 @@ struct MixMfmaArgs {
   // the history roll rides in this launch (hist_roll.h): new history, the next call's raw-peak buffer to zero; null = not here
   float2* hist_new; unsigned* zero; int zero_n;
 #ifdef PYSDR_DIAG
-  // [grid][6]: HW_REG_XCC_ID, HW_REG_HW_ID, s_memtime at the workgroup's start / end, s_memrealtime (constant 100 MHz) at its
-  // start / end -- where each workgroup ran and at what clock (scripts/diag/mfma_bimodal.py); null: not recorded
+  // [grid][24]: HW_REG_XCC_ID, HW_REG_HW_ID, s_memtime at the workgroup's start / end, s_memrealtime (constant 100 MHz) at its
+  // start / end -- where each workgroup ran and at what clock -- then per wave the shader-clock cycles it stood at the tile
+  // loop's barrier (copy waves: + the wait for their own copies in the high half) (scripts/diag/mfma_bimodal.py); null: not recorded
   unsigned long long* wg_stamps;
 #endif
 };

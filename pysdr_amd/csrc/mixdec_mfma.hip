@@ -177,6 +177,16 @@ struct MmChunk {
   }
 };
 
+// The tile loop's workgroup barrier; in the diagnostic build every wave adds up the shader-clock cycles it stood there
+// (mixdec_mfma_kernel writes the sums behind the workgroup's placement stamps: scripts/diag/mfma_bimodal.py --barriers).
+#ifdef PYSDR_DIAG
+#define MM_TILE_BARRIER(acc) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); __syncthreads(); (acc) += __builtin_amdgcn_s_memtime() - _t; } while (0)
+#define MM_TILE_BARRIER_LDS(acc) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); mm_barrier_lds_only(); (acc) += __builtin_amdgcn_s_memtime() - _t; } while (0)
+#else
+#define MM_TILE_BARRIER(acc) __syncthreads()
+#define MM_TILE_BARRIER_LDS(acc) mm_barrier_lds_only()
+#endif
+
 // One consumer wave = (row block b, window slice Q) for the whole launch: per tile SPW k-steps of one 8-byte LDS
 // read (Re, Im of one sample per lane) and two MFMAs.  Every read offset is a compile-time constant (DS offset
 // field); the pad a window crosses every P samples adds 16 bytes, and the ONE step per crossing that the parity
@@ -236,6 +246,7 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
 
   float pk_run = 0.f;
   uint32_t pk_chunk = 0u;
+  unsigned long long bar_cycles = 0ull;
   MmChunk ch;
   int origin = a.origin_rel0 + t_begin * G::TILE;
   ch.init(a, origin > 0 ? origin : 0);
@@ -265,7 +276,7 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
       pk_chunk = ch.ck;
     }
     // behind this barrier: tiles tb and (CARRY) tb+1 are in LDS, and the partial area this trip writes has been read
-    __syncthreads();
+    MM_TILE_BARRIER(bar_cycles);
     if (!G::CARRY) {                  // the head of the ring is read here, behind the barrier (one more tile of copies in flight instead)
 #pragma unroll
       for (int ls = 0; ls < kA; ++ls) ring[ls] = rd(pa, pb, ls);
@@ -309,6 +320,9 @@ __device__ __forceinline__ void mm_consumer(const MixMfmaArgs& a, unsigned lds0,
   __syncthreads();                    // (last) the partial sums of tile t_end-1 are complete
   pk_run = mm_wave_max63(pk_run);
   if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
+#ifdef PYSDR_DIAG
+  if (a.wg_stamps && lane == 0) a.wg_stamps[(size_t)blockIdx.x * 24 + 6 + b_blk * G::WK + Q] = bar_cycles;
+#endif
 }
 
 // Reduce + rotate output e of tile `tb` from its partial sums (thread e = output e of the tile; false: no such output).
@@ -359,6 +373,7 @@ __device__ __forceinline__ void mm_epi(const MixMfmaArgs& a, unsigned part0, int
   constexpr int kFlush = 1;
 #endif
   const int n = t_end - t_begin;
+  unsigned long long bar_cycles = 0ull;
   mm_barrier_lds_only();              // (1)
   // trip 0 leaves these waves idle (no tile is finished yet): workgroup 0's roll the decimator's history meanwhile
   if (blockIdx.x == 0 && a.hist_new != nullptr)
@@ -372,7 +387,7 @@ __device__ __forceinline__ void mm_epi(const MixMfmaArgs& a, unsigned part0, int
       have[j] = false;
       hold[j] = make_float2(0.f, 0.f);
       if (i0 + j < n) {               // tile i0+j is complete behind the barrier of the trip after it (or the last one)
-        mm_barrier_lds_only();
+        MM_TILE_BARRIER_LDS(bar_cycles);
         have[j] = mm_epilogue<G>(a, t_begin + i0 + j, part0 + (((i0 + j) & 1) ? (unsigned)G::PART_BYTES : 0u), etid, hold[j]);
       }
     }
@@ -391,6 +406,9 @@ __device__ __forceinline__ void mm_epi(const MixMfmaArgs& a, unsigned part0, int
 #endif
     }
   }
+#ifdef PYSDR_DIAG
+  if (a.wg_stamps && (etid & 63) == 0) a.wg_stamps[(size_t)blockIdx.x * 24 + 6 + G::NCONS + G::NDMA + (etid >> 6)] = bar_cycles;
+#endif
 }
 
 // The DMA waves: keep NBUF-1 tiles of copies in flight, and scan the raw peak of the (few) tiles whose image touches
@@ -442,6 +460,7 @@ __device__ __forceinline__ void mm_dma(const MixMfmaArgs& a, unsigned lds0, int 
   }
   float pk_run = 0.f;
   uint32_t pk_chunk = 0u;
+  unsigned long long bar_cycles = 0ull, wait_cycles = 0ull;
   MmChunk ch;
   int origin = a.origin_rel0 + t_begin * G::TILE;
   ch.init(a, origin > 0 ? origin : 0);
@@ -452,11 +471,17 @@ __device__ __forceinline__ void mm_dma(const MixMfmaArgs& a, unsigned lds0, int 
       int allow = 0;
 #pragma unroll
       for (int j = 0; j < kKI; ++j) allow += infl[j];
+#ifdef PYSDR_DIAG
+      const unsigned long long _t = __builtin_amdgcn_s_memtime();
       mm_dma_wait_allow(allow);
+      wait_cycles += __builtin_amdgcn_s_memtime() - _t;
+#else
+      mm_dma_wait_allow(allow);
+#endif
     }
     // behind this barrier nobody reads the image of tile tb-1 any more: tile tb+NBUF-1 goes there
-    __syncthreads();
     const int fslot = (slot == 0) ? G::NBUF - 1 : slot - 1;
+    MM_TILE_BARRIER(bar_cycles);
     const int n_new = stage(tb + G::NBUF - 1, fslot);
     if (kKI > 0) {
 #pragma unroll
@@ -506,6 +531,10 @@ __device__ __forceinline__ void mm_dma(const MixMfmaArgs& a, unsigned lds0, int 
   __syncthreads();                    // (last)
   pk_run = mm_wave_max63(pk_run);
   if (lane == 63 && pk_run > 0.f) atomicMax(a.peak + pk_chunk, __float_as_uint(pk_run));
+#ifdef PYSDR_DIAG
+  // (the copy waves' slots hold the barrier wait in the low and the wait for their own copies in the high 32 bits)
+  if (a.wg_stamps && lane == 0) a.wg_stamps[(size_t)blockIdx.x * 24 + 6 + G::NCONS + pw] = (bar_cycles & 0xFFFFFFFFull) | (wait_cycles << 32);
+#endif
 }
 
 template <class G, int Q>
@@ -546,7 +575,7 @@ __global__ __launch_bounds__(G::NTHREADS) void mixdec_mfma_kernel(const MixMfmaA
   if (t_begin >= t_end) return;
 #ifdef PYSDR_DIAG
   if (a.wg_stamps && tid == 0) {
-    unsigned long long* w = a.wg_stamps + (size_t)blockIdx.x * 6;
+    unsigned long long* w = a.wg_stamps + (size_t)blockIdx.x * 24;
     w[0] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20);      // HW_REG_XCC_ID[3:0]
     w[1] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
     w[2] = __builtin_amdgcn_s_memtime();
@@ -573,7 +602,7 @@ __global__ __launch_bounds__(G::NTHREADS) void mixdec_mfma_kernel(const MixMfmaA
     mm_consumer_switch<G, 0>(wave - b_blk * G::WK, a, lds0, part0, b_blk, lane, t_begin, t_end);
 #ifdef PYSDR_DIAG
     if (a.wg_stamps && tid == 0) {
-      unsigned long long* w = a.wg_stamps + (size_t)blockIdx.x * 6;
+      unsigned long long* w = a.wg_stamps + (size_t)blockIdx.x * 24;
       w[3] = __builtin_amdgcn_s_memtime();
       w[5] = __builtin_amdgcn_s_memrealtime();
     }

@@ -41,7 +41,7 @@ for ic in range(NCTX):
     for back in range(min(NL, 32)):
         _lib.check(lib.pysdr_get_elapsed_ms(ctx.h, 0, back, C.byref(ms)), "elapsed")
         times.append(ms.value)
-    st = np.zeros((1024, 6), dtype=np.uint64)
+    st = np.zeros((1024, 24), dtype=np.uint64)
     _lib.check(fn(ctx.h, st.ctypes.data), "stamps")
     st = st[:256].astype(np.int64)
     xcc = st[:, 0]
@@ -58,6 +58,14 @@ for ic in range(NCTX):
           f" start skew max {t0.max() * 10e-3:.1f} us; shader clock GHz: min {ghz.min():.3f} median {np.median(ghz):.3f} max {ghz.max():.3f}")
     per_xcc = [f"{x}: {np.median(dt_real[xcc == x]) * 1e6:.0f} us @ {np.median(ghz[xcc == x]):.2f} GHz" for x in range(8) if (xcc == x).any()]
     print("   per XCC median: " + "; ".join(per_xcc))
+    # where the waves stand: cycles at the tile loop's barrier as a fraction of the workgroup's run (C1: waves 0-7 consumers,
+    # 8-13 copies, 14-15 epilogue)
+    bar = st[:, 6:22]
+    frac_b = (bar & 0xFFFFFFFF) / np.maximum(dt_clk, 1)[:, None]
+    frac_w = (bar >> 32) / np.maximum(dt_clk, 1)[:, None]
+    print("   barrier wait, fraction of the run, mean over workgroups: consumers " + " ".join(f"{v:.2f}" for v in frac_b[:, :8].mean(axis=0)) +
+          " | copy waves " + " ".join(f"{v:.2f}" for v in frac_b[:, 8:14].mean(axis=0)) + " (+ waiting for their copies " +
+          " ".join(f"{v:.2f}" for v in frac_w[:, 8:14].mean(axis=0)) + ") | epilogue " + " ".join(f"{v:.2f}" for v in frac_b[:, 14:16].mean(axis=0)))
     distinct = len({(int(a), int(b), int(c_)) for a, b, c_ in zip(xcc, se, cu)})
     print(f"   distinct (XCC, SE, CU) of the 256 workgroups: {distinct}")
     if ic % 2 == 0:
@@ -77,7 +85,7 @@ for pace in (0.0, 0.0, 0.002, 0.02):
         ctx.process_batch(base, B, L, on_device=True)
         _lib.check(lib.pysdr_sync(ctx.h), "sync")
         _lib.check(lib.pysdr_get_elapsed_ms(ctx.h, 0, 0, C.byref(ms)), "elapsed")
-        st = np.zeros((1024, 6), dtype=np.uint64)
+        st = np.zeros((1024, 24), dtype=np.uint64)
         _lib.check(fn(ctx.h, st.ctypes.data), "stamps")
         st = st[:256].astype(np.int64)
         real = (st[:, 5] - st[:, 4]) * 10e-9
