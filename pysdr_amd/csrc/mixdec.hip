@@ -542,6 +542,8 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
     }
   }
 
+  int flush_in = a.yflush;       // tiles until the output stage is flushed (a countdown: `(tb - t_begin + 1) % a.yflush` was a 32-bit
+                                 // division by a run-time value, ~25 scalar + 6 vector instructions per tile and wave)
   for (int tb = t_begin; tb < t_end; ++tb) {
     float2* const xs = ((tb - t_begin) & 1) ? buf1 : buf0;
     float2* const xn = ((tb - t_begin) & 1) ? buf0 : buf1;
@@ -801,7 +803,8 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
     }
     PYSDR_STAMP(5);
     // ---- flush the output stage: RX r, 64 outputs per wave-store (512 contiguous bytes)
-    if (tb + 1 == t_end || (tb - t_begin + 1) % a.yflush == 0) {
+    if (tb + 1 == t_end || --flush_in == 0) {
+      flush_in = a.yflush;
       __syncthreads();
       const int n_st = cur.i_first + cur.tile_n - i_base;
       const int cpr = (n_st + 63) >> 6;
