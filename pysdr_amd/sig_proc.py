@@ -40,12 +40,13 @@ def _device_of(P):
 def _chunk_key(x):
     """Identity of a chunk for the per-chunk cache of ``Receiver.demod_data``: where it lives, how long it is and 16 of its
     samples (a buffer reused in place for the next chunk keeps its address; its contents do not stay)."""
+    where = x.__array_interface__['data'][0] if isinstance(x, np.ndarray) else 0     # (a list becomes a NEW array on every call: no address)
     x = np.asarray(x)
     n = x.shape[0] if x.ndim else 0
     if n == 0:
         return (0, 0, b'')
     idx = (np.arange(16, dtype=np.int64) * (n - 1)) // 15
-    return (x.__array_interface__['data'][0], n, x[idx].tobytes())
+    return (where, n, x[idx].tobytes())
 
 
 # ----------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ OUT=${1:-gpurun_out/prof}
 QUICK=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$OUT" && mkdir -p "$OUT"
-TAG=${PROFILE_TAG:-r05}
+TAG=${PROFILE_TAG:-r06}
 declare -a CFG_NAMES=() CFG_ARGS=()
 run_cfg() {  # name, pmc(0/1), bench args...
   local name=$1 pmc=$2; shift 2
@@ -40,6 +40,9 @@ run_cfg c4 1 --workload c4
 run_cfg c4mono 0 --workload c4mono --no-cpu-baseline
 run_cfg rx6 0 --workload rx6 --no-cpu-baseline
 run_cfg c1synch 0 --workload c1synch --no-cpu-baseline
+# the reference's own multi-receiver launch scripts with its default 1001-tap prototype (FT8tri:47-74, TEST:13-32): matrix-core shapes of mixdec.hip
+run_cfg ft8tri 1 --workload ft8tri
+run_cfg test2rx 1 --workload test2rx
 # The plain bench lines (events only, no profiler attached) come LAST: the counters above are first condensed into
 # profiles/<tag>_pmc_traffic.json (stamped with the hashes of the kernel sources), so that the lines carry `traffic`.
 python3 scripts/summarize_profiles.py "$OUT" profiles "$TAG" > "$OUT/summarize.log" 2>&1

@@ -102,7 +102,22 @@ static void narrowband(const Rate& r, int ntaps_dec) {
   OK(pysdr_reset(c, 1, 3));
   OK(pysdr_set_agc(c, 1, 0, 0.4f));
   OK(pysdr_set_squelch(c, 2, 0.05f));
+  {
+    // the ratio squelch: its two FIRs belong to the context, the block sums are allocated when it is first armed
+    std::vector<float> lp(63, 1.0f / 63), hp(63, 0.f);
+    hp[31] = 1.f;
+    FAILS(pysdr_set_squelch_ratio(c, 2, 2.0f, lp.data(), hp.data(), 65));
+    FAILS(pysdr_set_squelch_ratio(c, 2, 2.0f, nullptr, hp.data(), 63));
+    OK(pysdr_set_squelch_ratio(c, 2, 2.0f, lp.data(), hp.data(), 63));
+    OK(pysdr_set_squelch_ratio(c, 1, 0.0f, nullptr, nullptr, 0));                // disarming needs no taps
+  }
   run_calls(c, r, nrx, max_chunks, {L, 5, L});
+  {
+    float sq1 = 0, sq2 = 0;
+    int gate = 0;
+    OK(pysdr_squelch_ratio_get(c, 2, &sq1, &sq2, &gate));
+    FAILS(pysdr_squelch_ratio_get(c, 9, &sq1, &sq2, &gate));
+  }
   pysdr_agc_state st;
   OK(pysdr_agc_get(c, 3, &st));
   int seg = 0, pat = 0, open = 0;

@@ -49,13 +49,29 @@ bool same_tile(const Tile& a, const Tile& b) {
 }  // namespace
 
 size_t mixdec_lds_bytes(const MixDecArgs& a) {
-  return (2 * (size_t)a.tile_cap + (size_t)a.nrx * a.up * a.kpad + (size_t)a.nrx * a.ycap) * sizeof(float2);
+  return (2 * (size_t)a.tile_cap + (a.taps_lds ? (size_t)a.nrx * a.up * a.kpad : 0) + (size_t)a.nrx * a.ycap) * sizeof(float2);
+}
+
+// The host's view of which instantiation a shape runs on (mixdec.hip md_dispatch / MdShape, restated: the templates do not
+// compile without hipcc): the long-prototype multi-RX shapes are 12 (2-4 RX) or 8 (5, 6 RX) waves that hold their taps.
+MixdecVariant mixdec_variant(int nrx, int up, int kpad, int threads) {
+  MixdecVariant v{1024, 0, 1};
+  if (kpad == 336 && up == 3 && threads == 1024 && nrx >= 2 && nrx <= 6) { v.tpb = (nrx <= 4) ? 768 : 512; v.can_hold = 1; v.nh = 1; }
+  else if (kpad == 96) { v.nh = (nrx > 4) ? 2 : 1; v.can_hold = 1; }
+  else if (nrx == 1 && (kpad == 64 || kpad == 256 || kpad == 336)) v.can_hold = 1;
+  return v;
 }
 
 static void roll_on_host(const float2* x, const float2* hist_old, float2* hist_new, int hist_len, uint32_t n_total, unsigned* zero, int zero_n);
 int launch_mixdec(const MixDecArgs& a, int threads, int grid, hipStream_t) {
   if (a.hist_new) roll_on_host(a.x, a.hist, a.hist_new, a.hist_len, a.n_total, a.zero, a.zero_n);
   SAN_CHECK(threads >= 64 && threads <= 1024 && (threads & 63) == 0, "threads %d", threads);
+  if (!a.taps_lds) {
+    // the waves hold their taps (no LDS copy of them): the plan must guarantee hold mode for the instantiation's own thread count
+    const MixdecVariant v = mixdec_variant(a.nrx, a.up, a.kpad, threads);
+    const int nwaves = std::min(threads, v.tpb) / 64;
+    SAN_CHECK(v.tpb != 1024 && v.can_hold && a.up * v.nh <= nwaves && a.tile_out % a.up == 0, "taps_lds = 0 without hold mode (tile_out %d, %d waves)", a.tile_out, nwaves);
+  }
   SAN_CHECK(grid >= 1, "grid %d", grid);
   SAN_CHECK(mixdec_lds_bytes(a) <= 160 * 1024, "LDS %zu", mixdec_lds_bytes(a));
   SAN_CHECK(a.nrx >= 1 && a.nrx <= PYSDR_MAX_RX && a.up >= 1 && a.down >= 1 && a.kpad % 16 == 0, "shape");
@@ -296,6 +312,12 @@ int launch_demod_fir(const Stage2Args& a, hipStream_t) {
       a.blkpeak[((size_t)r * a.nchunks + k) * kBlkStride] = 0u;
       a.blknoise[((size_t)r * a.nchunks + k) * kBlkStride] = 0.f;
       a.blkcnt[((size_t)r * a.nchunks + k) * kBlkStride] = 0u;
+    }
+    if (a.sq_ratio[r] && a.sq_thresh[r] > 0.f && a.det[r] == kDetFm) {   // the ratio squelch's second set of block sums and its two FIRs
+      SAN_CHECK(a.blknoise2 != nullptr && a.sqtaps != nullptr && a.sq_ntaps >= 1 && a.sq_ntaps <= kSqTapsMax, "ratio squelch armed without its buffers (%d taps)", a.sq_ntaps);
+      SAN_CHECK(a.sq_ntaps - 1 <= a.hy - 2, "ratio squelch: %d taps reach behind the %d outputs of history", a.sq_ntaps, a.hy);
+      read_all(a.sqtaps, (size_t)2 * kSqTapsMax);
+      for (int k = 0; k < a.nchunks; ++k) a.blknoise2[((size_t)r * a.nchunks + k) * kBlkStride] = 0.f;
     }
   }
   return PYSDR_OK;
