@@ -1042,7 +1042,9 @@ def main():
     mfma_on = bool(tune[7]) and nrx == 1 and ((not is_wfm and (P.UP, P.DOWN, cfg['ntaps_dec']) == (3, 128, 1001)) or
                                               (is_wfm and rxs[0].demod.wfm_d1 == 40 and cfg['ntaps_dec'] == 255))
     overlapped = bool(lib.pysdr_last_call_overlapped(ctx.h))
-    front_name = ((("mixdec_mfma_kernel (f32 MFMA, shifted-tap columns; " if mfma_on else f"mixdec_kernel<{nrx}> (") +
+    mm4_on = (not is_wfm) and 2 <= nrx <= 6 and P.UP == 3 and -(-cfg['ntaps_dec'] // 3) in range(321, 337) and int(tune[5]) == 1024
+    front_name = ((("mixdec_mfma_kernel (f32 MFMA, shifted-tap columns; " if mfma_on else
+                    (f"mixdec_kernel<{nrx},21,MM> (f32 MFMA 4x4x1 blocks = tap residues, taps held in registers; " if mm4_on else f"mixdec_kernel<{nrx}> (")) +
                    "fused NCO mix + polyphase decimate, all RX)" + (" + am_phase_kernel" if synch else "")) if not is_wfm else
                   (("mixdec_mfma_kernel<1/40>" if mfma_on else "mixdec_kernel<1,16>") +
                    (" + wfm_disc_kernel (IF decimate, discriminator; the pilot loop runs on the second stream)" if overlapped else

@@ -252,6 +252,31 @@ __device__ __forceinline__ void peak_scan(const MixDecArgs& a, const Tile& cur, 
 
 }
 
+// The copies and the raw-peak scan of a STEADY tile (mixdec_kernel's add-only tile loop): every argument is a constant of the run
+// but the image's source address.  Copies: this wave's 1 KiB pieces, SGPR base + per-lane offset (no vector address arithmetic).
+__device__ __forceinline__ void steady_stage(const char* src, unsigned voff0, unsigned lds_dst, int npieces, int wave, int nwaves) {
+  const unsigned keep = m0_save();
+  for (int q = wave, i = 0; q < npieces; q += nwaves, ++i)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" PYSDR_GLDS_POLICY
+                 ::"v"(voff0 + (unsigned)(i * nwaves) * 1024u), "s"(src), "s"(lds_dst + (unsigned)q * 1024u) : "memory");
+  m0_restore(keep);
+}
+__device__ __forceinline__ float steady_peak(const float4* xv, int pi, int p_hi, int nthr, float pk_run) {
+  for (; pi + 3 * nthr <= p_hi; pi += 4 * nthr) {
+    const float4 v0 = xv[pi], v1 = xv[pi + nthr], v2 = xv[pi + 2 * nthr], v3 = xv[pi + 3 * nthr];
+    const float m0 = fmaxf(fmaf(v0.x, v0.x, v0.y * v0.y), fmaf(v0.z, v0.z, v0.w * v0.w));
+    const float m1 = fmaxf(fmaf(v1.x, v1.x, v1.y * v1.y), fmaf(v1.z, v1.z, v1.w * v1.w));
+    const float m2 = fmaxf(fmaf(v2.x, v2.x, v2.y * v2.y), fmaf(v2.z, v2.z, v2.w * v2.w));
+    const float m3 = fmaxf(fmaf(v3.x, v3.x, v3.y * v3.y), fmaf(v3.z, v3.z, v3.w * v3.w));
+    pk_run = fmaxf(fmaxf(pk_run, fmaxf(m0, m1)), fmaxf(m2, m3));
+  }
+  for (; pi <= p_hi; pi += nthr) {
+    const float4 v = xv[pi];
+    pk_run = fmaxf(pk_run, fmaxf(fmaf(v.x, v.x, v.y * v.y), fmaf(v.z, v.z, v.w * v.w)));
+  }
+  return pk_run;
+}
+
 // Fold the 16 lanes of each row for N sub-receivers (all 2N partial sums advance one DPP step
 // at a time, so consecutive instructions are independent: no DPP hazard stalls), then lane
 // s < ncount of every row rotates RX rbase + s by its LO phase and puts the sample into the LDS
@@ -304,6 +329,9 @@ __device__ __forceinline__ void fold_rotate_stage(const float2 (&A)[N], const fl
 #endif
 #ifndef MD_LONG_MM
 #define MD_LONG_MM 1         // the long-prototype shapes of 2 - 4 sub-receivers on the matrix cores (A/B: 0 = vector form)
+#endif
+#ifndef MD_STEADY
+#define MD_STEADY 1          // matrix-core shapes: runs of full interior tiles through the add-only tile loop (A/B: 0 = the generic body for every tile)
 #endif
 #ifndef MD_MM_EPCONST
 #define MD_MM_EPCONST -1     // matrix-core shapes: the epilogue lane's LO constants looked up per task (1) or held in registers (0); -1: held
@@ -379,8 +407,8 @@ __device__ __forceinline__ float dpp_row_ror8(float v) {
 // two rotations, the four rows by swaps -- which leaves output rho's totals in row rho; there lane (q = pair, j even) has
 // Re, its neighbour Im: it rotates RX 2 q + j / 2 by the LO phase and stages the sample like fold_rotate_stage.
 template <int G, int R>
-__device__ __forceinline__ void mm_fold_rotate_stage(const md_f4 (&acc)[G], int lane, bool valid, uint32_t rel, uint32_t p0,
-                                                     uint32_t fw, float2* ys, int ycap, int io) {
+__device__ __forceinline__ void mm_fold_rotate_stage(const md_f4 (&acc)[G], int lane, bool valid, uint32_t ph, float2* ys, int ycap,
+                                                     int io) {
   float tot[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -401,13 +429,59 @@ __device__ __forceinline__ void mm_fold_rotate_stage(const md_f4 (&acc)[G], int 
   const float other = dpp_quad_xor1(t);               // the Im column beside a Re column
   const int rx = 2 * q + (j >> 1);
   if (valid && q < G && (j & 1) == 0 && rx < R) {
-    const uint32_t ph = p0 + fw * rel;
-    const float rev = (float)(int)ph * (1.0f / 4294967296.0f);
+    const float rev = (float)(int)ph * (1.0f / 4294967296.0f);       // ph = the LO's 32-bit phase at the output's newest sample
     const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
     float2 o;
     o.x = t * cs - other * sn;
     o.y = t * sn + other * cs;
     ys[rx * ycap + io] = o;
+  }
+}
+
+// The dot products of one task on the matrix cores: 16 blocks = 16 tap residues, rows = the quad's outputs, columns = (Re, Im) of
+// an RX pair; xr = this lane's LDS pointer (block b, row i: x[n_i - b - 16 (NJ - 1)], so that step jj reads element 16 (NJ - 1 - jj)).
+// G = 1: the Re x chain and the Im x chain have an accumulator each (a chain on ONE accumulator issues every 15 cycles instead of
+// 8: scripts/diag/mfma4x4_probe.hip); G >= 2: the pairs alternate, one accumulator per pair is enough.
+// The reads of x go through a RING of kXA register pairs, kXA steps ahead of the MFMAs that use them, pinned by
+// sched_group_barrier: left alone hipcc reuses four registers and puts a full s_waitcnt lgkmcnt(0) in front of every four MFMAs --
+// one exposed LDS latency per 40 cycles of matrix work (the same finding as mixdec_mfma.hip's consumer).
+template <int G, int NJ>
+__device__ __forceinline__ void mm_task_dots(lds_cf2 xr, const float (&bre)[G][NJ], const float (&bim)[G][NJ], md_f4 (&acc)[G]) {
+  constexpr int kNA = (G == 1 || !MD_MM_ONEACC) ? 2 * G : G;
+  md_f4 accs[kNA];
+#pragma unroll
+  for (int q = 0; q < kNA; ++q) accs[q] = (md_f4){0.f, 0.f, 0.f, 0.f};
+  constexpr int kTop = 16 * (NJ - 1);
+  constexpr int kXA = (MD_XAHEAD < NJ) ? MD_XAHEAD : NJ;
+  float2 ring[kXA];
+#pragma unroll
+  for (int u = 0; u < kXA; ++u) ring[u] = lds_ld(xr, kTop - 16 * u);
+  __builtin_amdgcn_sched_group_barrier(0x100, kXA, 0);
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const float2 xv = ring[jj % kXA];
+    if constexpr (kNA == 2 * G) {
+#pragma unroll
+      for (int gq = 0; gq < G; ++gq) {
+        accs[2 * gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.x, bre[gq][jj], accs[2 * gq], 0, 0, 0);
+        accs[2 * gq + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.y, bim[gq][jj], accs[2 * gq + 1], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int gq = 0; gq < G; ++gq) accs[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.x, bre[gq][jj], accs[gq], 0, 0, 0);
+#pragma unroll
+      for (int gq = 0; gq < G; ++gq) accs[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.y, bim[gq][jj], accs[gq], 0, 0, 0);
+    }
+    if (jj + kXA < NJ) ring[jj % kXA] = lds_ld(xr, kTop - 16 * (jj + kXA));
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * G, 0);
+    if (jj + kXA < NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+  }
+  if constexpr (kNA == 2 * G) {
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) acc[gq] = accs[2 * gq] + accs[2 * gq + 1];
+  } else {
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) acc[gq] = accs[gq];
   }
 }
 
@@ -545,6 +619,121 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
   int flush_in = a.yflush;       // tiles until the output stage is flushed (a countdown: `(tb - t_begin + 1) % a.yflush` was a 32-bit
                                  // division by a run-time value, ~25 scalar + 6 vector instructions per tile and wave)
   for (int tb = t_begin; tb < t_end; ++tb) {
+    // ---- STEADY RUNS (matrix-core shapes).  When tile_out is a multiple of UP every full interior tile is the one before it
+    // shifted by dq = tile_out DOWN / UP samples: its image, the samples it owns, where every lane of every task reads and where
+    // its outputs go are arithmetic progressions.  The generic body below spends ~230 scalar + ~280 vector instructions per
+    // wave and tile on re-deriving them (SQ_INSTS_SALU / _VALU, profiles/r06_ft8tri_pmc_mfma.json) beside 84 MFMAs and 21 LDS
+    // reads of real work -- twelve waves of that are what the kernel's issue slots go to, not its memory traffic.  So: the
+    // longest stretch of tiles from here that are full, not at either end of the call or of this workgroup's share, copied whole
+    // (LDS-DMA pieces inside the call) and owned by ONE chunk (fast peak) is found by two divisions, its per-lane constants are
+    // set up once, and its tiles run a loop that only adds.  Same reads, same MFMA chains, same block reduction, same phases:
+    // bit for bit the generic body's results (tests: every cut-independence test crosses both paths; MD_STEADY=0 for the A/B).
+    if constexpr (kMm && MD_STEADY) {
+      int run = 0;
+      const int dq = a.dq_tile;
+      const int npieces_s = (cur.npairs + 63) >> 6;
+      const int e_lo0 = cur.own_lo & ~1, e_hi0 = cur.own_hi | 1;
+      const int ntask_w = (hold_q0 < a.tpc) ? ((a.tpc - hold_q0 + hold_step - 1) / hold_step) : 0;   // this wave's tasks per tile
+      constexpr int kSlots = 2;                                  // ... of which the run keeps per-lane constants for two (the host's plan gives 1 or 2)
+      if (kCanHold && hold && a.aligned16 && a.dr_tile == 0 && (dq & 1) == 0 && tb > 0 && cur.tile_n == a.tile_out && a.dbg == 0 &&
+          __builtin_amdgcn_readfirstlane(a.tpc) <= kSlots * hold_step &&
+          e_lo0 >= pk_lo && e_hi0 <= pk_hi && cur.lo + dq >= 0) {
+        // tiles t = tb .. tb + run - 1: t + 2 < ntiles, t + 1 < t_end, the copy of t + 1 inside the call, the peak of t inside the chunk
+        int lim = min(a.ntiles - 2, t_end - 1) - tb;
+        const long long room = (long long)a.n_total - 128LL * npieces_s - (long long)(cur.lo + dq);
+        if (room < 0) lim = 0;
+        else lim = min(lim, 1 + (int)(room / dq));
+        lim = min(lim, 1 + (pk_hi - e_hi0) / dq);
+        run = lim;
+      }
+      if (run >= 2) {
+        // ---- per-run constants
+        const int d0 = cur.rel_f - cur.lo;                      // tap 0 of the tile's first output, inside its image (the same for every tile of the run)
+        uint32_t qcr, pcr;
+        divmod_magic((uint32_t)cur.p_f + (uint32_t)hold_c * (uint32_t)a.down, (uint32_t)a.up, a.magic, qcr, pcr);
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        const int rho = lane_l >> 4;
+        uint32_t ep_p0 = 0u, ep_fw = 0u;
+        {
+          const int rx = 2 * ((lane_l >> 2) & 3) + ((lane_l & 3) >> 1);
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (rx == r) { ep_p0 = a.phase0[r]; ep_fw = a.fword[r]; }
+        }
+        constexpr int kTopS = 16 * ((NJ > 0 ? NJ : 1) - 1);
+        int xoff[kSlots], ioff[kSlots];
+        uint32_t phs[kSlots];
+        const uint32_t dph = ep_fw * (uint32_t)dq;
+#pragma unroll
+        for (int u = 0; u < kSlots; ++u) {
+          const int qq = hold_q0 + u * hold_step;               // (waves without tasks: hold_q0 = 1 << 29, never < tpc)
+          const int sbu = d0 + (int)qcr + 4 * qq * a.down;
+          xoff[u] = (sbu + v_gdown - kTopS) * 8;                // bytes from the image's first sample: this lane's lowest read
+          ioff[u] = hold_c + 4 * qq * a.up + rho * a.up;
+          phs[u] = ep_p0 + ep_fw * (uint32_t)(sbu + cur.lo + rho * a.down);
+        }
+        // peak: pair indices of this thread inside the image
+        const int pk_p0 = ((e_lo0 - cur.lo) >> 1) + tid, pk_phi = (e_hi0 - cur.lo) >> 1;
+        // copies: this wave's pieces of an image, 1 KiB each: SGPR base + per-lane offset
+        const unsigned voff0 = (unsigned)(wave * 1024 + lane * 16);
+        const unsigned lds_b0 = (unsigned)(size_t)(const __attribute__((address_space(3))) void*)buf0;
+        const char* src_next = reinterpret_cast<const char*>(a.x + (cur.lo + dq));      // image of tile tb + 1
+        int i_first_s = cur.i_first;
+        for (int k = 0; k < run; ++k) {
+          const int io_base = i_first_s - i_base;
+          const int par = (tb + k - t_begin) & 1;
+          const unsigned tb8 = (unsigned)a.tile_cap * 8u;
+          const unsigned xs_b = lds_b0 + (par ? tb8 : 0u), xn_b = lds_b0 + (par ? 0u : tb8);
+          const float4* const xs_v = (const float4*)(const __attribute__((address_space(3))) float4*)(size_t)xs_b;
+          dma_wait();
+          __syncthreads();
+          const int ord_s = (MD_PHASE_ORDERS > 1) ? ((MD_PHASE_ORDERS == 2) ? ((wave >> 2) & 1) : (wave >> 2) % 3) : 0;
+          if (ord_s != 1) steady_stage(src_next, voff0, xn_b, npieces_s, wave, nwaves);
+          if (ord_s == 0) pk_run = steady_peak(xs_v, pk_p0, pk_phi, nthr, pk_run);
+#pragma unroll
+          for (int u = 0; u < kSlots; ++u) {
+            if (u < ntask_w) {
+              md_f4 acc[kG];
+              mm_task_dots<kG, (kMm ? NJ : 1)>((lds_cf2)(size_t)(xs_b + (unsigned)xoff[u]), bre, bim, acc);
+              mm_fold_rotate_stage<kG, R>(acc, lane_l, true, phs[u], ys, a.ycap, io_base + ioff[u]);
+              phs[u] += dph;
+            }
+          }
+          if (ord_s == 1) steady_stage(src_next, voff0, xn_b, npieces_s, wave, nwaves);
+          if (ord_s != 0) pk_run = steady_peak(xs_v, pk_p0, pk_phi, nthr, pk_run);
+          // flush the output stage (the generic body's, with this tile's counters)
+          if (--flush_in == 0) {
+            flush_in = a.yflush;
+            __syncthreads();
+            const int n_st = i_first_s + a.tile_out - i_base;
+            const int cpr = (n_st + 63) >> 6;
+            for (int ch = wave; ch < R * cpr; ch += nwaves) {
+              int r = 0, c2 = ch;
+              while (c2 >= cpr) { c2 -= cpr; ++r; }
+              const int j = c2 * 64 + lane;
+              if (j < n_st) {
+                typedef float md_f2 __attribute__((ext_vector_type(2)));
+                const float2 v = ys[r * a.ycap + j];
+                __builtin_nontemporal_store((md_f2){v.x, v.y}, (md_f2*)(a.y[r] + i_base + j));
+              }
+            }
+            i_base = i_first_s + a.tile_out;
+          }
+          i_first_s += a.tile_out;
+          src_next += (size_t)dq * 8;
+        }
+        // ---- back to the generic body with the geometry of tile tb + run (its image was copied by the run's last tile): a full
+        // tile that is not the call's last, `run` steps of dq further on
+        {
+          const int sh = run * dq;
+          cur.i_first += run * a.tile_out;
+          cur.rel_f += sh; cur.rel_l += sh; cur.own_lo += sh; cur.own_hi += sh; cur.lo += sh; cur.hi += sh;
+        }
+        tb += run - 1;
+        continue;
+      }
+    }
     float2* const xs = ((tb - t_begin) & 1) ? buf1 : buf0;
     float2* const xn = ((tb - t_begin) & 1) ? buf0 : buf1;
     // tile tb has landed; after the barrier everybody is also done reading the other
@@ -677,51 +866,10 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
       // A += g*x.re, B += g*x.im per RX (two packed FMAs per tap, no operand shuffles);
       // y = (A.re - B.im, A.im + B.re)
       if (kCanHold && hold && kMm) {
-        // ---- matrix cores: 16 blocks = 16 tap residues, rows = the quad's outputs, columns = (Re, Im) of an RX pair
-        // G = 1: the Re x chain and the Im x chain have an accumulator each (a chain on ONE accumulator issues every 15 cycles
-        // instead of 8: scripts/diag/mfma4x4_probe.hip); G >= 2: the pairs alternate, one accumulator per pair is enough
-        constexpr int kNA = (kG == 1 || !MD_MM_ONEACC) ? 2 * kG : kG;
-        md_f4 accs[kNA];
-#pragma unroll
-        for (int q = 0; q < kNA; ++q) accs[q] = (md_f4){0.f, 0.f, 0.f, 0.f};
+        // ---- matrix cores (mm_task_dots)
         constexpr int kTop = 16 * ((NJ > 0 ? NJ : 1) - 1);
-        const lds_cf2 xr = to_lds(xp - kTop);
-        constexpr int kNJ = kMm ? NJ : 1;
-        // The reads of x go through a RING of kXA registers pairs, kXA steps ahead of the MFMAs that use them, pinned by
-        // sched_group_barrier: left alone hipcc reuses four registers and puts a full s_waitcnt lgkmcnt(0) in front of every
-        // four MFMAs -- one exposed LDS latency per 40 cycles of matrix work (the same finding as mixdec_mfma.hip's consumer).
-        constexpr int kXA = (MD_XAHEAD < kNJ) ? MD_XAHEAD : kNJ;
-        float2 ring[kXA];
-#pragma unroll
-        for (int u = 0; u < kXA; ++u) ring[u] = lds_ld(xr, kTop - 16 * u);
-        __builtin_amdgcn_sched_group_barrier(0x100, kXA, 0);
-#pragma unroll
-        for (int jj = 0; jj < kNJ; ++jj) {
-          const float2 xv = ring[jj % kXA];
-          if constexpr (kNA == 2 * kG) {
-#pragma unroll
-            for (int gq = 0; gq < kG; ++gq) {
-              accs[2 * gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.x, bre[gq][jj], accs[2 * gq], 0, 0, 0);
-              accs[2 * gq + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.y, bim[gq][jj], accs[2 * gq + 1], 0, 0, 0);
-            }
-          } else {
-#pragma unroll
-            for (int gq = 0; gq < kG; ++gq) accs[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.x, bre[gq][jj], accs[gq], 0, 0, 0);
-#pragma unroll
-            for (int gq = 0; gq < kG; ++gq) accs[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv.y, bim[gq][jj], accs[gq], 0, 0, 0);
-          }
-          if (jj + kXA < kNJ) ring[jj % kXA] = lds_ld(xr, kTop - 16 * (jj + kXA));
-          __builtin_amdgcn_sched_group_barrier(0x008, 2 * kG, 0);
-          if (jj + kXA < kNJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
         md_f4 acc[kG];
-        if constexpr (kNA == 2 * kG) {
-#pragma unroll
-          for (int gq = 0; gq < kG; ++gq) acc[gq] = accs[2 * gq] + accs[2 * gq + 1];
-        } else {
-#pragma unroll
-          for (int gq = 0; gq < kG; ++gq) acc[gq] = accs[gq];
-        }
+        mm_task_dots<kG, (kMm ? NJ : 1)>(to_lds(xp - kTop), bre, bim, acc);
         // the epilogue's lane finishes output rho = lane >> 4 of the quad (the reads above were for output lane & 3)
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));
@@ -736,7 +884,7 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
           for (int r = 0; r < R; ++r)
             if (rx == r) { ep_p0 = a.phase0[r]; ep_fw = a.fword[r]; }
         }
-        mm_fold_rotate_stage<kG, R>(acc, lane_l, i_ep <= i_last, rel_ep, ep_p0, ep_fw, ys, a.ycap, i_ep - i_base);
+        mm_fold_rotate_stage<kG, R>(acc, lane_l, i_ep <= i_last, ep_p0 + ep_fw * rel_ep, ys, a.ycap, i_ep - i_base);
       } else if (kCanHold && hold) {
         float2 A[RH], B[RH];
 #pragma unroll

@@ -188,8 +188,12 @@ _Z4testv:
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_no_shipped_kernel_uses_scratch():
     """A spilled register is a hidden wait for the LDS-DMA (its reload's s_waitcnt vmcnt(0) also waits for the NEXT tile's
-    copies: DESIGN.md 4.1, round 3): every kernel of the shipped library must compile without scratch, with the flags
-    pysdr_amd/build.py uses."""
+    copies: DESIGN.md 4.1, round 3): no kernel of the shipped library may touch private memory, with the flags
+    pysdr_amd/build.py uses.  What is checked is the hazard itself -- no `scratch_*` / private `buffer_*` instruction in any
+    kernel, no spilled vector register -- and, for every kernel but the ones named below, an empty stack frame as well.  The
+    matrix-core shapes of mixdec.hip (round 6) are AT the scalar-register limit: hipcc gives them a frame of 36 bytes for
+    scalar-spill slots that it then serves from VGPR lanes (v_writelane / v_readlane; `-Rpass-analysis=stack-frame-layout`:
+    "Spill, Size: 32" + one variable) without emitting a single memory instruction for it."""
     from concurrent.futures import ThreadPoolExecutor
     from pysdr_amd import build as pb                                        # SOURCES, EXTRA_FLAGS: importing builds nothing
     files = [f for f in pb.SOURCES if f != "api.hip"]                        # api.hip holds no device code
@@ -197,18 +201,33 @@ def test_no_shipped_kernel_uses_scratch():
     def one(f):
         return f, _isa(f, ["-fPIC", *pb.EXTRA_FLAGS.get(f, [])])
 
-    bad, nk = [], 0
+    def lane_served(fname, kname):
+        return fname == "mixdec.hip" and re.search(r"mixdec_kernelILi\d+ELi21ELi(768|512)ELi\d+ELi1E", kname or "") is not None
+
+    bad, nk, framed = [], 0, []
     with ThreadPoolExecutor(max_workers=4) as ex:
         for f, lines in ex.map(one, files):
+            for sym, insns in _functions(lines):
+                for no, text, in_asm in insns:
+                    op = text.split()[0] if text.split() else ""
+                    if op.startswith("scratch_") or (op.startswith("buffer_") and " off" not in text and "s[0:3]" in text):
+                        bad.append((f, sym, no, text))
             name = None
             for ln in lines:
                 m = re.search(r"\.name:\s+(\S+)", ln)
                 if m:
                     name = m.group(1)
+                m = re.search(r"\.vgpr_spill_count:\s+(\d+)", ln)
+                if m and int(m.group(1)) != 0:
+                    bad.append((f, name, "vgpr_spill_count", int(m.group(1))))
                 m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", ln)
                 if m:
                     nk += 1
                     if int(m.group(1)) != 0:
-                        bad.append((f, name, int(m.group(1))))
+                        if lane_served(f, name) and int(m.group(1)) <= 64:
+                            framed.append((name, int(m.group(1))))
+                        else:
+                            bad.append((f, name, int(m.group(1))))
     assert nk >= 40, nk
     assert not bad, bad
+    assert len(framed) <= 5, framed
