@@ -509,16 +509,18 @@ def test_reference_launch_scripts_multi_rx_1001_taps(name):
 
 
 @pytest.mark.parametrize("grid", [0, 3])
-@pytest.mark.parametrize("name,nrx", [("FT8TRI", 3), ("TEST2RX", 2), ("FT8TRI", 2), ("C3", 4), ("C3", 6)])
+@pytest.mark.parametrize("name,nrx", [("FT8TRI", 3), ("TEST2RX", 2), ("FT8TRI", 2), ("C3", 4), ("C3", 6), ("C3", 5), ("RTL", 2)])
 def test_multi_rx_long_prototype_does_not_depend_on_the_cut(name, nrx, grid, monkeypatch):
     """The tap-holding shapes of the vector mix + decimate kernel (mixdec.hip, 768 threads: 2 - 6 sub-receivers, 1001 taps at
-    UP = 3; 4 and 6 RX on C3's stream re-run with the long prototype): chunk by chunk == one batch == cut at random
+    UP = 3; 4, 5 and 6 RX on C3's stream re-run with the long prototype; 3/500, 3/250 and 3/128): chunk by chunk == one batch == cut at random
     places, bit for bit, for every sub-receiver -- at the default grid and held to three workgroups (many tiles per
     workgroup: the output stage's flush cadence, peaks carried across chunks) -- and the baseband IQ equals the oracle."""
     if grid:
         monkeypatch.setenv("PYSDR_TUNING", "1")
         monkeypatch.setenv("PYSDR_MIXDEC_GRID", str(grid))
-    cfg = dict(so.CONFIGS[name], ntaps_dec=1001)
+    cfg = dict(so.CONFIGS["TEST2RX" if name == "RTL" else name], ntaps_dec=1001)
+    if name == "RTL":
+        cfg['fs'] = 2.048e6                   # the reference's RTL rate (3/128 to 48 kHz): TEST's two NFM sub-receivers on it
     if name == "C3":
         import bench
         cfg['rx'] = bench.RX6[:nrx]
