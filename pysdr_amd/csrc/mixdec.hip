@@ -270,6 +270,9 @@ __device__ __forceinline__ float steady_peak(const float4* xv, int pi, int p_hi,
     const float m3 = fmaxf(fmaf(v3.x, v3.x, v3.y * v3.y), fmaf(v3.z, v3.z, v3.w * v3.w));
     pk_run = fmaxf(fmaxf(pk_run, fmaxf(m0, m1)), fmaxf(m2, m3));
   }
+  // (one or two trips: left alone hipcc vectorises this remainder by two, with a scalar epilogue and NaN bookkeeping around it:
+  //  80 instructions of the steady loop's 440; time within the spread, profiles/r06_long_multirx_variants.txt section 7)
+#pragma clang loop vectorize(disable) unroll(disable)
   for (; pi <= p_hi; pi += nthr) {
     const float4 v = xv[pi];
     pk_run = fmaxf(pk_run, fmaxf(fmaf(v.x, v.x, v.y * v.y), fmaf(v.z, v.z, v.w * v.w)));
