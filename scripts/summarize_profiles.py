@@ -27,9 +27,15 @@ def sha(name):
     return hashlib.sha256(open(os.path.join(ROOT, "pysdr_amd", "csrc", name), "rb").read()).hexdigest()[:16]
 
 
+def newest(pattern):
+    """gpurun MERGES a call's files into gpurun_out/: a directory collected twice holds both runs' <pid>_*.csv.  Only the newest."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
 def pmc(cfg, name):
     out = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(src, cfg, name, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(src, cfg, name, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             out[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
     return out
@@ -45,7 +51,7 @@ for cfg in sorted(os.listdir(src)):
     d = os.path.join(src, cfg)
     if not os.path.isdir(d):
         continue
-    ks = glob.glob(os.path.join(d, "kt", "*", "*kernel_stats.csv"))
+    ks = newest(os.path.join(d, "kt", "*", "*kernel_stats.csv"))
     if ks:
         open(os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"), "w").write(open(ks[0]).read())
     for name in ("bench.json", "bench_kt.json"):

@@ -562,6 +562,37 @@ def test_multi_rx_long_prototype_does_not_depend_on_the_cut(name, nrx, grid, mon
         assert relerr(np.concatenate(iq1[i]), want) <= TOL, (i, o.mode)
 
 
+@pytest.mark.parametrize("name", ["FT8TRI", "TEST2RX"])
+def test_steady_runs_equal_the_generic_tile_loop_bit_for_bit(name, monkeypatch):
+    """The matrix-core shapes run stretches of full interior tiles through an add-only tile loop (mixdec.hip, STEADY RUNS).  A
+    batch of 12 chunks on the default grid is at most one tile per workgroup (every tile through the generic body); held to 2, 5
+    and 7 workgroups the same batch is runs of tens of tiles with different beginnings and ends.  Baseband IQ, audio and the raw
+    chunk peaks must not tell the difference."""
+    cfg = so.CONFIGS[name]
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    B = 12
+    x = so.synth_iq(cfg, B * L, 77)
+    got = {}
+    for grid in (0, 2, 5, 7):
+        monkeypatch.setenv("PYSDR_TUNING", "1")
+        if grid:
+            monkeypatch.setenv("PYSDR_MIXDEC_GRID", str(grid))
+        else:
+            monkeypatch.delenv("PYSDR_MIXDEC_GRID", raising=False)
+        P, g = make_gpu_receivers(cfg, max_batch_chunks=B)
+        ctx = P._pysdr_stream
+        ctx.process_batch(x, B, L, on_device=False)
+        got[grid] = [ctx.fetch(i, B) for i in range(len(g))]
+    for grid in (2, 5, 7):
+        for i in range(len(cfg['rx'])):
+            am0, iq0, cn0, pk0 = got[0][i]
+            am, iq, cn, pk = got[grid][i]
+            assert np.array_equal(iq, iq0), (grid, i)
+            assert np.array_equal(am, am0), (grid, i)
+            assert np.array_equal(pk, pk0), (grid, i)
+            assert list(cn) == list(cn0)
+
+
 def test_a_sub_receiver_left_out_for_a_chunk_does_not_shift_anyones_chunks():
     """The sub-receivers of a stream share one launch sequence per chunk (sig_proc.Receiver.demod_data).  Which chunk the
     shared results belong to is decided by the chunk (address, length, fingerprint), not by counting calls: chunk 1 is asked
