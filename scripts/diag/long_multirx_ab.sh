@@ -9,7 +9,7 @@ for rep in $(seq 1 ${REPS:-2}); do
  for w in ${WLS:-ft8tri test2rx}; do
   for v in ${VARIANTS:-main}; do
    args="--workload $w"
-   case $w in c3_1001) args="--workload c3 --ntaps 1001 --no-psd";; rx6_1001) args="--workload rx6 --ntaps 1001";; c2_1001) args="--workload c2 --ntaps 1001";; esac
+   case $w in c2|rx6|c1|c4) args="--workload $w";; c3_nopsd) args="--workload c3 --no-psd";; c3_1001) args="--workload c3 --ntaps 1001 --no-psd";; rx6_1001) args="--workload rx6 --ntaps 1001";; c2_1001) args="--workload c2 --ntaps 1001";; esac
    if [ "$v" = main ]; then e="PYSDR_X=0"; else e="PYSDR_TUNING=1 PYSDR_LIB_VARIANT=$v"; fi
    env $e python3 bench.py $args $B 2>&1 | tail -1 | python3 -c "
 import sys,json
