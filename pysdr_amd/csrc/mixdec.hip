@@ -333,6 +333,9 @@ __device__ __forceinline__ void fold_rotate_stage(const float2 (&A)[N], const fl
 #ifndef MD_LONG_MM
 #define MD_LONG_MM 1         // the long-prototype shapes of 2 - 4 sub-receivers on the matrix cores (A/B: 0 = vector form)
 #endif
+#ifndef MD_UP6_HOLD
+#define MD_UP6_HOLD 1        // 1001 taps at UP = 6, one or two sub-receivers: taps held in registers (A/B: 0 = the generic form, taps in LDS)
+#endif
 #ifndef MD_STEADY
 #define MD_STEADY 1          // matrix-core shapes: runs of full interior tiles through the add-only tile loop (A/B: 0 = the generic body for every tile)
 #endif
@@ -1015,6 +1018,14 @@ template <int R, class F>
 int md_dispatch_r(int up, int kpad, int threads, F& f) {
   // 255-tap prototypes at UP = 3 (the BASELINE configurations) have 96 taps per branch
   if (kpad == 96) return f.template go<R, 6, 1024, 0, 0>();
+  // the default 1001-tap prototype at UP = 6 (1, 5, 7 MS/s -> 48 kHz: FT8:42, FT8FT4:34, FT8dual:43): 167 taps per branch, eleven
+  // tap pairs per lane and RX held in registers by six groups of waves (one or two sub-receivers; more do not fit the 24 pairs
+  // a 1024-thread wave may hold and run the generic form)
+#if MD_UP6_HOLD
+  if constexpr (R <= 2) {
+    if (kpad == 176 && up == 6 && threads == 1024) return f.template go<R, 11, 1024, 0, 0>();
+  }
+#endif
   // single-RX long filters: the 255-tap video filter of the broadcast-FM front end (UP = 1, 256
   // taps in one branch) and the reference's default 1001-tap prototype at UP = 3 (336 per branch)
   if constexpr (R == 1) {

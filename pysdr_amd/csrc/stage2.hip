@@ -1625,15 +1625,24 @@ int launch_agc_scan(const Stage2Args& a, const EpilogueArgs& e, hipStream_t st) 
   // from ~7.6k blocks per call on this passes the 64 KB a kernel gets without asking (pysdr_create bounds max_chunks so
   // that it stays inside the 160 KB a workgroup can have); the attribute is per (function, device)
   if (lds > 48 * 1024) {
-    if (lds > 160 * 1024) { set_last_error("agc: %d blocks per call need %zu bytes of LDS", a.nchunks, lds); return PYSDR_ERR_ARG; }
+    // what the kernel may ask for at run time = the workgroup's 160 KB minus what it holds statically (hipcc promotes a small
+    // private array of this kernel to 256 bytes of LDS: asking for the full 160 KB was refused with "invalid argument", i.e.
+    // every call of more than ~5500 blocks failed -- 1 MS/s batches; scripts/launch_script_rates.py found it in round 6)
     static std::mutex attr_mu;
     static uint64_t attr_done = 0;
+    static size_t max_dyn = 0;
     int dev = 0;
     PYSDR_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(attr_mu);
+    if (max_dyn == 0) {
+      hipFuncAttributes fa;
+      PYSDR_HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(agc_scan_kernel)));
+      max_dyn = (size_t)160 * 1024 - fa.sharedSizeBytes;
+    }
+    if (lds > max_dyn) { set_last_error("agc: %d blocks per call need %zu bytes of LDS (%zu available)", a.nchunks, lds, max_dyn); return PYSDR_ERR_ARG; }
     if (!((attr_done >> (dev & 63)) & 1ull)) {
       PYSDR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(agc_scan_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_dyn));
       attr_done |= 1ull << (dev & 63);
     }
   }

@@ -163,10 +163,13 @@ def test_ragged_and_tiny_chunks(chunks):
 
 
 @pytest.mark.parametrize("fs,ntaps", [(2.4e6, 255), (1.8e6, 127), (2.048e6, 1001), (10e6, 255), (6.144e6, 63),
-                                      (1.024e6, 255), (2.56e6, 1001), (2.56e6, 255), (2.048e6, 255)])
+                                      (1.024e6, 255), (2.56e6, 1001), (2.56e6, 255), (2.048e6, 255),
+                                      (1e6, 1001), (5e6, 1001), (3e6, 1001), (6e6, 1001), (9e6, 1001), (10e6, 1001)])
 def test_random_call_lengths_across_rates(fs, ntaps):
     """Tile geometry (incremental steps, whole-piece copies, chunk straddling, odd tails) under
-    call lengths drawn at random, for UP/DOWN = 1/50, 2/75, 3/128, 3/625, 1/128, 3/64, 3/160: the
+    call lengths drawn at random, for UP/DOWN = 1/50, 2/75, 3/128, 3/625, 1/128, 3/64, 3/160 -- and, with the
+    reference's default 1001-tap prototype, the SDRplay rates of Tables.py:45 its launch scripts use besides 4 and 8 MS/s:
+    1 MS/s (FT8:42, FT8FT4:34; 6/125), 5 MS/s (FT8dual:43; 6/625), and 3, 6, 9, 10 MS/s (2/125, 1/125, 2/375, 3/625) -- the
     baseband IQ and the raw-chunk peak must not depend on how the stream is cut.  The rates of
     Tables.py:44-45 whose DOWN is a multiple of 32 (2.048, 1.024, 2.56 MS/s) are the ones whose rows share
     LDS banks in mixdec.hip; 2.048 MS/s with the reference's default 1001-tap prototype (params.py:134) and
@@ -291,7 +294,7 @@ def test_batch_equals_chunked_bit_exact(grid, monkeypatch):
 
 @pytest.mark.parametrize("grid", [0, 3])
 @pytest.mark.parametrize("fs,ntaps", [(2.048e6, 1001), (1.024e6, 255), (1.024e6, 1001), (2.56e6, 1001),
-                                      (1.536e6, 1001), (1.792e6, 1001), (1.92e6, 1001)])
+                                      (1.536e6, 1001), (1.792e6, 1001), (1.92e6, 1001), (1e6, 1001), (5e6, 1001)])
 def test_long_prototype_does_not_depend_on_the_cut(fs, ntaps, grid, monkeypatch):
     """One sub-receiver at 2.048 MS/s with the reference's default 1001-tap prototype runs the mix + decimate
     on the matrix cores (mixdec_mfma.hip: rows = windows of the input, columns = the outputs a window feeds).
@@ -591,6 +594,41 @@ def test_steady_runs_equal_the_generic_tile_loop_bit_for_bit(name, monkeypatch):
             assert np.array_equal(am, am0), (grid, i)
             assert np.array_equal(pk, pk0), (grid, i)
             assert list(cn) == list(cn0)
+
+
+def test_a_call_of_many_thousand_blocks_equals_its_halves():
+    """1 MS/s (FT8:42): a chunk is 21333 samples, so a resident batch of the size the other workloads use is 6000+ AGC blocks
+    -- above ~5500 the block recursion's LDS passes what a kernel gets without asking for it (launch_agc_scan), and until
+    round 6 asking failed.  One call of 6144 chunks == two calls of 3072, bit for bit (audio, baseband, AGC state), and its
+    first chunks equal the oracle's."""
+    fs = 1e6
+    cfg = dict(so.CONFIGS['C2'], fs=fs, ntaps_dec=1001,
+               carriers=[dict(f=0.1 * fs, kind='usb', amp=0.2, tone=1200.0), dict(f=-0.2 * fs, kind='usb', amp=0.1, tone=800.0)],
+               rx=[dict(frq=0.1 * fs, mode='USB', video_bw=45e3, af_bw=5e3), dict(frq=-0.2 * fs, mode='USB', video_bw=45e3, af_bw=5e3)])
+    L = so.chunk_sizes(fs, 48e3)[3]
+    B = 6144
+    x8 = so.synth_iq(cfg, 8 * L, 9)
+    x = np.tile(x8, B // 8)
+    P1, g1 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    c1 = P1._pysdr_stream
+    c1.process_batch(x, B, L, on_device=False)
+    one = [c1.fetch(i, B) for i in range(2)]
+    P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B // 2)
+    c2 = P2._pysdr_stream
+    halves = [[], []]
+    for h in range(2):
+        c2.process_batch(x[h * (B // 2) * L:(h + 1) * (B // 2) * L], B // 2, L, on_device=False)
+        for i in range(2):
+            halves[i].append([np.array(v).copy() for v in c2.fetch(i, B // 2)])
+    for i in range(2):
+        am, iq, cn, pk = one[i]
+        assert np.array_equal(am, np.concatenate([halves[i][0][0], halves[i][1][0]])), i
+        assert np.array_equal(iq, np.concatenate([halves[i][0][1], halves[i][1][1]])), i
+        assert np.array_equal(pk, np.concatenate([halves[i][0][3], halves[i][1][3]])), i
+        assert g1[i].agc.gain == g2[i].agc.gain
+    for i, o in enumerate(so.make_receivers(cfg, np.float32)):
+        want = np.concatenate([o.demod_data(x[k * L:(k + 1) * L]) for k in range(6)])
+        assert relerr(one[i][0][:len(want)], want) <= TOL, i
 
 
 def test_a_sub_receiver_left_out_for_a_chunk_does_not_shift_anyones_chunks():
