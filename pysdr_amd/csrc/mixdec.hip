@@ -333,6 +333,11 @@ __device__ __forceinline__ void fold_rotate_stage(const float2 (&A)[N], const fl
 #ifndef MD_LONG_MM
 #define MD_LONG_MM 1         // the long-prototype shapes of 2 - 4 sub-receivers on the matrix cores (A/B: 0 = vector form)
 #endif
+#ifndef MD_UP6_MM
+#define MD_UP6_MM 2          // 1001 taps at UP = 6: the matrix-core form from this many sub-receivers (0: never).  One box, front end as a fraction
+                             // of HBM, matrix cores / vector form: 1 MS/s x 1 RX 0.32 / 0.375, x 2 0.31 / 0.27, x 3 0.245 / 0.187; 5 MS/s x 2 0.66 / 0.67,
+                             // x 4 0.61 / 0.445; 7 MS/s x 3 0.73 / 0.61 (scripts/diag/up6_mm_ab.sh, profiles/r06_launch_script_rates.txt)
+#endif
 #ifndef MD_UP6_HOLD
 #define MD_UP6_HOLD 1        // 1001 taps at UP = 6, one or two sub-receivers: taps held in registers (A/B: 0 = the generic form, taps in LDS)
 #endif
@@ -640,9 +645,7 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
       const int npieces_s = (cur.npairs + 63) >> 6;
       const int e_lo0 = cur.own_lo & ~1, e_hi0 = cur.own_hi | 1;
       const int ntask_w = (hold_q0 < a.tpc) ? ((a.tpc - hold_q0 + hold_step - 1) / hold_step) : 0;   // this wave's tasks per tile
-      constexpr int kSlots = 2;                                  // ... of which the run keeps per-lane constants for two (the host's plan gives 1 or 2)
       if (kCanHold && hold && a.aligned16 && a.dr_tile == 0 && (dq & 1) == 0 && tb > 0 && cur.tile_n == a.tile_out && a.dbg == 0 &&
-          __builtin_amdgcn_readfirstlane(a.tpc) <= kSlots * hold_step &&
           e_lo0 >= pk_lo && e_hi0 <= pk_hi && cur.lo + dq >= 0) {
         // tiles t = tb .. tb + run - 1: t + 2 < ntiles, t + 1 < t_end, the copy of t + 1 inside the call, the peak of t inside the chunk
         int lim = min(a.ntiles - 2, t_end - 1) - tb;
@@ -668,17 +671,16 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
             if (rx == r) { ep_p0 = a.phase0[r]; ep_fw = a.fword[r]; }
         }
         constexpr int kTopS = 16 * ((NJ > 0 ? NJ : 1) - 1);
-        int xoff[kSlots], ioff[kSlots];
-        uint32_t phs[kSlots];
-        const uint32_t dph = ep_fw * (uint32_t)dq;
-#pragma unroll
-        for (int u = 0; u < kSlots; ++u) {
-          const int qq = hold_q0 + u * hold_step;               // (waves without tasks: hold_q0 = 1 << 29, never < tpc)
-          const int sbu = d0 + (int)qcr + 4 * qq * a.down;
-          xoff[u] = (sbu + v_gdown - kTopS) * 8;                // bytes from the image's first sample: this lane's lowest read
-          ioff[u] = hold_c + 4 * qq * a.up + rho * a.up;
-          phs[u] = ep_p0 + ep_fw * (uint32_t)(sbu + cur.lo + rho * a.down);
-        }
+        // this wave's tasks of a tile are quads hold_q0, hold_q0 + hold_step, ...: one more arithmetic progression, so the run keeps
+        // the first task's per-lane constants and the step from task to task (any number of tasks per wave: 1 at 8 MS/s, 8 at 1 MS/s)
+        const int qq0 = (ntask_w > 0) ? hold_q0 : 0;            // (waves without tasks: hold_q0 = 1 << 29)
+        const int sb0 = d0 + (int)qcr + 4 * qq0 * a.down;
+        const int xoff0 = (sb0 + v_gdown - kTopS) * 8;          // bytes from the image's first sample: this lane's lowest read
+        const int ioff0 = hold_c + 4 * qq0 * a.up + rho * a.up;
+        uint32_t ph0 = ep_p0 + ep_fw * (uint32_t)(sb0 + cur.lo + rho * a.down);
+        const uint32_t dph = ep_fw * (uint32_t)dq;              // ... per tile
+        const int dxo = 4 * hold_step * a.down * 8, dio = 4 * hold_step * a.up;      // ... per task (scalar)
+        const uint32_t dph_t = ep_fw * (uint32_t)(4 * hold_step * a.down);
         // peak: pair indices of this thread inside the image
         const int pk_p0 = ((e_lo0 - cur.lo) >> 1) + tid, pk_phi = (e_hi0 - cur.lo) >> 1;
         // copies: this wave's pieces of an image, 1 KiB each: SGPR base + per-lane offset
@@ -697,14 +699,16 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
           const int ord_s = (MD_PHASE_ORDERS > 1) ? ((MD_PHASE_ORDERS == 2) ? ((wave >> 2) & 1) : (wave >> 2) % 3) : 0;
           if (ord_s != 1) steady_stage(src_next, voff0, xn_b, npieces_s, wave, nwaves);
           if (ord_s == 0) pk_run = steady_peak(xs_v, pk_p0, pk_phi, nthr, pk_run);
-#pragma unroll
-          for (int u = 0; u < kSlots; ++u) {
-            if (u < ntask_w) {
+          {
+            int xo = xoff0, io = io_base + ioff0;
+            uint32_t pht = ph0;
+            for (int u = 0; u < ntask_w; ++u) {
               md_f4 acc[kG];
-              mm_task_dots<kG, (kMm ? NJ : 1)>((lds_cf2)(size_t)(xs_b + (unsigned)xoff[u]), bre, bim, acc);
-              mm_fold_rotate_stage<kG, R>(acc, lane_l, true, phs[u], ys, a.ycap, io_base + ioff[u]);
-              phs[u] += dph;
+              mm_task_dots<kG, (kMm ? NJ : 1)>((lds_cf2)(size_t)(xs_b + (unsigned)xo), bre, bim, acc);
+              mm_fold_rotate_stage<kG, R>(acc, lane_l, true, pht, ys, a.ycap, io);
+              xo += dxo; io += dio; pht += dph_t;
             }
+            ph0 += dph;
           }
           if (ord_s == 1) steady_stage(src_next, voff0, xn_b, npieces_s, wave, nwaves);
           if (ord_s != 0) pk_run = steady_peak(xs_v, pk_p0, pk_phi, nthr, pk_run);
@@ -1019,10 +1023,15 @@ int md_dispatch_r(int up, int kpad, int threads, F& f) {
   // 255-tap prototypes at UP = 3 (the BASELINE configurations) have 96 taps per branch
   if (kpad == 96) return f.template go<R, 6, 1024, 0, 0>();
   // the default 1001-tap prototype at UP = 6 (1, 5, 7 MS/s -> 48 kHz: FT8:42, FT8FT4:34, FT8dual:43): 167 taps per branch, eleven
-  // tap pairs per lane and RX held in registers by six groups of waves (one or two sub-receivers; more do not fit the 24 pairs
-  // a 1024-thread wave may hold and run the generic form)
+  // tap pairs per lane held in registers by six groups of waves (one sub-receiver; two with MD_UP6_MM > 2) ...
+#if MD_UP6_MM
+  // ... and on the matrix cores (12 waves, two per branch) from MD_UP6_MM sub-receivers
+  if constexpr (R >= MD_UP6_MM && R <= 6) {
+    if (kpad == 176 && up == 6 && threads == 1024) return f.template go<R, 11, 768, 0, 1>();
+  }
+#endif
 #if MD_UP6_HOLD
-  if constexpr (R <= 2) {
+  if constexpr (R <= 2 && (MD_UP6_MM == 0 || R < MD_UP6_MM)) {
     if (kpad == 176 && up == 6 && threads == 1024) return f.template go<R, 11, 1024, 0, 0>();
   }
 #endif

@@ -192,7 +192,7 @@ def test_no_shipped_kernel_uses_scratch():
     pysdr_amd/build.py uses.  What is checked is the hazard itself -- no `scratch_*` / private `buffer_*` instruction in any
     kernel, no spilled vector register -- and, for every kernel but the ones named below, an empty stack frame as well.  The
     matrix-core shapes of mixdec.hip (round 6) are AT the scalar-register limit: hipcc gives them a frame of 36 bytes for
-    scalar-spill slots that it then serves from VGPR lanes (v_writelane / v_readlane; `-Rpass-analysis=stack-frame-layout`:
+    scalar-spill slots (36 - 68 bytes) that it then serves from VGPR lanes (v_writelane / v_readlane; `-Rpass-analysis=stack-frame-layout`:
     "Spill, Size: 32" + one variable) without emitting a single memory instruction for it."""
     from concurrent.futures import ThreadPoolExecutor
     from pysdr_amd import build as pb                                        # SOURCES, EXTRA_FLAGS: importing builds nothing
@@ -202,7 +202,7 @@ def test_no_shipped_kernel_uses_scratch():
         return f, _isa(f, ["-fPIC", *pb.EXTRA_FLAGS.get(f, [])])
 
     def lane_served(fname, kname):
-        return fname == "mixdec.hip" and re.search(r"mixdec_kernelILi\d+ELi21ELi(768|512)ELi\d+ELi1E", kname or "") is not None
+        return fname == "mixdec.hip" and re.search(r"mixdec_kernelILi\d+ELi(21|11)ELi(768|512)ELi\d+ELi1E", kname or "") is not None
 
     bad, nk, framed = [], 0, []
     with ThreadPoolExecutor(max_workers=4) as ex:
@@ -224,10 +224,10 @@ def test_no_shipped_kernel_uses_scratch():
                 if m:
                     nk += 1
                     if int(m.group(1)) != 0:
-                        if lane_served(f, name) and int(m.group(1)) <= 64:
+                        if lane_served(f, name) and int(m.group(1)) <= 128:
                             framed.append((name, int(m.group(1))))
                         else:
                             bad.append((f, name, int(m.group(1))))
     assert nk >= 40, nk
     assert not bad, bad
-    assert len(framed) <= 5, framed
+    assert len(framed) <= 10, framed
