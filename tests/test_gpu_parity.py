@@ -603,17 +603,19 @@ def test_a_call_of_many_thousand_blocks_equals_its_halves():
     first chunks equal the oracle's."""
     fs = 1e6
     cfg = dict(so.CONFIGS['C2'], fs=fs, ntaps_dec=1001,
-               carriers=[dict(f=0.1 * fs, kind='usb', amp=0.2, tone=1200.0), dict(f=-0.2 * fs, kind='usb', amp=0.1, tone=800.0)],
-               rx=[dict(frq=0.1 * fs, mode='USB', video_bw=45e3, af_bw=5e3), dict(frq=-0.2 * fs, mode='USB', video_bw=45e3, af_bw=5e3)])
+               carriers=[dict(f=0.1 * fs, kind='usb', amp=0.2, tone=1200.0), dict(f=-0.2 * fs, kind='fm', amp=0.1, tone=800.0, dev=2500.0)],
+               rx=[dict(frq=0.1 * fs, mode='USB', video_bw=45e3, af_bw=5e3), dict(frq=-0.2 * fs, mode='NFM', video_bw=10e3, af_bw=5e3)])
     L = so.chunk_sizes(fs, 48e3)[3]
     B = 6144
     x8 = so.synth_iq(cfg, 8 * L, 9)
     x = np.tile(x8, B // 8)
     P1, g1 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    g1[1].squelch_ratio = 2.0                 # (the ratio squelch keeps five arrays per block in that LDS instead of two)
     c1 = P1._pysdr_stream
     c1.process_batch(x, B, L, on_device=False)
     one = [c1.fetch(i, B) for i in range(2)]
     P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B // 2)
+    g2[1].squelch_ratio = 2.0
     c2 = P2._pysdr_stream
     halves = [[], []]
     for h in range(2):
@@ -626,7 +628,10 @@ def test_a_call_of_many_thousand_blocks_equals_its_halves():
         assert np.array_equal(iq, np.concatenate([halves[i][0][1], halves[i][1][1]])), i
         assert np.array_equal(pk, np.concatenate([halves[i][0][3], halves[i][1][3]])), i
         assert g1[i].agc.gain == g2[i].agc.gain
-    for i, o in enumerate(so.make_receivers(cfg, np.float32)):
+    assert g1[1].squelch_ratio_state == g2[1].squelch_ratio_state
+    ro = so.make_receivers(cfg, np.float32)
+    ro[1].squelch_ratio = np.float32(2.0)
+    for i, o in enumerate(ro):
         want = np.concatenate([o.demod_data(x[k * L:(k + 1) * L]) for k in range(6)])
         assert relerr(one[i][0][:len(want)], want) <= TOL, i
 
