@@ -107,6 +107,9 @@ def parse(argv=None):
                     help="after the timed loop every rank checks the LAST step's device buffers against the float32 "
                          "oracle (first 2 chunks per sub-receiver, PSD frame 0); default ON")
     ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="default command only: do not measure the HBM traffic of this run in two rocprofv3 --pmc child passes "
+                         "(the line then carries the stored figure of profiles/, guarded by source hashes)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="the default command (workload c3, 1 GPU) also runs c1, c2 and c4 at their default batch for --steps "
                          "steps each, in child processes AFTER its own timed loop, and reports them as `other_configs` "
@@ -619,6 +622,47 @@ def measured_traffic(args, nrx, B, kernel_prefix, sources):
     return None, None
 
 
+def live_traffic(args):
+    """HBM traffic of THIS run's kernels, measured now: two child passes of this same command (3 steps each) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- counters in passes of their own, never beside a trace, as
+    MI355X_MICROARCH.md prescribes -- -> {kernel: bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB}.  Launches of the
+    full batch only (within a factor two of the largest of a kernel).  None where rocprofv3 is missing or a pass fails: the line
+    then carries the stored, hash-guarded figure of profiles/ (measured_traffic) as before."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    per = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        td = tempfile.mkdtemp(prefix="pysdr_pmc_", dir="/tmp")
+        cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", td, "--", sys.executable, os.path.abspath(__file__),
+               "--no-cpu-baseline", "--no-host-fed", "--no-other-configs", "--no-verify", "--full-line", "--steps", "3", "--warmup", "1"]
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, TMPDIR="/tmp"))
+            if p.returncode != 0:
+                return None
+            vals = {}
+            for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == ctr and "pysdr" in r.get("Kernel_Name", ""):
+                        m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+                        vals.setdefault(m.group(1) if m else r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            if not vals:
+                return None
+            for k, v in vals.items():
+                v = [x for x in v if x >= 0.5 * max(v)]
+                per.setdefault(k, {})[ctr] = sum(v) / len(v)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    return {k: (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 for k, v in per.items()}
+
+
 def other_configs(args):
     """The other single-GPU configurations (BASELINE.json configs[0], [1], [3]; mono FM, MAX_RX = 6, AM-Synch) through this
     same tool, one child process each, AFTER the C3 loop has been timed and its buffers freed: throughput, step time, the
@@ -709,7 +753,8 @@ def compact_line(out, full_path):
         line["roofline"] = {"bound": r["bound"], "achieved": _sig(r["achieved"]), "peak": r["peak"], "unit": r["unit"], "frac": _sig(r["frac"], 4),
                             "traffic": _sig(r.get("traffic"), 5), "traffic_ratio": _sig(ratio, 4),
                             "traffic_source": ("none" if not r.get("traffic_source") else ("stale profile" if r.get("traffic") is None else
-                                               r["traffic_source"].split(" (")[0] + " (stored PMC passes, source-hash guarded)")),
+                                               ("live: 2 rocprofv3 --pmc child passes of this command" if r["traffic_source"].startswith("live") else
+                                                r["traffic_source"].split(" (")[0] + " (stored PMC passes, source-hash guarded)"))),
                             "kernel": r["kernel"].split(" (")[0], "avg_launch_ms": _sig(r["avg_launch_ms"])}
     else:
         line["roofline"] = None
@@ -1053,10 +1098,12 @@ def main():
                    measured_traffic(args, nrx, B, "mixdec", ["mixdec_mfma.hip", "mixdec_mfma_geom.h"] if (mfma_on and not is_wfm)
                                     else (["mixdec_mfma.hip", "mixdec_mfma_geom.h", "resamp_small.hip"] if mfma_on else ["mixdec.hip"])))
     psd_tr = measured_traffic(args, nrx, B, "psd", ["psdfft.hip"])
+    psd_pairs_per_call = None
     if psd_tr[0] is not None and sp is not None and sp_tune[0] > 0:
         # the profile's figure is per launch pair of one group of frames; one call = nframes / group of them
         per_launch = -(-int(sp_tune[0]) // max(1, int(sp_tune[2])))          # frames of one cols + rows launch pair
-        psd_tr = (psd_tr[0] * nframes / float(per_launch), psd_tr[1] + f"; per launch pair of {per_launch} frames, scaled to the call")
+        psd_pairs_per_call = nframes / float(per_launch)
+        psd_tr = (psd_tr[0] * psd_pairs_per_call, psd_tr[1] + f"; per launch pair of {per_launch} frames, scaled to the call")
     r_psd = roof("psd_cols_pk + psd_rows_pk (window, zero-pad, 64k four-step FFT with a 24-bit intermediate, |.|^2, dB, fftshift)"
                  if (sp is not None and sp_tune[3]) else "psd kernels (window, zero-pad, 64k FFT, |.|^2, dB, fftshift)",
                  psd_bytes, psd_ms, psd_tr,
@@ -1163,6 +1210,20 @@ def main():
     if (rank == 0 and world == 1 and args.workload == "c3" and not args.no_other_configs and not args.no_demod
             and not args.nrx and not args.no_psd and not args.chunks and not args.ntaps):
         out["other_configs"] = other_configs(args)
+        if not args.no_live_traffic:
+            lt = live_traffic(args)
+            if lt:
+                src = "live: two rocprofv3 --pmc child passes of this command, 3 steps each (2*FETCH_SIZE + WRITE_SIZE)"
+                psd_live = lt.get("psd_cols_pk_kernel", 0.0) + lt.get("psd_rows_pk_kernel", 0.0)
+                for key in ("roofline", "roofline_psd", "roofline_mixdec"):
+                    r = out.get(key)
+                    if not r:
+                        continue
+                    if r["kernel"].startswith("psd") and psd_live > 0 and psd_pairs_per_call:
+                        r["traffic"], r["traffic_source"] = psd_live * psd_pairs_per_call, src + "; per launch pair, scaled to the call"
+                    elif r["kernel"].startswith("mixdec_kernel") and lt.get("mixdec_kernel", 0.0) > 0:
+                        r["traffic"], r["traffic_source"] = lt["mixdec_kernel"], src
+                out["live_traffic_bytes_per_launch"] = {k: round(v) for k, v in sorted(lt.items())}
     if rank == 0:
         try:                     # RCCL prints a version banner through C stdio: the JSON stays the LAST line
             C.CDLL(None).fflush(None)
