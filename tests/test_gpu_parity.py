@@ -596,6 +596,48 @@ def test_steady_runs_equal_the_generic_tile_loop_bit_for_bit(name, monkeypatch):
             assert list(cn) == list(cn0)
 
 
+_EXOTIC = {
+    # am.bat:1 (`python am.py -fake -fc 15e3 -fsout 44.1`): 2.048 MS/s -> 44.1 kHz = 441/20480, three taps per branch
+    "am.bat 44.1 kHz": dict(fs=2.048e6, fs_out=44.1e3, rx=[dict(frq=15e3, mode='AM', video_bw=10e3, af_bw=5e3)]),
+    # startup4 (`pySDR.py -fc 600 760 -audio 2 -fs 1`): two AM broadcast stations at 1 MS/s (6/125)
+    "two AM at 1 MS/s": dict(fs=1e6, rx=[dict(frq=-80e3, mode='AM', video_bw=10e3, af_bw=5e3), dict(frq=80e3, mode='AM', video_bw=10e3, af_bw=5e3)]),
+    # startup2-6 / PANADAPTOR (`-mode IQ -fsout $FS -af_bw 45 -vid_bw 45`): the panadaptor's IQ tap at 2 MS/s (3/125)
+    "IQ 45 kHz at 2 MS/s": dict(fs=2e6, rx=[dict(frq=100e3, mode='IQ', video_bw=45e3, af_bw=45e3)]),
+    # startup (`-mode CW -fsout 48 -vid_bw 45 -af_bw .5`) at 2 MS/s
+    "CW 500 Hz at 2 MS/s": dict(fs=2e6, rx=[dict(frq=-150e3, mode='CW', video_bw=45e3, af_bw=500.0, bfo=700.0)]),
+    # startup5/6 (`-mode USB -af_bw 10 -vid_bw 45`)
+    "USB 10 kHz at 2 MS/s": dict(fs=2e6, rx=[dict(frq=50e3, mode='USB', video_bw=45e3, af_bw=10e3)]),
+    # the ends of the rate tables (Tables.py:44-45): 0.25 MS/s = 24/125, 0.5 = 12/125, 3.2 = 3/200, 2.88 = 1/60, 2.16 = 1/45, 9 = 2/375, 7 = 6/875
+    "0.25 MS/s": dict(fs=0.25e6, rx=[dict(frq=20e3, mode='USB', video_bw=10e3, af_bw=3e3)]),
+    "0.5 MS/s x 2": dict(fs=0.5e6, rx=[dict(frq=40e3, mode='USB', video_bw=10e3, af_bw=3e3), dict(frq=-60e3, mode='NFM', video_bw=20e3, af_bw=4e3)]),
+    "3.2 MS/s": dict(fs=3.2e6, rx=[dict(frq=300e3, mode='AM', video_bw=10e3, af_bw=5e3)]),
+    "2.88 MS/s": dict(fs=2.88e6, rx=[dict(frq=-300e3, mode='NFM', video_bw=20e3, af_bw=4e3)]),
+    "2.16 MS/s": dict(fs=2.16e6, rx=[dict(frq=200e3, mode='LSB', video_bw=10e3, af_bw=3e3)]),
+    "9 MS/s x 3": dict(fs=9e6, rx=[dict(frq=1e6, mode='USB', video_bw=45e3, af_bw=5e3), dict(frq=-2e6, mode='USB', video_bw=45e3, af_bw=5e3),
+                                    dict(frq=3e6, mode='CW', video_bw=45e3, af_bw=500.0, bfo=700.0)]),
+    "7 MS/s x 5": dict(fs=7e6, rx=[dict(frq=(k - 2) * 0.9e6, mode='USB', video_bw=45e3, af_bw=5e3) for k in range(5)]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_EXOTIC))
+def test_operating_points_from_the_launch_scripts_and_the_ends_of_the_rate_tables(name):
+    """Found by walking the reference's launch scripts and rate tables instead of the BASELINE configurations (round 6: a batch
+    at 1 MS/s failed outright): odd output rates, the panadaptor's IQ tap, the narrow CW filter on the wide video filter, the
+    lowest and the highest rates of both devices -- default 1001-tap prototype, whole and ragged chunks, every sample against the
+    oracle."""
+    e = _EXOTIC[name]
+    fs, fs_out = e['fs'], e.get('fs_out', 48e3)
+    kinds = {'AM': 'am', 'NFM': 'fm', 'USB': 'usb', 'LSB': 'cw', 'CW': 'cw', 'IQ': 'usb'}
+    cfg = dict(fs=fs, fs_out=fs_out, ntaps_dec=1001, noise=2e-3,
+               # (LSB: a carrier 1 kHz BELOW the dial -- a signal in the other sideband leaves 0.004 of full scale behind the filter,
+               #  and 1e-5 of THAT is below the float32 rounding of the sums that cancel to it, in the oracle as in the kernel)
+               carriers=[dict(f=r['frq'] - (1000.0 if r['mode'] == 'LSB' else 0.0), kind=kinds[r['mode']], amp=0.2, tone=900.0 + 150 * i, depth=0.5,
+                              dev=2500.0) for i, r in enumerate(e['rx'])],
+               rx=e['rx'])
+    L = so.chunk_sizes(fs, fs_out)[3]
+    run_both(cfg, [L, L, 777, L - 5, 2 * L + 3], seed=21)
+
+
 def test_a_call_of_many_thousand_blocks_equals_its_halves():
     """1 MS/s (FT8:42): a chunk is 21333 samples, so a resident batch of the size the other workloads use is 6000+ AGC blocks
     -- above ~5500 the block recursion's LDS passes what a kernel gets without asking for it (launch_agc_scan), and until
