@@ -596,6 +596,39 @@ def test_steady_runs_equal_the_generic_tile_loop_bit_for_bit(name, monkeypatch):
             assert list(cn) == list(cn0)
 
 
+def test_the_largest_call_a_context_takes_equals_its_halves():
+    """max_chunks = 16384 (pysdr_create's bound: the AGC scan keeps a call's blocks in LDS, 141 KB there) at the lowest rate of
+    the tables (0.25 MS/s, 24/125: 5333 samples per chunk), an AM and an AM-Synch sub-receiver: 16384 AGC blocks, 8192 carrier-loop
+    segments in one call.  AM: bit for bit the two half calls; AM-Synch: within the parity bar of them (segment joins move)."""
+    fs = 0.25e6
+    cfg = dict(so.CONFIGS['C1'], fs=fs, ntaps_dec=1001,
+               carriers=[dict(f=30e3, kind='am', amp=0.3, tone=1000.0, depth=0.5), dict(f=-50e3 + 3.0, kind='am', amp=0.2, tone=700.0, depth=0.6)],
+               rx=[dict(frq=30e3, mode='AM', video_bw=10e3, af_bw=5e3), dict(frq=-50e3, mode='AM-Synch', video_bw=10e3, af_bw=5e3)])
+    L = so.chunk_sizes(fs, 48e3)[3]
+    B = 16384
+    x = np.tile(so.synth_iq(cfg, 64 * L, 19), B // 64)        # (a carrier phase step every 64 chunks: the loop re-acquires, in both cuts alike)
+    P1, g1 = make_gpu_receivers(cfg, max_batch_chunks=B)
+    c1 = P1._pysdr_stream
+    c1.process_batch(x, B, L, on_device=False)
+    one = [[np.array(v).copy() for v in c1.fetch(i, B)] for i in range(2)]
+    P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=B // 2)
+    c2 = P2._pysdr_stream
+    halves = [[], []]
+    for h in range(2):
+        c2.process_batch(x[h * (B // 2) * L:(h + 1) * (B // 2) * L], B // 2, L, on_device=False)
+        for i in range(2):
+            halves[i].append([np.array(v).copy() for v in c2.fetch(i, B // 2)])
+    both = [[np.concatenate([halves[i][0][j], halves[i][1][j]]) for j in range(4)] for i in range(2)]
+    assert np.array_equal(one[0][0], both[0][0]) and np.array_equal(one[0][1], both[0][1])
+    assert np.array_equal(one[1][1], both[1][1])                                     # (the baseband in front of the loop)
+    assert np.array_equal(one[0][3], both[0][3])
+    assert relerr(one[1][0][1024:], both[1][0][1024:]) <= TOL
+    o = so.make_receivers(cfg, np.float32)
+    for i in range(2):
+        want = np.concatenate([o[i].demod_data(x[k * L:(k + 1) * L]) for k in range(40)])
+        assert relerr(one[i][0][1024:len(want)], want[1024:]) <= TOL, i
+
+
 _EXOTIC = {
     # am.bat:1 (`python am.py -fake -fc 15e3 -fsout 44.1`): 2.048 MS/s -> 44.1 kHz = 441/20480, three taps per branch
     "am.bat 44.1 kHz": dict(fs=2.048e6, fs_out=44.1e3, rx=[dict(frq=15e3, mode='AM', video_bw=10e3, af_bw=5e3)]),
@@ -922,6 +955,30 @@ def test_c4_wbfm_10msps(stereo, grid, monkeypatch):
         amp = lambda s, f: 2 * abs(np.mean(s * np.exp(-2j * np.pi * f * t)))
         assert amp(ag.real, 1000.0) > 10 * amp(ag.real, 2500.0)
         assert amp(ag.imag, 2500.0) > 5 * amp(ag.imag, 1000.0)
+
+
+@pytest.mark.parametrize("fs", [1.024e6, 2.048e6, 2.56e6, 3.2e6, 2e6, 4e6, 8e6])
+def test_broadcast_fm_at_the_other_rates_of_the_tables(fs):
+    """Broadcast FM (WFM2: pilot PLL, stereo) away from BASELINE's 10 MS/s: the RTL rates one really listens to FM on and the
+    SDRplay ones (Tables.py:44-45) -- another IF decimation (the divisor of the rate closest to 250 kHz), another audio
+    resampler ratio, and below ~2 MS/s an IF decimator that is not the matrix-core one.  Four chunks against the serial oracle."""
+    from oracle import wfm_oracle as wo
+    from pysdr_amd import sig_proc
+    from pysdr_amd.params import RunTimeParams
+    L = so.chunk_sizes(fs, 48e3)[3]
+    n = 4
+    foff = 0.12 * fs
+    x = wo.synth_wfm(fs, n * L, 5, f_carrier=foff)
+    P = RunTimeParams(fs=fs, fc=[98.1e6], mode='WFM2', nfilt=255, foffset=foff, vid_bw=200e3)
+    g = sig_proc.Receiver(P, foff, 0, '1')
+    o = wo.WfmReceiver(fs, 48e3, foff, stereo=True, ntaps_dec=255, dtype=np.float32)
+    assert (g.demod.wfm_d1, g.demod.wfm_up2, g.demod.wfm_down2) == (o.d1, o.up2, o.down2)
+    for k in range(n):
+        xc = x[k * L:(k + 1) * L]
+        ag, ao = g.demod_data(xc), o.demod_data(xc)
+        assert ag.shape == ao.shape
+        assert relerr(g.iq, o.iq) <= TOL, (k, 'iq', relerr(g.iq, o.iq))
+        assert relerr(ag, ao) <= TOL, (k, 'am', relerr(ag, ao))
 
 
 def test_wfm_cannot_mix_with_narrowband_in_one_context():
