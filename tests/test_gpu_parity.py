@@ -259,6 +259,48 @@ def test_retune_and_filter_swap_on_the_matrix_core_path():
         assert relerr(am_g, am_o) <= TOL, (k, 'am')
 
 
+def test_retune_and_filter_swap_on_the_multi_rx_matrix_core_shapes():
+    """... and on the 4x4x1 shapes (FT8tri: three USB sub-receivers, 1001 taps): the waves load their tap operands from memory at
+    every launch, so a retune of one sub-receiver, a filter swap of another and a mode change of the third take effect at the
+    next chunk, phase continuous -- live chunks first, then the same stream in batches of three with the controls between batches."""
+    cfg = so.CONFIGS['FT8TRI']
+    L = so.chunk_sizes(cfg['fs'], cfg['fs_out'])[3]
+    x = so.synth_iq(cfg, 12 * L, 23)
+
+    def controls(k, g, o):
+        if k == 3:
+            fa, fb = g[1].lo.change_freq(-2975.3e3), o[1].lo.change_freq(-2975.3e3)
+            assert fa == pytest.approx(fb, abs=1e-9)
+        if k == 6:
+            g[0].dec.h = g[0].dec.filter_bank[4]
+            o[0].dec.set_taps(o[0].dec.filter_bank[4])
+            g[2].mode, g[2].af_bw = 'AM', 5e3                # (a detector whose output is not the stop band of a narrow filter)
+            o[2].set_mode('AM', af_bw=5e3)
+        if k == 9:
+            g[1].lo.change_freq(-2974e3), o[1].lo.change_freq(-2974e3)
+
+    P, g = make_gpu_receivers(cfg)
+    o = so.make_receivers(cfg, np.float32)
+    live = [[] for _ in g]
+    for k in range(12):
+        controls(k, g, o)
+        xc = x[k * L:(k + 1) * L]
+        for i, (rg, ro) in enumerate(zip(g, o)):
+            am_g, am_o = rg.demod_data(xc), ro.demod_data(xc)
+            assert relerr(rg.iq, ro.iq) <= TOL, (k, i, 'iq')
+            assert relerr(am_g, am_o) <= TOL, (k, i, 'am')
+            live[i].append(am_g.copy())
+    P2, g2 = make_gpu_receivers(cfg, max_batch_chunks=3)
+    o2 = so.make_receivers(cfg, np.float32)
+    ctx = P2._pysdr_stream
+    for k in range(0, 12, 3):
+        controls(k, g2, o2)
+        ctx.process_batch(x[k * L:(k + 3) * L], 3, L, on_device=False)
+        for i in range(3):
+            am = ctx.fetch(i, 3)[0]
+            assert np.array_equal(am, np.concatenate(live[i][k:k + 3])), (k, i)
+
+
 @pytest.mark.parametrize("grid", [0, 5])
 def test_batch_equals_chunked_bit_exact(grid, monkeypatch):
     """One launch over B chunks == B single-chunk calls (sigs/iir.py:83-125 property),
