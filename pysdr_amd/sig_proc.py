@@ -38,15 +38,17 @@ def _device_of(P):
 
 
 def _chunk_key(x):
-    """Identity of a chunk for the per-chunk cache of ``Receiver.demod_data``: where it lives, how long it is and 16 of its
-    samples (a buffer reused in place for the next chunk keeps its address; its contents do not stay)."""
-    where = x.__array_interface__['data'][0] if isinstance(x, np.ndarray) else 0     # (a list becomes a NEW array on every call: no address)
+    """Identity of a chunk for the per-chunk cache of ``Receiver.demod_data``: how long it is and 32 of its samples.  NOT where
+    it lives: a buffer reused in place for the next chunk keeps its address while its contents change, and a caller that hands
+    every sub-receiver its own copy of the chunk (a slice of an ``np.load`` archive is a new array on every access) has one
+    chunk at several addresses -- with the address in the key such a caller ran the stream once per sub-receiver, or not,
+    as the allocator happened to reuse memory (found by tests/test_golden.py in round 6)."""
     x = np.asarray(x)
     n = x.shape[0] if x.ndim else 0
     if n == 0:
-        return (0, 0, b'')
-    idx = (np.arange(16, dtype=np.int64) * (n - 1)) // 15
-    return (where, n, x[idx].tobytes())
+        return (0, b'')
+    idx = (np.arange(32, dtype=np.int64) * (n - 1)) // 31
+    return (n, x[idx].tobytes())
 
 
 # ----------------------------------------------------------------------------------------
@@ -407,12 +409,13 @@ class Receiver:
     def demod_data(self, x):
         """``rx.demod_data(x)`` (``receiver.py:235``).  The sub-receivers of a stream share ONE launch sequence per chunk: the
         first of them to be handed a chunk runs it for all, the others take their share from the cache.  WHICH chunk the
-        cache holds is decided by the chunk itself (buffer address, length and a fingerprint of 16 of its samples), not by
+        cache holds is decided by the chunk itself (its length and a fingerprint of 32 of its samples), not by
         counting calls: a caller that leaves a sub-receiver out for a chunk (the reference's MP_SCHEME 3 workers each call
         their own ``rx``, ``receiver.py:726-739``) then neither shifts that receiver onto the previous chunk's results nor
         the others onto a chunk that was never run.  The same receiver asking twice for the same samples runs them twice
-        (a stream may repeat).  What this cannot tell apart: two different chunks with the same address, length and
-        fingerprint (all-zero chunks) when a receiver skipped the first of them -- it then gets the first one's share."""
+        (a stream may repeat).  What this cannot tell apart: two different chunks with the same length and
+        fingerprint (all-zero chunks, a stream that repeats chunk for chunk) when a receiver skipped the first of them -- it
+        then gets the first one's share."""
         ctx = self._ctx
         key = _chunk_key(x)
         with ctx.lock:

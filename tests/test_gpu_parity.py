@@ -755,7 +755,7 @@ def test_a_call_of_many_thousand_blocks_equals_its_halves():
 
 def test_a_sub_receiver_left_out_for_a_chunk_does_not_shift_anyones_chunks():
     """The sub-receivers of a stream share one launch sequence per chunk (sig_proc.Receiver.demod_data).  Which chunk the
-    shared results belong to is decided by the chunk (address, length, fingerprint), not by counting calls: chunk 1 is asked
+    shared results belong to is decided by the chunk (length + a fingerprint of its samples), not by counting calls: chunk 1 is asked
     for by RX 0 only, chunk 2 by RX 1 FIRST -- it must get chunk 2's audio, not chunk 1's (with call counting it
     silently did), and RX 0 behind it shares that launch; asking twice for the same samples runs them twice."""
     cfg = dict(so.CONFIGS['C3'], rx=so.CONFIGS['C3']['rx'][:2])
@@ -781,6 +781,15 @@ def test_a_sub_receiver_left_out_for_a_chunk_does_not_shift_anyones_chunks():
     assert ctx.seq == 5
     g[0].demod_data(buf)                                               # the same samples again: a stream may repeat
     assert ctx.seq == 6
+    # every sub-receiver is handed its OWN copy of the chunk (a slice of an np.load archive is a new array on every access:
+    # tests/test_golden.py): one chunk, one launch, whatever addresses the copies have
+    keep = []
+    for k in (1, 2, 3):
+        for i in range(2):
+            cp = np.array(x[k * L:(k + 1) * L])
+            keep.append(cp)                                            # (held, so that no two copies share an address)
+            g[i].demod_data(cp)
+        assert ctx.seq == 6 + k
 
 
 def test_long_prototype_1001_taps_and_10msps():
