@@ -695,6 +695,16 @@ __device__ __forceinline__ void fir_run(const float* sre, const float* sim, cons
   for (int j = 0; j < kW; ++j) acc[j] = make_float2(ax[j].x + ax[j].y, ay[j].x + ay[j].y);
 }
 
+// fixed-point form of one term of the squelch's block sums, and its inverse (see fir_epilogue): 2^48 per unit -- terms are weights
+// <= 1e-3 times |detector output| <= ~10, a block has <= ~8k of them: the sum stays below 2^63 with room to spare
+constexpr double kSqFix = 281474976710656.0;
+__device__ __forceinline__ unsigned long long sq_fix(float v) { return __double2ull_rn((double)v * kSqFix); }
+__device__ __forceinline__ float sq_unfix(unsigned long long q) { return (float)((double)q * (1.0 / kSqFix)); }
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int o) {
+  const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 // What both forms of the kernel (packed FMAs below, matrix cores further down) do with a thread's eight consecutive outputs
 // acc[0..8) = outputs i0 + 8 tid ..: store them, and fold their magnitudes into the block peaks (and the squelch's noise sums).
 template <bool CPLX>
@@ -727,7 +737,12 @@ __device__ __forceinline__ void fir_epilogue(const Stage2Args& a, int r, int det
     }
   }
   const uint32_t wb0 = __shfl(blk_lo, 0);                 // lanes ascend: lane 0 invalid = wave invalid
-  float m0 = 0.f, m1 = 0.f, nz0 = 0.f, nz1 = 0.f, lz0 = 0.f, lz1 = 0.f;
+  // The squelch's block sums are accumulated as 64-bit FIXED-POINT integers (kSqFix = 2^48 per unit): integer addition is
+  // associative, so a block's sum does not depend on how a call's waves and lanes happen to partition it, nor on the order their
+  // atomics arrive in -- as float sums they were reproducible to an ulp, and batch == chunk by chunk held bit for bit only while
+  // the blocks kept their alignment to the waves (round 6: 1 MS/s, where a chunk is 1023.98 outputs, showed it).
+  float m0 = 0.f, m1 = 0.f;
+  unsigned long long nz0 = 0ull, nz1 = 0ull, lz0 = 0ull, lz1 = 0ull;
   unsigned cnt0 = 0u, cnt1 = 0u;
   // The RATIO squelch (sigs/squelch.m:92-145): z1 = low-pass < 3 kHz, z2 = high-pass > 4 kHz of the discriminator output
   // (FIRs of sq_ntaps taps over the staged detector values), per-sample one-pole envelopes of |z1|, |z2| with alpha = 0.001.
@@ -775,13 +790,14 @@ __device__ __forceinline__ void fir_epilogue(const Stage2Args& a, int r, int det
           const int e = kW * tid + H + 3 + j;             // S element of output ib+j
           hp = fabsf(sre[fir_pad(e)] - 2.f * sre[fir_pad(e - 1)] + sre[fir_pad(e - 2)]);
         }
-        if (slot == 0u) { m0 = fmaxf(m0, m); nz0 += hp; lz0 += lp; cnt0 += 1u; }
-        else if (slot == 1u) { m1 = fmaxf(m1, m); nz1 += hp; lz1 += lp; cnt1 += 1u; }
+        const unsigned long long hq = squelch ? sq_fix(hp) : 0ull, lq = ratio ? sq_fix(lp) : 0ull;
+        if (slot == 0u) { m0 = fmaxf(m0, m); nz0 += hq; lz0 += lq; cnt0 += 1u; }
+        else if (slot == 1u) { m1 = fmaxf(m1, m); nz1 += hq; lz1 += lq; cnt1 += 1u; }
         else {
           const size_t k = ((size_t)r * a.nchunks + bj) * kBlkStride;
           atomicMax(a.blkpeak + k, __float_as_uint(m));
-          if (squelch) { atomicAdd(a.blknoise + k, hp); atomicAdd(a.blkcnt + k, 1u); }
-          if (ratio) atomicAdd(a.blknoise2 + k, lp);
+          if (squelch) { atomicAdd(reinterpret_cast<unsigned long long*>(a.blknoise + k), hq); atomicAdd(a.blkcnt + k, 1u); }
+          if (ratio) atomicAdd(reinterpret_cast<unsigned long long*>(a.blknoise2 + k), lq);
         }
       }
   }
@@ -790,12 +806,12 @@ __device__ __forceinline__ void fir_epilogue(const Stage2Args& a, int r, int det
   if (squelch) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      nz0 += __shfl_xor(nz0, o); nz1 += __shfl_xor(nz1, o);
+      nz0 += shfl_xor_u64(nz0, o); nz1 += shfl_xor_u64(nz1, o);
       cnt0 += __shfl_xor(cnt0, o); cnt1 += __shfl_xor(cnt1, o);
     }
     if (ratio) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { lz0 += __shfl_xor(lz0, o); lz1 += __shfl_xor(lz1, o); }
+      for (int o = 32; o > 0; o >>= 1) { lz0 += shfl_xor_u64(lz0, o); lz1 += shfl_xor_u64(lz1, o); }
     }
   }
   if ((tid & 63) == 0 && wb0 != 0xFFFFFFFFu) {
@@ -805,10 +821,10 @@ __device__ __forceinline__ void fir_epilogue(const Stage2Args& a, int r, int det
     if (m0 > 0.f) atomicMax(a.blkpeak + k0, __float_as_uint(m0));
     if (m1 > 0.f) atomicMax(a.blkpeak + k1, __float_as_uint(m1));
     if (squelch) {
-      if (cnt0) { atomicAdd(a.blknoise + k0, nz0); atomicAdd(a.blkcnt + k0, cnt0); }
-      if (cnt1) { atomicAdd(a.blknoise + k1, nz1); atomicAdd(a.blkcnt + k1, cnt1); }
-      if (ratio && cnt0) atomicAdd(a.blknoise2 + k0, lz0);
-      if (ratio && cnt1) atomicAdd(a.blknoise2 + k1, lz1);
+      if (cnt0) { atomicAdd(reinterpret_cast<unsigned long long*>(a.blknoise + k0), nz0); atomicAdd(a.blkcnt + k0, cnt0); }
+      if (cnt1) { atomicAdd(reinterpret_cast<unsigned long long*>(a.blknoise + k1), nz1); atomicAdd(a.blkcnt + k1, cnt1); }
+      if (ratio && cnt0) atomicAdd(reinterpret_cast<unsigned long long*>(a.blknoise2 + k0), lz0);
+      if (ratio && cnt1) atomicAdd(reinterpret_cast<unsigned long long*>(a.blknoise2 + k1), lz1);
     }
   }
 }
@@ -1019,11 +1035,13 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
     for (int c = tid; c < nch; c += 256) {
       const size_t k = ((size_t)r * a.nchunks + c) * kBlkStride;
       const unsigned n = a.blkcnt[k];
-      wH[px(c)] = a.blknoise[k];
-      wL[px(c)] = a.blknoise2[k];
+      unsigned long long* qh = reinterpret_cast<unsigned long long*>(a.blknoise + k);
+      unsigned long long* ql = reinterpret_cast<unsigned long long*>(a.blknoise2 + k);
+      wH[px(c)] = sq_unfix(*qh);
+      wL[px(c)] = sq_unfix(*ql);
       dk[px(c)] = n > 0u ? __builtin_amdgcn_exp2f(kSqLog2Decay * (float)n) : -1.f;
-      a.blknoise[k] = 0.f;
-      a.blknoise2[k] = 0.f;
+      *qh = 0ull;
+      *ql = 0ull;
       a.blkcnt[k] = 0u;
     }
     __syncthreads();
@@ -1082,8 +1100,9 @@ __global__ __launch_bounds__(256) void agc_scan_kernel(const Stage2Args a, const
     for (int c = tid; c < nch; c += 256) {
       const size_t k = ((size_t)r * a.nchunks + c) * kBlkStride;
       const unsigned n = a.blkcnt[k];
-      nz[px(c)] = n > 0u ? __fdiv_rn(a.blknoise[k], (float)n) : -1.f;
-      a.blknoise[k] = 0.f;
+      unsigned long long* qh = reinterpret_cast<unsigned long long*>(a.blknoise + k);
+      nz[px(c)] = n > 0u ? __fdiv_rn(sq_unfix(*qh), (float)n) : -1.f;
+      *qh = 0ull;
       a.blkcnt[k] = 0u;
     }
     __syncthreads();
