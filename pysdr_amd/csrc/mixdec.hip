@@ -333,6 +333,9 @@ __device__ __forceinline__ void fold_rotate_stage(const float2 (&A)[N], const fl
 #ifndef MD_LONG_MM
 #define MD_LONG_MM 1         // the long-prototype shapes of 2 - 4 sub-receivers on the matrix cores (A/B: 0 = vector form)
 #endif
+#ifndef MD_STEADY_VEC1
+#define MD_STEADY_VEC1 1     // steady runs for the vector shape <1,11> (1 MS/s x 1 RX: front end 0.376 -> 0.402 of HBM, 5 MS/s x 1: 0.735 -> 0.743; A/B: 0)
+#endif
 #ifndef MD_UP6_MM
 #define MD_UP6_MM 2          // 1001 taps at UP = 6: the matrix-core form from this many sub-receivers (0: never).  One box, front end as a fraction
                              // of HBM, matrix cores / vector form: 1 MS/s x 1 RX 0.32 / 0.375, x 2 0.31 / 0.27, x 3 0.245 / 0.187; 5 MS/s x 2 0.66 / 0.67,
@@ -496,6 +499,30 @@ __device__ __forceinline__ void mm_task_dots(lds_cf2 xr, const float (&bre)[G][N
   }
 }
 
+// Vector form of a task's dot products with the taps in registers, for the steady runs of the one vector shape that has them
+// (<1,11>: 1001 taps at UP = 6, one sub-receiver -- FT8:42,70, 1 MS/s, eight tasks per wave and tile): every read of x up front.
+template <int RH, int NJ>
+__device__ __forceinline__ void vec_task_dots(lds_cf2 xr, const float2 (&greg)[RH][NJ], float2 (&A)[RH], float2 (&B)[RH]) {
+  constexpr int kTop = 16 * (NJ - 1);
+  float2 xg[NJ];
+#pragma unroll
+  for (int u = 0; u < NJ; ++u) xg[u] = lds_ld(xr, kTop - 16 * u);
+#pragma unroll
+  for (int r = 0; r < RH; ++r) { A[r] = make_float2(0.f, 0.f); B[r] = make_float2(0.f, 0.f); }
+#pragma unroll
+  for (int u = 0; u < NJ; ++u) {
+    const float2 xv = xg[u];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+      const float2 gg = greg[r][u];
+      A[r].x = fmaf(gg.x, xv.x, A[r].x);
+      A[r].y = fmaf(gg.y, xv.x, A[r].y);
+      B[r].x = fmaf(gg.x, xv.y, B[r].x);
+      B[r].y = fmaf(gg.y, xv.y, B[r].y);
+    }
+  }
+}
+
 template <int R, int NJ, int TPB, int NHX, int MM>
 __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -639,7 +666,8 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
     // (LDS-DMA pieces inside the call) and owned by ONE chunk (fast peak) is found by two divisions, its per-lane constants are
     // set up once, and its tiles run a loop that only adds.  Same reads, same MFMA chains, same block reduction, same phases:
     // bit for bit the generic body's results (tests: every cut-independence test crosses both paths; MD_STEADY=0 for the A/B).
-    if constexpr (kMm && MD_STEADY) {
+    constexpr bool kSteadyVec = !kMm && kCanHold && R == 1 && NJ == 11 && MD_STEADY_VEC1;     // ... and one vector shape, below
+    if constexpr ((kMm && MD_STEADY) || kSteadyVec) {
       int run = 0;
       const int dq = a.dq_tile;
       const int npieces_s = (cur.npairs + 63) >> 6;
@@ -665,17 +693,19 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
         const int rho = lane_l >> 4;
         uint32_t ep_p0 = 0u, ep_fw = 0u;
         {
-          const int rx = 2 * ((lane_l >> 2) & 3) + ((lane_l & 3) >> 1);
+          // the lane that finishes a sample: matrix-core form (pair q, column j) of row rho; vector form lane s of row rho = RX rbase + s
+          const int rx = kMm ? 2 * ((lane_l >> 2) & 3) + ((lane_l & 3) >> 1) : hold_rbase + (lane_l & 15);
 #pragma unroll
           for (int r = 0; r < R; ++r)
             if (rx == r) { ep_p0 = a.phase0[r]; ep_fw = a.fword[r]; }
         }
+        const int vgd = kMm ? v_gdown : (lane_l >> 4) * a.down - (lane_l & 15);   // (vector shapes that recompute it per task: here per run)
         constexpr int kTopS = 16 * ((NJ > 0 ? NJ : 1) - 1);
         // this wave's tasks of a tile are quads hold_q0, hold_q0 + hold_step, ...: one more arithmetic progression, so the run keeps
         // the first task's per-lane constants and the step from task to task (any number of tasks per wave: 1 at 8 MS/s, 8 at 1 MS/s)
         const int qq0 = (ntask_w > 0) ? hold_q0 : 0;            // (waves without tasks: hold_q0 = 1 << 29)
         const int sb0 = d0 + (int)qcr + 4 * qq0 * a.down;
-        const int xoff0 = (sb0 + v_gdown - kTopS) * 8;          // bytes from the image's first sample: this lane's lowest read
+        const int xoff0 = (sb0 + vgd - kTopS) * 8;              // bytes from the image's first sample: this lane's lowest read
         const int ioff0 = hold_c + 4 * qq0 * a.up + rho * a.up;
         uint32_t ph0 = ep_p0 + ep_fw * (uint32_t)(sb0 + cur.lo + rho * a.down);
         const uint32_t dph = ep_fw * (uint32_t)dq;              // ... per tile
@@ -696,16 +726,22 @@ __global__ __launch_bounds__(TPB) void mixdec_kernel(const MixDecArgs a) {
           const float4* const xs_v = (const float4*)(const __attribute__((address_space(3))) float4*)(size_t)xs_b;
           dma_wait();
           __syncthreads();
-          const int ord_s = (MD_PHASE_ORDERS > 1) ? ((MD_PHASE_ORDERS == 2) ? ((wave >> 2) & 1) : (wave >> 2) % 3) : 0;
+          const int ord_s = (kMm && MD_PHASE_ORDERS > 1) ? ((MD_PHASE_ORDERS == 2) ? ((wave >> 2) & 1) : (wave >> 2) % 3) : 0;
           if (ord_s != 1) steady_stage(src_next, voff0, xn_b, npieces_s, wave, nwaves);
           if (ord_s == 0) pk_run = steady_peak(xs_v, pk_p0, pk_phi, nthr, pk_run);
           {
             int xo = xoff0, io = io_base + ioff0;
             uint32_t pht = ph0;
             for (int u = 0; u < ntask_w; ++u) {
-              md_f4 acc[kG];
-              mm_task_dots<kG, (kMm ? NJ : 1)>((lds_cf2)(size_t)(xs_b + (unsigned)xo), bre, bim, acc);
-              mm_fold_rotate_stage<kG, R>(acc, lane_l, true, pht, ys, a.ycap, io);
+              if constexpr (kMm) {
+                md_f4 acc[kG];
+                mm_task_dots<kG, (kMm ? NJ : 1)>((lds_cf2)(size_t)(xs_b + (unsigned)xo), bre, bim, acc);
+                mm_fold_rotate_stage<kG, R>(acc, lane_l, true, pht, ys, a.ycap, io);
+              } else {
+                float2 A[RH], B[RH];
+                vec_task_dots<RH, (kCanHold && !kMm) ? NJ : 1>((lds_cf2)(size_t)(xs_b + (unsigned)xo), greg, A, B);
+                fold_rotate_stage<RH>(A, B, hold_rcount, hold_rbase, lane_l & 15, true, 0u, pht, 0u, ys, a.ycap, io);
+              }
               xo += dxo; io += dio; pht += dph_t;
             }
             ph0 += dph;
